@@ -1,0 +1,533 @@
+// C-ABI entry points of libexl_amd.so (declared in include/exl_amd.h): argument checking, handle / buffer
+// registries, threshold dispatch and the fused decode compositions.  Mirrors the pybind layer of the
+// reference, /root/reference/exllama_ext/exllama_ext.cpp, function by function (citations in the header).
+#include "common.h"
+
+#include <math.h>
+#include <mutex>
+#include <string.h>
+#include <unordered_set>
+#include <vector>
+
+// ---- errors -------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void exl_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* exl_last_error(void) { return g_err; }
+extern "C" int exl_version(void) { return 100; }
+
+// ---- tuning (reference defaults: model.py:94-103) --------------------------------------------------------
+ExlTuning g_tuning = {8, 2, 8, 0, 0, 0, 0, 0, 0};
+
+extern "C" int exl_set_tuning(const ExlTuning* t)
+{
+    EXL_REQUIRE(t, EXL_E_INVALID, "exl_set_tuning: null");
+    g_tuning = *t;
+    return 0;
+}
+
+extern "C" int exl_get_tuning(ExlTuning* t)
+{
+    EXL_REQUIRE(t, EXL_E_INVALID, "exl_get_tuning: null");
+    *t = g_tuning;
+    return 0;
+}
+
+// ---- per-device buffers --------------------------------------------------------------------------------
+static DeviceBuffers g_buffers[EXL_MAX_DEVICES];
+static const size_t kWorkspaceFloats = (size_t) 16 * 1024 * 1024;     // 64 MiB
+
+DeviceBuffers* exl_buffers(int device) { return &g_buffers[device]; }
+
+static int ensure_workspace(int device)
+{
+    DeviceBuffers* b = &g_buffers[device];
+    if (b->workspace) return 0;
+    int prev = 0;
+    EXL_HIP(hipGetDevice(&prev));
+    EXL_HIP(hipSetDevice(device));
+    EXL_HIP(hipMalloc((void**) &b->workspace, kWorkspaceFloats * sizeof(float)));
+    b->workspace_floats = kWorkspaceFloats;
+    EXL_HIP(hipSetDevice(prev));
+    return 0;
+}
+
+int exl_workspace(int device, size_t floats, float** out)
+{
+    EXL_REQUIRE(device >= 0 && device < EXL_MAX_DEVICES, EXL_E_INVALID, "invalid device index %d", device);
+    EXL_TRY(ensure_workspace(device));      // lazily allocated when prepare_buffers was skipped (NOT capturable)
+    DeviceBuffers* b = &g_buffers[device];
+    EXL_REQUIRE(b->workspace_floats >= floats, EXL_E_TOO_SMALL, "workspace too small (%zu < %zu floats)",
+                b->workspace_floats, floats);
+    *out = b->workspace;
+    return 0;
+}
+
+extern "C" int exl_prepare_buffers(int device, void* temp_state, size_t temp_state_numel, void* temp_mlp,
+                                   size_t temp_mlp_numel, void* temp_zeros_float, size_t max_zeros_float,
+                                   void* temp_dq, size_t temp_dq_numel)
+{
+    EXL_REQUIRE(device >= 0, EXL_E_INVALID, "no device index");
+    EXL_REQUIRE(device < EXL_MAX_DEVICES, EXL_E_INVALID, "invalid device index");
+    DeviceBuffers* b = &g_buffers[device];
+    b->temp_state = (f16*) temp_state;   b->temp_state_numel = temp_state_numel;
+    b->temp_mlp = (f16*) temp_mlp;       b->temp_mlp_numel = temp_mlp_numel;
+    b->temp_zeros_float = (float*) temp_zeros_float; b->max_zeros_float = max_zeros_float;
+    b->temp_dq = (f16*) temp_dq;         b->temp_dq_numel = temp_dq_numel;
+    b->prepared = true;
+    return ensure_workspace(device);
+}
+
+// ---- Q4 handles -----------------------------------------------------------------------------------------
+static std::vector<Q4Matrix*> g_matrices;
+static std::unordered_set<void*> g_live;
+
+Q4Matrix* q4_from_handle(void* h)
+{
+    if (!h || g_live.find(h) == g_live.end()) return nullptr;
+    Q4Matrix* m = (Q4Matrix*) h;
+    return m->magic == EXL_Q4_MAGIC ? m : nullptr;
+}
+
+static void free_matrix(Q4Matrix* m)
+{
+    if (m->x_map) {
+        int prev = 0;
+        if (hipGetDevice(&prev) == hipSuccess) {
+            (void) hipSetDevice(m->device);
+            (void) hipFree(m->x_map);                        // the reference leaks this (q4_matrix.cu:55-57,108)
+            (void) hipSetDevice(prev);
+        }
+    }
+    m->magic = 0;
+    delete m;
+}
+
+extern "C" int exl_cleanup(void)
+{
+    for (Q4Matrix* m : g_matrices) free_matrix(m);
+    g_matrices.clear();
+    g_live.clear();
+    for (int d = 0; d < EXL_MAX_DEVICES; ++d) {
+        DeviceBuffers* b = &g_buffers[d];
+        if (b->workspace) {
+            int prev = 0;
+            if (hipGetDevice(&prev) == hipSuccess) {
+                (void) hipSetDevice(d);
+                (void) hipFree(b->workspace);
+                (void) hipSetDevice(prev);
+            }
+        }
+        memset(b, 0, sizeof(*b));
+    }
+    return 0;
+}
+
+extern "C" int exl_make_q4(int device, int height, int width, int groups, uint32_t* qweight, uint32_t* qzeros,
+                           uint16_t* scales, const uint32_t* g_idx_host, void* stream, void** out_handle)
+{
+    EXL_REQUIRE(out_handle, EXL_E_INVALID, "make_q4: out_handle is null");
+    *out_handle = nullptr;
+    EXL_REQUIRE(device >= 0 && device < EXL_MAX_DEVICES, EXL_E_INVALID, "make_q4: invalid device index %d", device);
+    EXL_REQUIRE(qweight && qzeros && scales, EXL_E_INVALID, "make_q4: null tensor pointer");
+    EXL_REQUIRE(height > 0 && width > 0 && groups > 0, EXL_E_INVALID, "make_q4: bad shape");
+    EXL_REQUIRE(height % 8 == 0, EXL_E_INVALID, "make_q4: height must be a multiple of 8");
+    EXL_REQUIRE(width % 8 == 0, EXL_E_INVALID, "make_q4: width must be a multiple of 8 (qzeros packs 8 columns)");
+    EXL_REQUIRE(height % groups == 0, EXL_E_INVALID, "w.shape[-2] must be a multiple of zeros.shape[-2]");
+    const int groupsize = height / groups;
+    EXL_REQUIRE(groupsize % 8 == 0, EXL_E_UNSUPPORTED, "make_q4: groupsize %d is not a multiple of 8", groupsize);
+
+    Q4Matrix* m = new Q4Matrix();
+    m->magic = EXL_Q4_MAGIC;
+    m->device = device;
+    m->height = height;
+    m->width = width;
+    m->groups = groups;
+    m->groupsize = groupsize;
+    m->qweight = qweight;
+    m->qzeros = qzeros;
+    m->scales = (f16*) scales;
+    m->x_map = nullptr;
+
+    if (g_idx_host) {
+        // stable counting sort of rows by group -> x_map (new row -> old row); integer-exact restatement of
+        // the reference's host code (q4_matrix.cu:110-139) with 32-bit counters
+        std::vector<uint32_t> start(groups + 1, 0), x_map(height);
+        for (int i = 0; i < height; ++i) {
+            if (g_idx_host[i] >= (uint32_t) groups) { delete m; EXL_FAIL(EXL_E_INVALID, "make_q4: g_idx[%d] = %u out of range", i, g_idx_host[i]); }
+            start[g_idx_host[i] + 1]++;
+        }
+        for (int gidx = 0; gidx < groups; ++gidx) start[gidx + 1] += start[gidx];
+        for (int row = 0; row < height; ++row) x_map[start[g_idx_host[row]]++] = (uint32_t) row;
+        int prev = 0;
+        hipError_t e = hipGetDevice(&prev);
+        if (e == hipSuccess) e = hipSetDevice(device);
+        if (e != hipSuccess) { delete m; EXL_FAIL((int) e, "make_q4: hipSetDevice(%d) failed: %s", device, hipGetErrorString(e)); }
+        const int r = launch_make_sequential(m, x_map.data(), (hipStream_t) stream);
+        (void) hipSetDevice(prev);
+        if (r) { delete m; return r; }
+    }
+    g_matrices.push_back(m);
+    g_live.insert(m);
+    *out_handle = m;
+    return 0;
+}
+
+extern "C" int exl_free_q4(void* handle)
+{
+    Q4Matrix* m = q4_from_handle(handle);
+    EXL_REQUIRE(m, EXL_E_INVALID, "free_q4: invalid handle");
+    for (size_t i = 0; i < g_matrices.size(); ++i)
+        if (g_matrices[i] == m) { g_matrices.erase(g_matrices.begin() + i); break; }
+    g_live.erase(m);
+    free_matrix(m);
+    return 0;
+}
+
+extern "C" int exl_q4_info(void* handle, int* device, int* height, int* width, int* groups, int* groupsize,
+                           const uint32_t** x_map_dev)
+{
+    Q4Matrix* m = q4_from_handle(handle);
+    EXL_REQUIRE(m, EXL_E_INVALID, "q4_info: invalid handle");
+    if (device) *device = m->device;
+    if (height) *height = m->height;
+    if (width) *width = m->width;
+    if (groups) *groups = m->groups;
+    if (groupsize) *groupsize = m->groupsize;
+    if (x_map_dev) *x_map_dev = m->x_map;
+    return 0;
+}
+
+// ---- q4 matmul ------------------------------------------------------------------------------------------
+struct DeviceGuard {
+    int prev; bool ok;
+    explicit DeviceGuard(int d) : prev(0), ok(false) {
+        if (hipGetDevice(&prev) == hipSuccess && (prev == d || hipSetDevice(d) == hipSuccess)) ok = true;
+    }
+    ~DeviceGuard() { int cur = 0; if (ok && hipGetDevice(&cur) == hipSuccess && cur != prev) (void) hipSetDevice(prev); }
+};
+
+static int q4_gemv(Q4Matrix* m, const void* x, int rows, void* out, int no_zero, hipStream_t s)
+{
+    float* ws = nullptr;
+    EXL_TRY(exl_workspace(m->device, 0, &ws));
+    return launch_q4_gemv(m, (const f16*) x, rows, (f16*) out, no_zero, ws, exl_buffers(m->device)->workspace_floats, s);
+}
+
+static int q4_gemm(Q4Matrix* m, const void* x, int rows, void* out, int no_zero, f16* tmp, size_t tmp_numel,
+                   hipStream_t s)
+{
+    return launch_q4_gemm(m, (const f16*) x, rows, (f16*) out, no_zero, tmp, tmp_numel, s);
+}
+
+// rows < thd (or thd == 0) -> GEMV, exactly the reference's test (exllama_ext.cpp:217); the GEMV handles at
+// most 8 rows, so larger row counts fall through to the MFMA kernel even when thd says "never".
+static int q4_dispatch(Q4Matrix* m, const void* x, int rows, void* out, int no_zero, f16* tmp, size_t tmp_numel,
+                       hipStream_t s)
+{
+    const int thd = g_tuning.matmul_recons_thd;
+    if ((thd == 0 || rows < thd) && rows <= 8) return q4_gemv(m, x, rows, out, no_zero, s);
+    return q4_gemm(m, x, rows, out, no_zero, tmp, tmp_numel, s);
+}
+
+#define Q4_PROLOGUE(name)                                                                      \
+    Q4Matrix* m = q4_from_handle(w);                                                           \
+    EXL_REQUIRE(m, EXL_E_INVALID, name ": invalid q4 handle");                                 \
+    EXL_REQUIRE(x && out, EXL_E_INVALID, name ": null tensor pointer");                        \
+    EXL_REQUIRE(x_height >= 0, EXL_E_INVALID, name ": negative row count");                    \
+    DeviceGuard guard(m->device);                                                              \
+    EXL_REQUIRE(guard.ok, EXL_E_INVALID, name ": cannot select device %d", m->device);         \
+    DeviceBuffers* bufs = exl_buffers(m->device);
+
+extern "C" int exl_q4_matmul(void* w, const void* x, int x_height, void* out, int no_zero, void* stream)
+{
+    Q4_PROLOGUE("q4_matmul")
+    return q4_dispatch(m, x, x_height, out, no_zero, bufs->temp_state, bufs->temp_state_numel, (hipStream_t) stream);
+}
+
+extern "C" int exl_q4_matmul_gemv(void* w, const void* x, int x_height, void* out, int no_zero, void* stream)
+{
+    Q4_PROLOGUE("q4_matmul_gemv")
+    (void) bufs;
+    return q4_gemv(m, x, x_height, out, no_zero, (hipStream_t) stream);
+}
+
+extern "C" int exl_q4_matmul_gemm(void* w, const void* x, int x_height, void* out, int no_zero, void* stream)
+{
+    Q4_PROLOGUE("q4_matmul_gemm")
+    return q4_gemm(m, x, x_height, out, no_zero, bufs->temp_state, bufs->temp_state_numel, (hipStream_t) stream);
+}
+
+extern "C" int exl_q4_matmul_lora(void* w, const void* x, int x_height, void* out, const void* lora_a,
+                                  const void* lora_b, int rank, void* lora_temp, void* stream)
+{
+    Q4_PROLOGUE("q4_matmul_lora")
+    EXL_REQUIRE(lora_a && lora_b && lora_temp && rank > 0, EXL_E_INVALID, "q4_matmul_lora: missing LoRA tensors");
+    hipStream_t s = (hipStream_t) stream;
+    EXL_TRY(launch_half_gemm((const f16*) x, (const f16*) lora_a, (f16*) lora_temp, x_height, m->height, rank, 0, s));
+    EXL_TRY(launch_half_gemm((const f16*) lora_temp, (const f16*) lora_b, (f16*) out, x_height, rank, m->width, 0, s));
+    return q4_dispatch(m, x, x_height, out, 1, bufs->temp_state, bufs->temp_state_numel, s);
+}
+
+extern "C" int exl_q4_reconstruct(void* w, void* out_w16, void* stream)
+{
+    Q4Matrix* m = q4_from_handle(w);
+    EXL_REQUIRE(m && out_w16, EXL_E_INVALID, "q4_reconstruct: invalid argument");
+    DeviceGuard guard(m->device);
+    return launch_reconstruct(m, (f16*) out_w16, (hipStream_t) stream);
+}
+
+extern "C" int exl_column_remap(const void* x, void* x_new, int height, int width, const uint32_t* x_map_dev,
+                                void* stream)
+{
+    EXL_REQUIRE(x && x_new && x_map_dev, EXL_E_INVALID, "column_remap: null pointer");
+    EXL_REQUIRE(width % 8 == 0, EXL_E_UNSUPPORTED, "column_remap: width (%d) must be a multiple of 8", width);
+    EXL_REQUIRE(height <= 65535, EXL_E_UNSUPPORTED, "column_remap: more than 65535 rows");
+    return launch_column_remap((const f16*) x, (f16*) x_new, height, width, x_map_dev, (hipStream_t) stream);
+}
+
+extern "C" int exl_half_matmul(const void* x, const void* w, void* out, int height, int dim, int width, int no_zero,
+                               void* stream)
+{
+    EXL_REQUIRE(x && w && out, EXL_E_INVALID, "half_matmul: null pointer");
+    return launch_half_gemm((const f16*) x, (const f16*) w, (f16*) out, height, dim, width, no_zero, (hipStream_t) stream);
+}
+
+extern "C" int exl_rms_norm(const void* x, const void* w, void* out, float epsilon, int rows, int dim, void* stream)
+{
+    EXL_REQUIRE(x && w && out, EXL_E_INVALID, "rms_norm: null pointer");
+    return launch_rms_norm((const f16*) x, (const f16*) w, (f16*) out, epsilon, rows, dim, (hipStream_t) stream);
+}
+
+extern "C" int exl_rope(void* x, const void* sin, const void* cos, int bsz, int rows_per_batch, int head_dim,
+                        int num_heads, int past_len, const int32_t* past_len_dev, void* stream)
+{
+    EXL_REQUIRE(x && sin && cos, EXL_E_INVALID, "rope_: null pointer");
+    return launch_rope((f16*) x, (const f16*) sin, (const f16*) cos, bsz, rows_per_batch, head_dim, num_heads, past_len,
+                       past_len_dev, (hipStream_t) stream);
+}
+
+extern "C" int exl_silu_mul(void* x, const void* y, int height, int width, void* stream)
+{
+    EXL_REQUIRE(x && y, EXL_E_INVALID, "silu_mul: null pointer");
+    return launch_silu_mul((f16*) x, (const f16*) y, height, width, (hipStream_t) stream);
+}
+
+extern "C" int exl_update_cache(const void* key_states, const void* value_states, void* key_cache, void* value_cache,
+                                int bsz, int q_len, int num_kv_heads, int head_dim, int max_seq_len, int past_len,
+                                const int32_t* past_len_dev, void* stream)
+{
+    EXL_REQUIRE(key_states && value_states && key_cache && value_cache, EXL_E_INVALID, "update_cache: null pointer");
+    EXL_REQUIRE(past_len >= 0 && past_len + q_len <= max_seq_len, EXL_E_INVALID,
+                "update_cache: past_len + q_len (%d) exceeds max_seq_len (%d)", past_len + q_len, max_seq_len);
+    return launch_update_cache((const f16*) key_states, (const f16*) value_states, (f16*) key_cache, (f16*) value_cache,
+                               bsz, q_len, num_kv_heads, head_dim, max_seq_len, past_len, past_len_dev, (hipStream_t) stream);
+}
+
+extern "C" int exl_attention(const void* q, const void* key_cache, const void* value_cache, void* out,
+                             const void* mask, int bsz, int q_len, int num_heads, int num_kv_heads, int head_dim,
+                             int max_seq_len, int past_len, const int32_t* past_len_dev, void* stream)
+{
+    EXL_REQUIRE(q && key_cache && value_cache && out, EXL_E_INVALID, "attention: null pointer");
+    EXL_REQUIRE((long) bsz * q_len <= 65535, EXL_E_UNSUPPORTED, "attention: bsz * q_len > 65535");
+    int device = 0;
+    EXL_HIP(hipGetDevice(&device));
+    float* ws = nullptr;
+    EXL_TRY(exl_workspace(device, 0, &ws));
+    return launch_attention((const f16*) q, (const f16*) key_cache, (const f16*) value_cache, (f16*) out,
+                            (const f16*) mask, bsz, q_len, num_heads, num_kv_heads, head_dim, max_seq_len, past_len,
+                            past_len_dev, ws, exl_buffers(device)->workspace_floats, (hipStream_t) stream);
+}
+
+// ---- fused decode ops ---------------------------------------------------------------------------------------
+extern "C" int exl_q4_attn(int device, const void* x, const void* rms_norm_weight, float epsilon, void* query_states,
+                           void* key_states, void* value_states, void* q_proj, void* k_proj, void* v_proj,
+                           const void* sin, const void* cos, int bsz, int q_len, int dim, int head_dim, int num_heads,
+                           int num_kv_heads, int past_len, const int32_t* past_len_dev, void* key_cache,
+                           void* value_cache, int max_seq_len, const void* q_a, const void* q_b, int q_rank,
+                           const void* k_a, const void* k_b, int k_rank, const void* v_a, const void* v_b, int v_rank,
+                           void* lora_temp, void* stream)
+{
+    EXL_REQUIRE(device >= 0, EXL_E_INVALID, "no device index");
+    EXL_REQUIRE(device < EXL_MAX_DEVICES, EXL_E_INVALID, "invalid device index");
+    Q4Matrix* qm = q4_from_handle(q_proj);
+    Q4Matrix* km = q4_from_handle(k_proj);
+    Q4Matrix* vm = q4_from_handle(v_proj);
+    EXL_REQUIRE(qm && km && vm, EXL_E_INVALID, "q4_attn: invalid q4 handle");
+    EXL_REQUIRE(x && rms_norm_weight && query_states && key_states && value_states && sin && cos && key_cache &&
+                value_cache, EXL_E_INVALID, "q4_attn: null pointer");
+    EXL_REQUIRE(qm->height == dim && km->height == dim && vm->height == dim, EXL_E_INVALID, "x and w have incompatible shapes");
+    DeviceBuffers* bufs = exl_buffers(device);
+    EXL_REQUIRE(bufs->prepared, EXL_E_NO_BUFFERS, "q4_attn: prepare_buffers was not called for device %d", device);
+    const int rows = bsz * q_len;
+    EXL_REQUIRE(bufs->temp_state_numel >= (size_t) 2 * rows * dim, EXL_E_TOO_SMALL, "temp_state buffer too small");
+    if (!past_len_dev)
+        EXL_REQUIRE(past_len >= 0 && past_len + q_len <= max_seq_len, EXL_E_INVALID, "q4_attn: cache overflow (%d + %d > %d)",
+                    past_len, q_len, max_seq_len);
+    DeviceGuard guard(device);
+    hipStream_t s = (hipStream_t) stream;
+
+    f16* temp_x = bufs->temp_state;                              // [rows, dim]
+    f16* remap_tmp = bufs->temp_state + (size_t) rows * dim;     // act-order gather scratch for the GEMM path
+    const size_t remap_numel = bufs->temp_state_numel - (size_t) rows * dim;
+    EXL_TRY(launch_rms_norm((const f16*) x, (const f16*) rms_norm_weight, temp_x, epsilon, rows, dim, s));
+
+    struct Proj { Q4Matrix* m; void* out; const void* a; const void* b; int rank; };
+    const Proj projs[3] = {{qm, query_states, q_a, q_b, q_rank}, {km, key_states, k_a, k_b, k_rank},
+                           {vm, value_states, v_a, v_b, v_rank}};
+    for (const Proj& p : projs) {
+        int no_zero = 0;
+        if (p.a && p.b && p.rank > 0) {
+            EXL_REQUIRE(lora_temp, EXL_E_INVALID, "q4_attn: lora_temp missing");
+            EXL_TRY(launch_half_gemm(temp_x, (const f16*) p.a, (f16*) lora_temp, rows, dim, p.rank, 0, s));
+            EXL_TRY(launch_half_gemm((const f16*) lora_temp, (const f16*) p.b, (f16*) p.out, rows, p.rank, p.m->width, 0, s));
+            no_zero = 1;
+        }
+        if (rows <= 8) EXL_TRY(q4_gemv(p.m, temp_x, rows, p.out, no_zero, s));
+        else           EXL_TRY(q4_gemm(p.m, temp_x, rows, p.out, no_zero, remap_tmp, remap_numel, s));
+    }
+    EXL_TRY(launch_rope((f16*) query_states, (const f16*) sin, (const f16*) cos, bsz, q_len * num_heads, head_dim,
+                        num_heads, past_len, past_len_dev, s));
+    EXL_TRY(launch_rope((f16*) key_states, (const f16*) sin, (const f16*) cos, bsz, q_len * num_kv_heads, head_dim,
+                        num_kv_heads, past_len, past_len_dev, s));
+    return launch_update_cache((const f16*) key_states, (const f16*) value_states, (f16*) key_cache, (f16*) value_cache,
+                               bsz, q_len, num_kv_heads, head_dim, max_seq_len, past_len, past_len_dev, s);
+}
+
+extern "C" int exl_q4_attn_2(void* x, const void* attn_output, void* o_proj, int height, const void* o_a,
+                             const void* o_b, int o_rank, void* lora_temp, void* stream)
+{
+    Q4Matrix* om = q4_from_handle(o_proj);
+    EXL_REQUIRE(om, EXL_E_INVALID, "q4_attn_2: invalid q4 handle");
+    EXL_REQUIRE(x && attn_output, EXL_E_INVALID, "q4_attn_2: null pointer");
+    DeviceGuard guard(om->device);
+    DeviceBuffers* bufs = exl_buffers(om->device);
+    hipStream_t s = (hipStream_t) stream;
+    if (o_a && o_b && o_rank > 0) {
+        EXL_REQUIRE(lora_temp, EXL_E_INVALID, "q4_attn_2: lora_temp missing");
+        EXL_TRY(launch_half_gemm((const f16*) attn_output, (const f16*) o_a, (f16*) lora_temp, height, om->height, o_rank, 0, s));
+        EXL_TRY(launch_half_gemm((const f16*) lora_temp, (const f16*) o_b, (f16*) x, height, o_rank, om->width, 1, s));
+    }
+    if (height <= 8) return q4_gemv(om, attn_output, height, x, 1, s);
+    return q4_gemm(om, attn_output, height, x, 1, bufs->temp_state, bufs->temp_state_numel, s);
+}
+
+extern "C" int exl_q4_mlp(int device, void* x, const void* rms_norm_weight, float epsilon, void* gate, void* up,
+                          void* down, int height, int dim, const void* gate_a, const void* gate_b, int gate_rank,
+                          const void* up_a, const void* up_b, int up_rank, const void* down_a, const void* down_b,
+                          int down_rank, void* lora_temp, void* stream)
+{
+    EXL_REQUIRE(device >= 0, EXL_E_INVALID, "no device index");
+    EXL_REQUIRE(device < EXL_MAX_DEVICES, EXL_E_INVALID, "invalid device index");
+    Q4Matrix* gm = q4_from_handle(gate);
+    Q4Matrix* um = q4_from_handle(up);
+    Q4Matrix* dm = q4_from_handle(down);
+    EXL_REQUIRE(gm && um && dm, EXL_E_INVALID, "q4_mlp: invalid q4 handle");
+    EXL_REQUIRE(x && rms_norm_weight, EXL_E_INVALID, "q4_mlp: null pointer");
+    EXL_REQUIRE(gm->height == dim && um->height == dim && dm->width == dim && dm->height == um->width &&
+                gm->width == um->width, EXL_E_INVALID, "q4_mlp: incompatible shapes");
+    DeviceBuffers* bufs = exl_buffers(device);
+    EXL_REQUIRE(bufs->prepared, EXL_E_NO_BUFFERS, "q4_mlp: prepare_buffers was not called for device %d", device);
+    EXL_REQUIRE(bufs->temp_state_numel >= (size_t) 2 * height * dim, EXL_E_TOO_SMALL, "temp_state buffer too small");
+    const int inter = um->width;
+    EXL_REQUIRE(bufs->temp_mlp_numel >= (size_t) 2 * height * inter, EXL_E_TOO_SMALL, "temp_mlp buffer too small");
+    DeviceGuard guard(device);
+    hipStream_t s = (hipStream_t) stream;
+
+    f16* temp_x = bufs->temp_state;
+    f16* remap_tmp = bufs->temp_state + (size_t) height * dim;
+    const size_t remap_numel = bufs->temp_state_numel - (size_t) height * dim;
+    f16* t0 = bufs->temp_mlp;
+    f16* t1 = bufs->temp_mlp + (size_t) height * inter;
+    EXL_TRY(launch_rms_norm((const f16*) x, (const f16*) rms_norm_weight, temp_x, epsilon, height, dim, s));
+
+    int gz = 0, uz = 0;
+    if (gate_a && gate_b && gate_rank > 0) {
+        EXL_REQUIRE(lora_temp, EXL_E_INVALID, "q4_mlp: lora_temp missing");
+        EXL_TRY(launch_half_gemm(temp_x, (const f16*) gate_a, (f16*) lora_temp, height, dim, gate_rank, 0, s));
+        EXL_TRY(launch_half_gemm((const f16*) lora_temp, (const f16*) gate_b, t0, height, gate_rank, inter, 0, s));
+        gz = 1;
+    }
+    if (up_a && up_b && up_rank > 0) {
+        EXL_REQUIRE(lora_temp, EXL_E_INVALID, "q4_mlp: lora_temp missing");
+        EXL_TRY(launch_half_gemm(temp_x, (const f16*) up_a, (f16*) lora_temp, height, dim, up_rank, 0, s));
+        EXL_TRY(launch_half_gemm((const f16*) lora_temp, (const f16*) up_b, t1, height, up_rank, inter, 0, s));
+        uz = 1;
+    }
+    if (height <= 8) {
+        EXL_TRY(q4_gemv(gm, temp_x, height, t0, gz, s));
+        EXL_TRY(q4_gemv(um, temp_x, height, t1, uz, s));
+    } else {
+        EXL_TRY(q4_gemm(gm, temp_x, height, t0, gz, remap_tmp, remap_numel, s));
+        EXL_TRY(q4_gemm(um, temp_x, height, t1, uz, remap_tmp, remap_numel, s));
+    }
+    EXL_TRY(launch_silu_mul(t0, t1, height, inter, s));
+    if (down_a && down_b && down_rank > 0) {
+        EXL_REQUIRE(lora_temp, EXL_E_INVALID, "q4_mlp: lora_temp missing");
+        EXL_TRY(launch_half_gemm(t0, (const f16*) down_a, (f16*) lora_temp, height, inter, down_rank, 0, s));
+        EXL_TRY(launch_half_gemm((const f16*) lora_temp, (const f16*) down_b, (f16*) x, height, down_rank, dim, 1, s));
+    }
+    // the down projection's act-order gather may not reuse temp_x's region: use temp_state from the start
+    if (height <= 8) return q4_gemv(dm, t0, height, x, 1, s);
+    return q4_gemm(dm, t0, height, x, 1, bufs->temp_state, bufs->temp_state_numel, s);
+}
+
+// ---- repetition penalty on the host (fp32, deterministic) -----------------------------------------------------
+// Semantics of /root/reference/exllama_ext/cpu_func/rep_penalty.cpp:5-31 and :36-74: walk the
+// sequence backwards; the penalty stays at penalty_max for `sustain` tokens, then ramps linearly to 1 over `decay`.
+struct PenaltyRamp {
+    float v, dv; int s, beg;
+    PenaltyRamp(float penalty_max, int sustain, int decay, int seq_len) {
+        v = penalty_max;
+        dv = decay ? (1.0f - penalty_max) / (float) decay : 0.0f;
+        s = sustain == -1 ? seq_len : sustain;
+        beg = seq_len - s - decay;
+        if (beg < 0) beg = 0;
+    }
+    inline void step() { if (--s < 0) v += dv; }
+};
+
+extern "C" int exl_rep_penalty(int vocab_size, const uint64_t* sequence_host, float* rep_mask_host, float penalty_max,
+                               int sustain, int decay, int seq_len)
+{
+    EXL_REQUIRE(rep_mask_host && (sequence_host || seq_len == 0), EXL_E_INVALID, "rep_penalty: null pointer");
+    for (int i = 0; i < vocab_size; ++i) rep_mask_host[i] = 1.0f;
+    PenaltyRamp ramp(penalty_max, sustain, decay, seq_len);
+    for (int i = seq_len - 1; i >= ramp.beg; --i) {
+        const uint64_t t = sequence_host[i];
+        EXL_REQUIRE(t < (uint64_t) vocab_size, EXL_E_INVALID, "rep_penalty: token %llu outside the vocabulary", (unsigned long long) t);
+        if (ramp.v > rep_mask_host[t]) rep_mask_host[t] = ramp.v;
+        ramp.step();
+    }
+    return 0;
+}
+
+extern "C" int exl_apply_rep_penalty(int vocab_size, const uint64_t* sequence_host, float penalty_max, int sustain,
+                                     int decay, int seq_len, int bsz, float* logits_host)
+{
+    EXL_REQUIRE(logits_host && (sequence_host || seq_len == 0), EXL_E_INVALID, "apply_rep_penalty: null pointer");
+    std::vector<unsigned char> seen((size_t) vocab_size);
+    for (int b = 0; b < bsz; ++b) {
+        const uint64_t* seq = sequence_host + (size_t) b * seq_len;
+        float* logits = logits_host + (size_t) b * vocab_size;
+        std::fill(seen.begin(), seen.end(), 0);
+        PenaltyRamp ramp(penalty_max, sustain, decay, seq_len);
+        for (int i = seq_len - 1; i >= ramp.beg; --i) {
+            const uint64_t t = seq[i];
+            EXL_REQUIRE(t < (uint64_t) vocab_size, EXL_E_INVALID, "apply_rep_penalty: token %llu outside the vocabulary", (unsigned long long) t);
+            if (!seen[t]) {
+                if (logits[t] > 0.0f) logits[t] /= ramp.v; else logits[t] *= ramp.v;
+                seen[t] = 1;
+            }
+            ramp.step();
+        }
+    }
+    return 0;
+}

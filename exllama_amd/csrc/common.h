@@ -1,0 +1,98 @@
+// Internal declarations shared by the HIP translation units of libexl_amd.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/exl_amd.h"
+
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// 128-bit streaming load (weights are read exactly once per token: keep them out of the way of L2-resident data)
+#ifdef __HIPCC__
+__device__ __forceinline__ uint4 nt_load16(const void* p)
+{
+    const u32x4 v = __builtin_nontemporal_load((const u32x4*) p);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+#endif
+
+// ---- error plumbing ---------------------------------------------------------------------------------
+void exl_set_error(const char* fmt, ...);
+
+#define EXL_FAIL(code, ...) do { exl_set_error(__VA_ARGS__); return (code); } while (0)
+#define EXL_REQUIRE(cond, code, ...) do { if (!(cond)) { exl_set_error(__VA_ARGS__); return (code); } } while (0)
+#define EXL_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    exl_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); return (int) _e; } } while (0)
+#define EXL_LAUNCH_CHECK() do { hipError_t _e = hipGetLastError(); if (_e != hipSuccess) { \
+    exl_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); return (int) _e; } } while (0)
+#define EXL_TRY(expr) do { int _r = (expr); if (_r != 0) return _r; } while (0)
+
+// ---- Q4 matrix handle (reference: exllama_ext/cuda_func/q4_matrix.cuh:8-46) ---------------------------
+struct Q4Matrix {
+    uint32_t magic;
+    int device;
+    int height;        // K
+    int width;         // N
+    int groups;
+    int groupsize;
+    uint32_t* qweight; // borrowed [K/8, N]
+    uint32_t* qzeros;  // borrowed [G, N/8]
+    f16* scales;       // borrowed [G, N]
+    uint32_t* x_map;   // owned   [K] or NULL (act-order)
+};
+#define EXL_Q4_MAGIC 0x51344d58u
+
+// Looks the pointer up in the registry of live handles (never dereferences an unknown pointer).
+Q4Matrix* q4_from_handle(void* h);
+
+// ---- per-device buffers (reference: exllama_ext/cuda_buffers.cuh) -------------------------------------
+struct DeviceBuffers {
+    bool prepared;
+    f16* temp_state;  size_t temp_state_numel;
+    f16* temp_mlp;    size_t temp_mlp_numel;
+    float* temp_zeros_float; size_t max_zeros_float;
+    f16* temp_dq;     size_t temp_dq_numel;
+    float* workspace; size_t workspace_floats;   // owned: split-K slabs / attention partials
+};
+DeviceBuffers* exl_buffers(int device);           // never NULL for 0 <= device < EXL_MAX_DEVICES
+int exl_workspace(int device, size_t floats, float** out);   // fails if too small / not prepared
+extern ExlTuning g_tuning;
+
+// ---- launchers implemented in the .hip files -----------------------------------------------------------
+int launch_make_sequential(Q4Matrix* m, const uint32_t* x_map_host, hipStream_t s);
+int launch_reconstruct(const Q4Matrix* m, f16* out, hipStream_t s);
+int launch_column_remap(const f16* x, f16* x_new, int height, int width, const uint32_t* x_map, hipStream_t s);
+
+// x_norm: optional fused prologue = RMSNorm(x) with weight `norm_w` (NULL = plain x)
+struct GemvArgs {
+    const Q4Matrix* w;
+    const f16* x; int rows;
+    f16* out; int no_zero;
+    float* slabs; size_t slab_floats;
+};
+int launch_q4_gemv(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_zero, float* ws, size_t ws_floats,
+                   hipStream_t s);
+int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_zero, f16* remap_tmp,
+                   size_t remap_tmp_numel, hipStream_t s);
+int launch_half_gemm(const f16* x, const f16* w, f16* out, int M, int K, int N, int no_zero, hipStream_t s);
+
+int launch_rms_norm(const f16* x, const f16* w, f16* out, float eps, int rows, int dim, hipStream_t s);
+int launch_rope(f16* x, const f16* sin, const f16* cos, int bsz, int rows_per_batch, int head_dim, int num_heads,
+                int past_len, const int32_t* past_len_dev, hipStream_t s);
+int launch_silu_mul(f16* x, const f16* y, int height, int width, hipStream_t s);
+int launch_update_cache(const f16* k, const f16* v, f16* kc, f16* vc, int bsz, int q_len, int kvh, int hd,
+                        int max_seq, int past_len, const int32_t* past_len_dev, hipStream_t s);
+int launch_attention(const f16* q, const f16* kc, const f16* vc, f16* out, const f16* mask, int bsz, int q_len,
+                     int heads, int kv_heads, int hd, int max_seq, int past_len, const int32_t* past_len_dev,
+                     float* ws, size_t ws_floats, hipStream_t s);

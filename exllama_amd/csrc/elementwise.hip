@@ -1,0 +1,203 @@
+// HBM-bound glue kernels: RMSNorm, RoPE, SiLU*mul, KV-cache scatter.  One pass each, 128-bit accesses,
+// wave64 reductions, no atomics, no zeroed scratch.
+//
+// Behavioural reference (arithmetic contract):
+//   /root/reference/exllama_ext/cuda_func/rms_norm.cu:21-152   (two kernels + fp32 atomics there)
+//   /root/reference/exllama_ext/cuda_func/rope.cu:21-88
+//   /root/reference/exllama_ext/cuda_func/q4_mlp.cu:16-88      silu / silu_mul_cuda_kernel
+//   /root/reference/exllama_ext/cuda_func/q4_attn.cu:19-72     update_cache_kernel
+#include "common.h"
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RMSNorm: out = h( h(x * h(rsqrt(mean(x^2) + eps))) * w ).  One 256-thread block per row; the row is kept
+// in registers between the reduction and the scaling (dim <= 256*8*MAXV), so x is read from HBM once.
+// ---------------------------------------------------------------------------------------------------
+template <int MAXV>
+__global__ __launch_bounds__(256) void rms_norm_kernel(const f16* __restrict__ x, const f16* __restrict__ w,
+                                                       f16* __restrict__ out, float eps, int dim)
+{
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const f16* xr = x + (size_t) row * dim;
+    f16* orow = out + (size_t) row * dim;
+    const int nvec = dim >> 3;                              // dim % 8 == 0 (checked by the launcher)
+
+    f16x8 v[MAXV];
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = tid + i * 256;
+        if (idx < nvec) {
+            v[i] = *(const f16x8*) (xr + idx * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = (float) v[i][j]; acc = fmaf(f, f, acc); }
+        }
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    const float total = red[0] + red[1] + red[2] + red[3];
+    const float rmf = 1.0f / sqrtf(total * (1.0f / (float) dim) + eps);
+    const f16 rm = (f16) rmf;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = tid + i * 256;
+        if (idx < nvec) {
+            const f16x8 wv = *(const f16x8*) (w + idx * 8);
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f16 m = v[i][j] * rm;              // fp16 multiply, rounded
+                o[j] = m * wv[j];                        // second fp16 multiply, rounded
+            }
+            *(f16x8*) (orow + idx * 8) = o;
+        }
+    }
+}
+
+int launch_rms_norm(const f16* x, const f16* w, f16* out, float eps, int rows, int dim, hipStream_t s)
+{
+    if (rows <= 0) return 0;
+    EXL_REQUIRE(dim % 8 == 0, EXL_E_UNSUPPORTED, "rms_norm: dim (%d) must be a multiple of 8", dim);
+    EXL_REQUIRE(dim <= 256 * 8 * 16, EXL_E_UNSUPPORTED, "rms_norm: dim (%d) > 32768 unsupported", dim);
+    const int nvec = dim / 8;
+    const int per = (nvec + 255) / 256;
+    if (per <= 2)      hipLaunchKernelGGL(rms_norm_kernel<2>,  dim3(rows), dim3(256), 0, s, x, w, out, eps, dim);
+    else if (per <= 4) hipLaunchKernelGGL(rms_norm_kernel<4>,  dim3(rows), dim3(256), 0, s, x, w, out, eps, dim);
+    else if (per <= 8) hipLaunchKernelGGL(rms_norm_kernel<8>,  dim3(rows), dim3(256), 0, s, x, w, out, eps, dim);
+    else               hipLaunchKernelGGL(rms_norm_kernel<16>, dim3(rows), dim3(256), 0, s, x, w, out, eps, dim);
+    EXL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RoPE (rotate-half), in place.  One thread = 8 columns of the left half + the matching 8 of the right half.
+//   l' = h(fma(l, cos_l, h(r * h(-sin_l))))      r' = h(fma(r, cos_r, h(l * sin_r)))
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_kernel(f16* __restrict__ x, const f16* __restrict__ sin,
+                                                   const f16* __restrict__ cos, int rows_per_batch, int head_dim,
+                                                   int num_heads, int past_len, const int32_t* __restrict__ past_len_dev,
+                                                   int total_rows)
+{
+    const int vec_per_row = head_dim >> 4;                  // (head_dim / 2) / 8
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int grow = gid / vec_per_row;                     // global row over bsz * rows_per_batch
+    if (grow >= total_rows) return;
+    const int v = gid - grow * vec_per_row;
+    const int row = grow % rows_per_batch;
+    const int past = past_len_dev ? *past_len_dev : past_len;
+    const int pos = past + row / num_heads;
+    const int hd2 = head_dim >> 1;
+
+    f16* xp = x + (size_t) grow * head_dim + v * 8;
+    const f16* sp = sin + (size_t) pos * head_dim + v * 8;
+    const f16* cp = cos + (size_t) pos * head_dim + v * 8;
+    const f16x8 l = *(const f16x8*) xp;
+    const f16x8 r = *(const f16x8*) (xp + hd2);
+    const f16x8 sl = *(const f16x8*) sp;
+    const f16x8 sr = *(const f16x8*) (sp + hd2);
+    const f16x8 cl = *(const f16x8*) cp;
+    const f16x8 cr = *(const f16x8*) (cp + hd2);
+    f16x8 nl, nr;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const f16 ls = r[j] * (-sl[j]);
+        const f16 rs = l[j] * sr[j];
+        nl[j] = __builtin_fmaf16(l[j], cl[j], ls);
+        nr[j] = __builtin_fmaf16(r[j], cr[j], rs);
+    }
+    *(f16x8*) xp = nl;
+    *(f16x8*) (xp + hd2) = nr;
+}
+
+int launch_rope(f16* x, const f16* sin, const f16* cos, int bsz, int rows_per_batch, int head_dim, int num_heads,
+                int past_len, const int32_t* past_len_dev, hipStream_t s)
+{
+    const int total_rows = bsz * rows_per_batch;
+    if (total_rows <= 0) return 0;
+    EXL_REQUIRE(head_dim % 16 == 0, EXL_E_UNSUPPORTED, "rope: head_dim (%d) must be a multiple of 16", head_dim);
+    EXL_REQUIRE(num_heads > 0, EXL_E_INVALID, "rope: num_heads must be > 0");
+    const long total = (long) total_rows * (head_dim / 16);
+    hipLaunchKernelGGL(rope_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, s, x, sin, cos, rows_per_batch,
+                       head_dim, num_heads, past_len, past_len_dev, total_rows);
+    EXL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SiLU(x) * y in fp16 steps: e = h(exp(-x)); s = h(1 + e); rc = h(1 / s); out = h(h(x * rc) * y)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f16 silu_mul_h(f16 x, f16 y)
+{
+    const f16 e = (f16) __expf((float) (f16) (-x));
+    const f16 sm = (f16) 1.0f + e;
+    const f16 rc = (f16) (1.0f / (float) sm);
+    const f16 v = x * rc;
+    return v * y;
+}
+
+__global__ __launch_bounds__(256) void silu_mul_kernel(f16* __restrict__ x, const f16* __restrict__ y, long nvec)
+{
+    const long i = (long) blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvec) return;
+    const f16x8 a = *(const f16x8*) (x + i * 8);
+    const f16x8 b = *(const f16x8*) (y + i * 8);
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = silu_mul_h(a[j], b[j]);
+    *(f16x8*) (x + i * 8) = o;
+}
+
+int launch_silu_mul(f16* x, const f16* y, int height, int width, hipStream_t s)
+{
+    const long n = (long) height * width;
+    if (n <= 0) return 0;
+    EXL_REQUIRE(n % 8 == 0, EXL_E_UNSUPPORTED, "silu_mul: height*width must be a multiple of 8");
+    const long nvec = n / 8;
+    hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned) ((nvec + 255) / 256)), dim3(256), 0, s, x, y, nvec);
+    EXL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// KV scatter: cache[b, h, past + t, :] = state[b, t, h, :]   (bit copy, 128-bit)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void update_cache_kernel(const f16* __restrict__ k, const f16* __restrict__ v,
+                                                           f16* __restrict__ kc, f16* __restrict__ vc, int q_len,
+                                                           int kvh, int hd, int max_seq, int past_len,
+                                                           const int32_t* __restrict__ past_len_dev, long total_vec)
+{
+    const long gid = (long) blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total_vec) return;
+    const int vec_per_head = hd >> 3;
+    const int d8 = (int) (gid % vec_per_head);
+    long rest = gid / vec_per_head;
+    const int h = (int) (rest % kvh); rest /= kvh;
+    const int t = (int) (rest % q_len);
+    const int b = (int) (rest / q_len);
+    const int past = past_len_dev ? *past_len_dev : past_len;
+    const size_t src = (((size_t) b * q_len + t) * kvh + h) * hd + d8 * 8;
+    const size_t dst = (((size_t) b * kvh + h) * max_seq + (past + t)) * hd + d8 * 8;
+    *(uint4*) (kc + dst) = *(const uint4*) (k + src);
+    *(uint4*) (vc + dst) = *(const uint4*) (v + src);
+}
+
+int launch_update_cache(const f16* k, const f16* v, f16* kc, f16* vc, int bsz, int q_len, int kvh, int hd,
+                        int max_seq, int past_len, const int32_t* past_len_dev, hipStream_t s)
+{
+    EXL_REQUIRE(hd % 8 == 0, EXL_E_UNSUPPORTED, "update_cache: head_dim (%d) must be a multiple of 8", hd);
+    const long total = (long) bsz * q_len * kvh * (hd / 8);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(update_cache_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, s, k, v, kc, vc, q_len,
+                       kvh, hd, max_seq, past_len, past_len_dev, total);
+    EXL_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,295 @@
+// Prefill path: out[M,N] (+)= x[M,K] @ dequant(W[K,N]) for large M -- int4 dequant fused into an MFMA GEMM.
+//
+// Replaces /root/reference/exllama_ext/cuda_func/q4_matmul.cu:301-344 (q4_matmul_recons_cuda), which
+// materialises the whole fp16 weight (q4_matrix.cu:170-224 reconstruct_kernel, K*N*2 bytes written and read
+// back per call) and then calls cublasHgemm.  Here nothing is materialised:
+//   * the GPTQ word (8 consecutive k of ONE output column) is exactly the per-lane B fragment of
+//     v_mfma_f32_32x32x16_f16 (lane = column, 8 consecutive k).  So packed weights go
+//     HBM -> VGPR -> (magic-number nibble expand, exact zero subtraction, ONE fp16 multiply by the group
+//     scale = bit-identical W16 to the reference's reconstruct) -> MFMA operand.  No LDS, no fp16 copy;
+//   * nibble pairs come out of a word in the order (0,4)(1,5)(2,6)(3,7); instead of re-ordering the weights
+//     (4 v_perm per word, per wave) the ACTIVATION tile is written to LDS in that k-order once per block --
+//     any k-permutation shared by A and B leaves the dot product unchanged;
+//   * A tile 128x64 fp16 through LDS, register-staged, double-buffered, XOR-swizzled so every
+//     ds_read_b128 lane group hits 16 distinct 16-byte slots;
+//   * 256 threads = 4 waves as 2(M) x 2(N), each 64x64 = 2x2 MFMA 32x32 tiles, fp32 accumulate;
+//   * blocks of one XCD walk m-tiles of the same weight column tile first, so a W tile is pulled from HBM
+//     once per XCD L2 rather than once per m-tile.
+// Act-order weights: x is gathered through x_map by column_remap into the borrowed temp_state buffer first
+// (same as the reference, q4_matmul.cu:320-325); folding the gather into the A-tile load is future work.
+#include "common.h"
+
+#define MAGIC_1024 0x64006400u
+#define BM 128
+#define BN 128
+#define BK 64
+
+__device__ __forceinline__ f16x2 as_h2(uint32_t v) { return __builtin_bit_cast(f16x2, v); }
+
+__device__ __forceinline__ uint4 permute_x8(uint4 d)
+{
+    uint4 o;
+    o.x = (d.x & 0xFFFFu) | (d.z << 16);
+    o.y = (d.x >> 16) | (d.z & 0xFFFF0000u);
+    o.z = (d.y & 0xFFFFu) | (d.w << 16);
+    o.w = (d.y >> 16) | (d.w & 0xFFFF0000u);
+    return o;
+}
+
+// LDS byte offset of the 16-byte slot (row, c8) of a [BM][BK] fp16 tile (128-byte rows, 8 slots per row).
+__device__ __forceinline__ int a_lds_off(int row, int c8) { return row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4); }
+
+// word -> 8 fp16 weights in slot order (q0,q4,q1,q5,q2,q6,q3,q7), each h( h(q - z) * s )
+__device__ __forceinline__ f16x8 dequant_word(uint32_t w, f16x2 zc0, f16x2 zc1, f16x2 s2)
+{
+    const f16x2 sixteenth = {(f16) 0.0625f, (f16) 0.0625f};
+    const uint32_t w8 = w >> 8;
+    const f16x2 d0 = (as_h2((w & 0x000F000Fu) | MAGIC_1024) + zc0) * s2;
+    const f16x2 d1 = (as_h2((w & 0x00F000F0u) | MAGIC_1024) * sixteenth + zc1) * s2;
+    const f16x2 d2 = (as_h2((w8 & 0x000F000Fu) | MAGIC_1024) + zc0) * s2;
+    const f16x2 d3 = (as_h2((w8 & 0x00F000F0u) | MAGIC_1024) * sixteenth + zc1) * s2;
+    f16x8 r;
+    r[0] = d0[0]; r[1] = d0[1]; r[2] = d1[0]; r[3] = d1[1];
+    r[4] = d2[0]; r[5] = d2[1]; r[6] = d3[0]; r[7] = d3[1];
+    return r;
+}
+
+__global__ __launch_bounds__(256) void q4_gemm_kernel(const f16* __restrict__ x, const uint32_t* __restrict__ qweight,
+                                                      const uint32_t* __restrict__ qzeros,
+                                                      const f16* __restrict__ scales, f16* __restrict__ out, int M,
+                                                      int K, int N, int gshift, int groupsize, int no_zero, int mtiles,
+                                                      int ntiles)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BM * BK * 2];
+
+    // ---- XCD-aware tile mapping: block b runs on XCD b % 8 (observed dispatch; speed only) ------------
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int idx = b >> 3;
+    const int nl = idx / mtiles;
+    const int mt = idx - nl * mtiles;
+    const int nt = nl * 8 + xcd;
+    if (nt >= ntiles) return;
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wm = wave >> 1;
+    const int wn = wave & 1;
+    const int g = lane >> 5;                                 // k half of the 16-wide MFMA step
+    const int c = lane & 31;
+
+    // B addressing: this lane owns columns n, n+1 (one uint2 per packed row)
+    const int n = n0 + wn * 64 + 2 * c;
+    const bool n_ok = n < N;
+    const uint32_t* wptr = qweight + n;
+    const int zsh = (n & 7) * 4;
+
+    // A staging: 4 x 16 bytes per thread per tile
+    int a_row[4], a_c8[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = tid + i * 256;
+        a_row[i] = id >> 3;
+        a_c8[i] = id & 7;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+
+    const int nk = (K + BK - 1) / BK;
+
+    auto load_a = [&](int k0, uint4 (&ar)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = m0 + a_row[i];
+            const int k = k0 + a_c8[i] * 8;
+            ar[i] = (row < M && k < K) ? *(const uint4*) (x + (size_t) row * K + k) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_a = [&](int buf, const uint4 (&ar)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *(uint4*) (lds + buf * (BM * BK * 2) + a_lds_off(a_row[i], a_c8[i])) = permute_x8(ar[i]);
+    };
+    auto load_b = [&](int k0, uint2 (&br)[4]) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int prow = (k0 >> 3) + 2 * kk + g;
+            br[kk] = (n_ok && prow * 8 < K) ? *(const uint2*) (wptr + (size_t) prow * N) : make_uint2(0, 0);
+        }
+    };
+
+    uint4 areg[4];
+    uint2 bcur[4], bnext[4];
+    load_a(0, areg);
+    load_b(0, bcur);
+    store_a(0, areg);
+    __syncthreads();
+
+    int cur_group = -1;
+    f16x2 zc0[2], zc1[2], s2[2];
+
+    for (int it = 0; it < nk; ++it) {
+        const int k0 = it * BK;
+        const bool more = it + 1 < nk;
+        if (more) {
+            load_a(k0 + BK, areg);
+            load_b(k0 + BK, bnext);
+        }
+        const unsigned char* abuf = lds + (it & 1) * (BM * BK * 2);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int k = k0 + kk * 16;
+            if (k < K) {                                       // block-uniform
+                const int grp = gshift >= 0 ? (k >> gshift) : (k / groupsize);
+                if (grp != cur_group) {                        // block-uniform
+                    cur_group = grp;
+                    uint32_t zw = 0;
+                    f16x2 sv = {(f16) 0.f, (f16) 0.f};
+                    if (n_ok) {
+                        zw = qzeros[(size_t) grp * (N >> 3) + (n >> 3)] >> zsh;
+                        sv = *(const f16x2*) (scales + (size_t) grp * N + n);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int z = (int) ((zw >> (4 * j)) & 0xFu) + 1;
+                        const f16 a = (f16) (float) (-(1024 + z));
+                        const f16 bb = (f16) (float) (-(64 + z));
+                        zc0[j] = (f16x2){a, a};
+                        zc1[j] = (f16x2){bb, bb};
+                        s2[j] = (f16x2){sv[j], sv[j]};
+                    }
+                }
+                f16x8 bf[2];
+                bf[0] = dequant_word(bcur[kk].x, zc0[0], zc1[0], s2[0]);
+                bf[1] = dequant_word(bcur[kk].y, zc0[1], zc1[1], s2[1]);
+                f16x8 af[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int row = wm * 64 + t * 32 + c;
+                    af[t] = *(const f16x8*) (abuf + a_lds_off(row, kk * 2 + g));
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], bf[j], acc[t][j], 0, 0, 0);
+            }
+        }
+        if (more) {
+            store_a((it + 1) & 1, areg);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) bcur[kk] = bnext[kk];
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: C[row = (r&3) + 8*(r>>2) + 4*g][col = c] per 32x32 tile --------------------------------
+    if (!n_ok) return;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            if (row < M) {
+                f16* op = out + (size_t) row * N + n;
+                float v0 = acc[t][0][r], v1 = acc[t][1][r];
+                if (no_zero) {
+                    const f16x2 prev = *(const f16x2*) op;
+                    v0 += (float) prev[0];
+                    v1 += (float) prev[1];
+                }
+                *(f16x2*) op = (f16x2){(f16) v0, (f16) v1};
+            }
+        }
+    }
+}
+
+int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_zero, f16* remap_tmp,
+                   size_t remap_tmp_numel, hipStream_t s)
+{
+    if (rows <= 0) return 0;
+    const int K = w->height, N = w->width;
+    EXL_REQUIRE(N % 2 == 0 && K % 16 == 0, EXL_E_UNSUPPORTED, "q4 gemm: need N %% 2 == 0 and K %% 16 == 0 (K=%d N=%d)", K, N);
+    EXL_REQUIRE(w->groupsize % 16 == 0, EXL_E_UNSUPPORTED, "q4 gemm: groupsize (%d) must be a multiple of 16", w->groupsize);
+    const f16* xin = x;
+    if (w->x_map) {
+        EXL_REQUIRE(remap_tmp && remap_tmp_numel >= (size_t) rows * K, EXL_E_TOO_SMALL,
+                    "q4 gemm: temp_state buffer is too small for the act-order gather (%zu < %zu halves)",
+                    remap_tmp_numel, (size_t) rows * K);
+        EXL_TRY(launch_column_remap(x, remap_tmp, rows, K, w->x_map, s));
+        xin = remap_tmp;
+    }
+    int gshift = -1;
+    if ((w->groupsize & (w->groupsize - 1)) == 0) { gshift = 0; while ((1 << gshift) < w->groupsize) ++gshift; }
+    const int mtiles = (rows + BM - 1) / BM;
+    const int ntiles = (N + BN - 1) / BN;
+    const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
+    hipLaunchKernelGGL(q4_gemm_kernel, dim3(grid), dim3(256), 0, s, xin, w->qweight, w->qzeros, w->scales, out, rows, K,
+                       N, gshift, w->groupsize, no_zero, mtiles, ntiles);
+    EXL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Plain fp16 GEMM out (+)= x[M,K] @ w[K,N] for the LoRA side path (reference: half_matmul.cu).  Small and
+// simple on purpose (64x64 tile, MFMA 32x32x16, fp32 accumulate): this op is not on the no-LoRA hot path.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void half_gemm_kernel(const f16* __restrict__ x, const f16* __restrict__ w,
+                                                        f16* __restrict__ out, int M, int K, int N, int no_zero)
+{
+    __shared__ f16 As[64][16 + 8];      // [m][k]
+    __shared__ f16 Bs[64][16 + 8];      // [n][k]  (transposed on the way in)
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = lane >> 5, c = lane & 31;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        for (int i = tid; i < 64 * 16; i += 256) {
+            const int r = i >> 4, kk = i & 15;
+            const int row = m0 + r, k = k0 + kk;
+            As[r][kk] = (row < M && k < K) ? x[(size_t) row * K + k] : (f16) 0.f;
+            const int kb = i >> 6, nn = i & 63;            // coalesced along n
+            const int col = n0 + nn, k2 = k0 + kb;
+            Bs[nn][kb] = (col < N && k2 < K) ? w[(size_t) k2 * N + col] : (f16) 0.f;
+        }
+        __syncthreads();
+        const f16x8 af = *(const f16x8*) &As[wm * 32 + c][g * 8];
+        const f16x8 bf = *(const f16x8*) &Bs[wn * 32 + c][g * 8];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+        __syncthreads();
+    }
+    const int col = n0 + wn * 32 + c;
+    if (col >= N) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        if (row < M) {
+            float v = acc[r];
+            if (no_zero) v += (float) out[(size_t) row * N + col];
+            out[(size_t) row * N + col] = (f16) v;
+        }
+    }
+}
+
+int launch_half_gemm(const f16* x, const f16* w, f16* out, int M, int K, int N, int no_zero, hipStream_t s)
+{
+    if (M <= 0 || N <= 0) return 0;
+    dim3 grid((N + 63) / 64, (M + 63) / 64);
+    hipLaunchKernelGGL(half_gemm_kernel, grid, dim3(256), 0, s, x, w, out, M, K, N, no_zero);
+    EXL_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,298 @@
+// Decode path: out[M,N] (+)= x[M,K] @ dequant(W[K,N]) for M <= 8 -- a bandwidth-bound wave64 GEMV.
+//
+// Replaces /root/reference/exllama_ext/cuda_func/q4_matmul.cu:35-212 (q4_matmul_kernel) and the
+// dot_product_8* helpers of /root/reference/exllama_ext/matrix.cuh:87-286.  Same algebra
+//     out[m,n] = sum_g scale[g,n] * sum_{k in g} x[m,k] * (q[k,n] - (z[g,n] + 1))
+// but designed for CDNA4 instead of translated:
+//   * packed weights are read straight from the GPTQ layout with 128-bit loads: one lane = one uint4 =
+//     4 adjacent output columns x 8 consecutive k;  TX lanes side by side cover full 128-byte lines;
+//   * the other lanes of the block walk DIFFERENT k-chunks of the same column tile (TY k-slices), every
+//     lane issues its whole chunk of loads before consuming the first (deep memory-level parallelism,
+//     no LDS round trip for weights);
+//   * nibbles are expanded with the fp16 magic-number trick (0x6400 | q -> 1024 + q) two at a time,
+//     zero-point removed exactly in fp16, products accumulated in FP32 with v_dot2_f32_f16;
+//   * x (gathered through x_map for act-order weights -- the reference's separate column_remap pass is
+//     fused here) is staged once per block in LDS, pre-permuted to the nibble-pair order;
+//   * k-slices are combined with wave shuffles + LDS; split-K across blocks writes fp32 slabs that a
+//     tiny second kernel sums in a FIXED order.  No atomics anywhere -> bit-reproducible run to run
+//     (the reference uses fp16 atomicAdd, q4_matmul.cu:206).
+#include "common.h"
+
+#define MAGIC_1024 0x64006400u
+
+__device__ __forceinline__ f16x2 as_h2(uint32_t v) { return __builtin_bit_cast(f16x2, v); }
+
+// (h0..h7) -> (h0,h4),(h1,h5),(h2,h6),(h3,h7): the order in which the nibble pairs come out of a packed word
+__device__ __forceinline__ uint4 permute_x8(uint4 d)
+{
+    uint4 o;
+    o.x = (d.x & 0xFFFFu) | (d.z << 16);
+    o.y = (d.x >> 16) | (d.z & 0xFFFF0000u);
+    o.z = (d.y & 0xFFFFu) | (d.w << 16);
+    o.w = (d.y >> 16) | (d.w & 0xFFFF0000u);
+    return o;
+}
+
+// sum_k x[k] * (q[k] - z) over the 8 nibbles of `w`;  x4 = 8 halves in permuted pair order
+__device__ __forceinline__ float dot8(uint32_t w, const uint4& x4, f16x2 zc0, f16x2 zc1, float acc)
+{
+    const f16x2 sixteenth = {(f16) 0.0625f, (f16) 0.0625f};
+    const uint32_t w8 = w >> 8;
+    const f16x2 d0 = as_h2((w & 0x000F000Fu) | MAGIC_1024) + zc0;                    // (q0 - z, q4 - z)
+    const f16x2 d1 = as_h2((w & 0x00F000F0u) | MAGIC_1024) * sixteenth + zc1;        // (q1 - z, q5 - z)
+    const f16x2 d2 = as_h2((w8 & 0x000F000Fu) | MAGIC_1024) + zc0;                   // (q2 - z, q6 - z)
+    const f16x2 d3 = as_h2((w8 & 0x00F000F0u) | MAGIC_1024) * sixteenth + zc1;       // (q3 - z, q7 - z)
+    acc = __builtin_amdgcn_fdot2(d0, as_h2(x4.x), acc, false);
+    acc = __builtin_amdgcn_fdot2(d1, as_h2(x4.y), acc, false);
+    acc = __builtin_amdgcn_fdot2(d2, as_h2(x4.z), acc, false);
+    acc = __builtin_amdgcn_fdot2(d3, as_h2(x4.w), acc, false);
+    return acc;
+}
+
+// M  : rows of x held per block (1, 2, 4, 8; real row count `rows` <= M)
+// TX : lanes across N (uint4 each) -> BN = 4 * TX columns per block; TY = 256 / TX k-slices
+// CH : packed rows (8 k each) per chunk; a chunk never straddles a group when groupsize >= 8 * CH
+template <int M, int TX, int CH>
+__global__ __launch_bounds__(256) void q4_gemv_kernel(const f16* __restrict__ x, const uint4* __restrict__ qweight,
+                                                      const uint32_t* __restrict__ qzeros,
+                                                      const f16* __restrict__ scales,
+                                                      const uint32_t* __restrict__ x_map, f16* __restrict__ out,
+                                                      float* __restrict__ slabs, int rows, int K, int N, int groupsize,
+                                                      int prows_per_block, int no_zero, int splitk)
+{
+    constexpr int TY = 256 / TX;
+    constexpr int BN = 4 * TX;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int tx = tid % TX;
+    const int ty = tid / TX;
+    const int n4 = N >> 2;
+    const int col = blockIdx.x * BN + tx * 4;
+    const int prow_total = K >> 3;
+    const int r0 = blockIdx.y * prows_per_block;
+    const int r1 = min(prow_total, r0 + prows_per_block);
+    const int nrows = r1 - r0;                               // packed rows handled by this block
+
+    // ---- stage x[:, 8*r0 .. 8*r1) into LDS, permuted, gathered through x_map when present ----------
+    uint4* xs = (uint4*) smem;                               // [M][nrows] uint4 (8 halves each)
+    for (int idx = tid; idx < M * nrows; idx += 256) {
+        const int m = idx / nrows;
+        const int rr = idx - m * nrows;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (m < rows) {
+            const f16* xr = x + (size_t) m * K;
+            const int k = (r0 + rr) * 8;
+            if (x_map) {
+                const uint4 m0 = *(const uint4*) (x_map + k);
+                const uint4 m1 = *(const uint4*) (x_map + k + 4);
+                f16x8 g;
+                g[0] = xr[m0.x]; g[1] = xr[m0.y]; g[2] = xr[m0.z]; g[3] = xr[m0.w];
+                g[4] = xr[m1.x]; g[5] = xr[m1.y]; g[6] = xr[m1.z]; g[7] = xr[m1.w];
+                v = __builtin_bit_cast(uint4, g);
+            } else {
+                v = *(const uint4*) (xr + k);
+            }
+        }
+        xs[idx] = permute_x8(v);
+    }
+    __syncthreads();
+
+    float acc[M][4];
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = 0.f;
+
+    const bool col_ok = col < N;
+    const int gprows = groupsize >> 3;                       // packed rows per group
+    const uint4* wcol = qweight + (col >> 2);
+
+    for (int c0 = ty * CH; c0 < nrows; c0 += TY * CH) {
+        // issue the whole chunk's weight loads first
+        uint4 wv[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int rr = c0 + i;
+            wv[i] = (col_ok && rr < nrows) ? nt_load16(wcol + (size_t) (r0 + rr) * n4)
+                                           : make_uint4(0, 0, 0, 0);
+        }
+        // group bookkeeping without per-row divisions: `until` = packed rows left in the current group
+        const int rbase = r0 + c0;
+        int g = rbase / gprows;
+        int until = gprows - (rbase - g * gprows);
+        f16x2 zc0[4], zc1[4];
+        float sc[4];
+        float part[M][4];
+        auto load_group = [&](int grp) {
+            uint32_t zw = 0;
+            f16x4 s4 = {(f16) 0.f, (f16) 0.f, (f16) 0.f, (f16) 0.f};
+            if (col_ok) {
+                zw = qzeros[(size_t) grp * (N >> 3) + (col >> 3)];
+                s4 = *(const f16x4*) (scales + (size_t) grp * N + col);
+            }
+            const int sh = (col & 7) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int z = (int) ((zw >> (sh + 4 * j)) & 0xFu) + 1;
+                const f16 a = (f16) (float) (-(1024 + z));
+                const f16 b = (f16) (float) (-(64 + z));
+                zc0[j] = (f16x2){a, a};
+                zc1[j] = (f16x2){b, b};
+                sc[j] = (float) s4[j];
+            }
+#pragma unroll
+            for (int m = 0; m < M; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) part[m][j] = 0.f;
+        };
+        auto flush_group = [&]() {
+#pragma unroll
+            for (int m = 0; m < M; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[m][j] = fmaf(sc[j], part[m][j], acc[m][j]);
+        };
+        load_group(g);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int rr = c0 + i;
+            if (rr < nrows) {
+                if (until == 0) { flush_group(); ++g; load_group(g); until = gprows; }
+                --until;
+                const uint32_t words[4] = {wv[i].x, wv[i].y, wv[i].z, wv[i].w};
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const uint4 x4 = xs[m * nrows + rr];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) part[m][j] = dot8(words[j], x4, zc0[j], zc1[j], part[m][j]);
+                }
+            }
+        }
+        flush_group();
+    }
+
+    // ---- combine the TY k-slices: shuffles inside the wave, LDS across the 4 waves -------------------
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = acc[m][j];
+#pragma unroll
+            for (int off = TX; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+            acc[m][j] = v;
+        }
+    __syncthreads();                                          // xs no longer needed: reuse LDS
+    float* red = (float*) smem;                               // [4 waves][M][BN]
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    if (lane < TX) {
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[(wave * M + m) * BN + lane * 4 + j] = acc[m][j];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < M * BN; idx += 256) {
+        const int m = idx / BN;
+        const int c = idx - m * BN;
+        const int n = blockIdx.x * BN + c;
+        if (m < rows && n < N) {
+            const float v = red[(0 * M + m) * BN + c] + red[(1 * M + m) * BN + c] + red[(2 * M + m) * BN + c] +
+                            red[(3 * M + m) * BN + c];
+            if (splitk == 1) {
+                float r = v;
+                if (no_zero) r += (float) out[(size_t) m * N + n];
+                out[(size_t) m * N + n] = (f16) r;
+            } else {
+                slabs[((size_t) blockIdx.y * rows + m) * N + n] = v;
+            }
+        }
+    }
+}
+
+// out[m,n] = h( sum_s slabs[s,m,n] (+ out[m,n]) ), slices added in ascending order.
+__global__ __launch_bounds__(256) void q4_gemv_reduce_kernel(const float* __restrict__ slabs, f16* __restrict__ out,
+                                                             int total, int splitk, int no_zero)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    float v = 0.f;
+    for (int s = 0; s < splitk; ++s) v += slabs[(size_t) s * total + i];
+    if (no_zero) v += (float) out[i];
+    out[i] = (f16) v;
+}
+
+template <int M, int TX>
+static int launch_cfg(int ch, dim3 grid, size_t smem, hipStream_t s, const f16* x, const Q4Matrix* w, f16* out,
+                      float* slabs, int rows, int prows_per_block, int no_zero, int splitk)
+{
+#define GEMV_ARGS x, (const uint4*) w->qweight, w->qzeros, w->scales, w->x_map, out, slabs, rows, w->height, \
+                  w->width, w->groupsize, prows_per_block, no_zero, splitk
+    if (ch == 16)     hipLaunchKernelGGL((q4_gemv_kernel<M, TX, 16>), grid, dim3(256), smem, s, GEMV_ARGS);
+    else if (ch == 8) hipLaunchKernelGGL((q4_gemv_kernel<M, TX, 8>),  grid, dim3(256), smem, s, GEMV_ARGS);
+    else              hipLaunchKernelGGL((q4_gemv_kernel<M, TX, 4>),  grid, dim3(256), smem, s, GEMV_ARGS);
+#undef GEMV_ARGS
+    EXL_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_q4_gemv(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_zero, float* ws, size_t ws_floats,
+                   hipStream_t s)
+{
+    if (rows <= 0) return 0;
+    const int K = w->height, N = w->width;
+    EXL_REQUIRE(rows <= 8, EXL_E_UNSUPPORTED, "q4 gemv: rows (%d) > 8", rows);
+    EXL_REQUIRE(N % 4 == 0 && K % 8 == 0, EXL_E_UNSUPPORTED, "q4 gemv: need N %% 4 == 0 and K %% 8 == 0");
+    EXL_REQUIRE(w->groupsize % 8 == 0, EXL_E_UNSUPPORTED, "q4 gemv: groupsize (%d) must be a multiple of 8", w->groupsize);
+
+    constexpr int TX = 8, TY = 32, BN = 32;
+    const int M = rows == 1 ? 1 : rows == 2 ? 2 : rows <= 4 ? 4 : 8;
+    const int prow_total = K / 8;
+    const int nb_n = (N + BN - 1) / BN;
+
+    // chunk length: at most one group, at most 16 packed rows
+    int ch = 16;
+    while (ch > 4 && (ch * 8 > w->groupsize || ch * TY > prow_total)) ch >>= 1;
+    // split K across blocks until the grid holds >= ~2 blocks per CU, keeping every k-slice busy
+    int splitk = 1;
+    while (nb_n * splitk < 512 && prow_total / (splitk * 2) >= TY * 4 && splitk < 16) {
+        splitk *= 2;
+        while (ch > 4 && ch * TY * splitk > prow_total) ch >>= 1;
+    }
+    // LDS bound: M * nrows * 16 B <= 64 KiB
+    int prows_per_block = (prow_total + splitk - 1) / splitk;
+    prows_per_block = (prows_per_block + ch - 1) / ch * ch;
+    while ((size_t) M * prows_per_block * 16 > 64 * 1024) {
+        splitk *= 2;
+        prows_per_block = (prow_total + splitk - 1) / splitk;
+        prows_per_block = (prows_per_block + ch - 1) / ch * ch;
+    }
+    splitk = (prow_total + prows_per_block - 1) / prows_per_block;
+
+    float* slabs = nullptr;
+    if (splitk > 1) {
+        const size_t need = (size_t) splitk * rows * N;
+        EXL_REQUIRE(ws && ws_floats >= need, EXL_E_TOO_SMALL, "q4 gemv: workspace too small (%zu < %zu floats)",
+                    ws_floats, need);
+        slabs = ws;
+    }
+    const size_t smem_x = (size_t) M * prows_per_block * 16;
+    const size_t smem_r = (size_t) 4 * M * BN * sizeof(float);
+    const size_t smem = smem_x > smem_r ? smem_x : smem_r;
+    dim3 grid(nb_n, splitk);
+    int r;
+    switch (M) {
+        case 1:  r = launch_cfg<1, TX>(ch, grid, smem, s, x, w, out, slabs, rows, prows_per_block, no_zero, splitk); break;
+        case 2:  r = launch_cfg<2, TX>(ch, grid, smem, s, x, w, out, slabs, rows, prows_per_block, no_zero, splitk); break;
+        case 4:  r = launch_cfg<4, TX>(ch, grid, smem, s, x, w, out, slabs, rows, prows_per_block, no_zero, splitk); break;
+        default: r = launch_cfg<8, TX>(ch, grid, smem, s, x, w, out, slabs, rows, prows_per_block, no_zero, splitk); break;
+    }
+    if (r) return r;
+    if (splitk > 1) {
+        const int total = rows * N;
+        hipLaunchKernelGGL(q4_gemv_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, slabs, out, total, splitk,
+                           no_zero);
+        EXL_LAUNCH_CHECK();
+    }
+    return 0;
+}

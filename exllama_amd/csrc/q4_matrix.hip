@@ -1,0 +1,117 @@
+// Q4 matrix construction, act-order repack, full dequantisation and the activation gather.
+//
+// Behavioural reference (arithmetic only; the kernels are written for wave64 / 128-bit accesses):
+//   /root/reference/exllama_ext/cuda_func/q4_matrix.cu:61-102   make_sequential_kernel
+//   /root/reference/exllama_ext/cuda_func/q4_matrix.cu:104-168  Q4Matrix::make_sequential
+//   /root/reference/exllama_ext/cuda_func/q4_matrix.cu:170-224  reconstruct_kernel / reconstruct
+//   /root/reference/exllama_ext/cuda_func/column_remap.cu:7-61  column_remap
+#include "common.h"
+
+// New packed row r takes nibble i from old row x_map[8r + i].  One thread = 4 adjacent columns (128-bit).
+__global__ __launch_bounds__(256) void make_sequential_kernel(const uint4* __restrict__ w, uint4* __restrict__ w_new,
+                                                              const uint32_t* __restrict__ x_map, int n4)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= n4) return;
+    uint4 dst = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t src = x_map[r * 8 + i];          // block-uniform -> scalar load
+        const uint4 v = w[(size_t) (src >> 3) * n4 + c];
+        const int sh = (src & 7) * 4;
+        dst.x |= ((v.x >> sh) & 0xFu) << (4 * i);
+        dst.y |= ((v.y >> sh) & 0xFu) << (4 * i);
+        dst.z |= ((v.z >> sh) & 0xFu) << (4 * i);
+        dst.w |= ((v.w >> sh) & 0xFu) << (4 * i);
+    }
+    w_new[(size_t) r * n4 + c] = dst;
+}
+
+int launch_make_sequential(Q4Matrix* m, const uint32_t* x_map_host, hipStream_t s)
+{
+    const size_t wbytes = (size_t) (m->height / 8) * m->width * sizeof(uint32_t);
+    uint32_t* tmp = nullptr;
+    EXL_HIP(hipMalloc((void**) &tmp, wbytes));
+    EXL_HIP(hipMalloc((void**) &m->x_map, (size_t) m->height * sizeof(uint32_t)));
+    EXL_HIP(hipMemcpyAsync(m->x_map, x_map_host, (size_t) m->height * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    const int n4 = m->width / 4;
+    dim3 grid((n4 + 255) / 256, m->height / 8);
+    hipLaunchKernelGGL(make_sequential_kernel, grid, dim3(256), 0, s, (const uint4*) m->qweight, (uint4*) tmp,
+                       m->x_map, n4);
+    EXL_LAUNCH_CHECK();
+    EXL_HIP(hipMemcpyAsync(m->qweight, tmp, wbytes, hipMemcpyDeviceToDevice, s));
+    EXL_HIP(hipStreamSynchronize(s));
+    EXL_HIP(hipFree(tmp));
+    return 0;
+}
+
+// W16[8r + j, n] = half(q - (z + 1)) * scale   (one fp16 multiply, as q4_matrix.cu:207)
+__global__ __launch_bounds__(256) void reconstruct_kernel(const uint4* __restrict__ w, f16* __restrict__ out,
+                                                          const f16* __restrict__ scales,
+                                                          const uint32_t* __restrict__ qzeros, int n4, int width,
+                                                          int groupsize)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;       // column quad
+    const int r = blockIdx.y;                           // packed row
+    if (c >= n4) return;
+    const int group = (r * 8) / groupsize;
+    const int col = c * 4;
+    const uint32_t zw = qzeros[(size_t) group * (width / 8) + (col >> 3)];
+    const f16x4 sc = *(const f16x4*) (scales + (size_t) group * width + col);
+    const uint4 v = w[(size_t) r * n4 + c];
+    const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+    int z[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) z[j] = (int) ((zw >> (4 * ((col & 7) + j))) & 0xFu) + 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        f16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = (int) ((words[j] >> (4 * i)) & 0xFu);
+            o[j] = (f16) (q - z[j]) * sc[j];
+        }
+        *(f16x4*) (out + (size_t) (r * 8 + i) * width + col) = o;
+    }
+}
+
+int launch_reconstruct(const Q4Matrix* m, f16* out, hipStream_t s)
+{
+    const int n4 = m->width / 4;
+    dim3 grid((n4 + 255) / 256, m->height / 8);
+    hipLaunchKernelGGL(reconstruct_kernel, grid, dim3(256), 0, s, (const uint4*) m->qweight, out, m->scales,
+                       m->qzeros, n4, m->width, m->groupsize);
+    EXL_LAUNCH_CHECK();
+    return 0;
+}
+
+// x_new[m, c] = x[m, x_map[c]];  one thread = 8 destination columns (one 128-bit store), 8 gathered halves.
+__global__ __launch_bounds__(256) void column_remap_kernel(const f16* __restrict__ x, f16* __restrict__ x_new,
+                                                           const uint32_t* __restrict__ x_map, int width)
+{
+    const int c8 = blockIdx.x * 256 + threadIdx.x;
+    const int row = blockIdx.y;
+    const int c = c8 * 8;
+    if (c >= width) return;
+    const f16* xr = x + (size_t) row * width;
+    if (c + 8 <= width) {
+        const uint4 m0 = *(const uint4*) (x_map + c);
+        const uint4 m1 = *(const uint4*) (x_map + c + 4);
+        f16x8 o;
+        o[0] = xr[m0.x]; o[1] = xr[m0.y]; o[2] = xr[m0.z]; o[3] = xr[m0.w];
+        o[4] = xr[m1.x]; o[5] = xr[m1.y]; o[6] = xr[m1.z]; o[7] = xr[m1.w];
+        *(f16x8*) (x_new + (size_t) row * width + c) = o;
+    } else {
+        for (int i = c; i < width; ++i) x_new[(size_t) row * width + i] = xr[x_map[i]];
+    }
+}
+
+int launch_column_remap(const f16* x, f16* x_new, int height, int width, const uint32_t* x_map, hipStream_t s)
+{
+    if (height <= 0) return 0;
+    dim3 grid(((width + 7) / 8 + 255) / 256, height);
+    hipLaunchKernelGGL(column_remap_kernel, grid, dim3(256), 0, s, x, x_new, x_map, width);
+    EXL_LAUNCH_CHECK();
+    return 0;
+}

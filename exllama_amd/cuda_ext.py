@@ -1,0 +1,430 @@
+"""Host-side mirror of the reference's operator surface for the GPTQ hot path.
+
+Same names, argument meaning and error behaviour as /root/reference/cuda_ext.py:87-166 and the pybind
+module it JIT-builds (/root/reference/exllama_ext/exllama_ext.cpp:743-762) -- but backed by the
+hand-written HIP library `libexl_amd.so` through its C ABI (include/exl_amd.h).  The reference's
+`model.py` / `generator.py` run against this module unchanged (`import cuda_ext` resolves to the shim at
+the repository root).
+
+    cuda_ext.exllama_ext.<fn>(...)      the 16 functions of the pybind module
+    cuda_ext.ext_make_q4 / ext_q4_matmul / ext_half_matmul / ext_rope_ / ext_rms_norm(_) /
+    cuda_ext.ext_rep_penalty_mask_cpu / ext_apply_rep_penalty_mask_cpu
+    cuda_ext.none_tensor                 the meta-device "None" sentinel (cuda_ext.py:82)
+
+There is no fallback: tensors must live on a HIP device ("cuda:N" in PyTorch-ROCm) and the native
+library must be built, otherwise these functions raise RuntimeError.
+"""
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+# Dummy tensor to pass instead of None (reference: cuda_ext.py:80-82)
+none_tensor = torch.empty((1, 1), device="meta")
+
+
+def _is_none(t):
+    return t is None or t.device.type == "meta"
+
+
+def _ptr(t):
+    return None if _is_none(t) else t.data_ptr()
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _req(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _req_dtype(t, dtype, name):
+    _req(t.dtype == dtype, f"{name} is incorrect datatype, must be {dtype}")
+
+
+def _req_cuda(t, name):
+    _req(t.is_cuda, f"{name} must be on a HIP device (exllama_amd has no CPU path), got {t.device}")
+    _req(t.is_contiguous(), f"{name} must be contiguous")
+
+
+class _Guard:
+    """Make `device` current for the duration of a native call (reference: OptionalCUDAGuard)."""
+
+    def __init__(self, device):
+        self.idx = device.index if isinstance(device, torch.device) else int(device)
+        self.prev = None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *a):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+
+
+class _ExllamaExt:
+    """Drop-in for the pybind module `exllama_ext` (exllama_ext.cpp:743-762)."""
+
+    def __init__(self):
+        self._lib = _lib.load()
+        self.tuning = _lib.ExlTuning(8, 2, 8, 0, 0, 0, 0, 0, 0)
+
+    # -- exllama_ext.cpp:89-112
+    def set_tuning_params(self, matmul_recons_thd, fused_mlp_thd, sdp_thd, matmul_fused_remap, rmsnorm_no_half2,
+                          rope_no_half2, matmul_no_half2, silu_no_half2, concurrent_streams):
+        self.tuning = _lib.ExlTuning(int(matmul_recons_thd), int(fused_mlp_thd), int(sdp_thd), int(matmul_fused_remap),
+                                     int(rmsnorm_no_half2), int(rope_no_half2), int(matmul_no_half2),
+                                     int(silu_no_half2), int(concurrent_streams))
+        check(self._lib.exl_set_tuning(C.byref(self.tuning)), "set_tuning_params")
+
+    # -- exllama_ext.cpp:126-152
+    def prepare_buffers(self, device, temp_state, temp_mlp, temp_zeros_float, temp_dq):
+        device = torch.device(device)
+        _req(device.index is not None and device.index >= 0, "no device index")
+        for t, n in ((temp_state, "temp_state"), (temp_mlp, "temp_mlp"), (temp_zeros_float, "temp_zeros_float"), (temp_dq, "temp_dq")):
+            _req_cuda(t, n)
+        with _Guard(device):
+            check(self._lib.exl_prepare_buffers(device.index, temp_state.data_ptr(), temp_state.numel(),
+                                                temp_mlp.data_ptr(), temp_mlp.numel(), temp_zeros_float.data_ptr(),
+                                                temp_zeros_float.size(-1), temp_dq.data_ptr(), temp_dq.numel()),
+                  "prepare_buffers")
+
+    # -- exllama_ext.cpp:117-121
+    def cleanup(self):
+        check(self._lib.exl_cleanup(), "cleanup")
+
+    # -- exllama_ext.cpp:157-194
+    def make_q4(self, qweight, qzeros, scales, g_idx, device):
+        _req_dtype(qweight, torch.int32, "qweight")
+        _req_dtype(qzeros, torch.int32, "qzeros")
+        _req_dtype(scales, torch.float16, "scales")
+        if not _is_none(g_idx):
+            _req_dtype(g_idx, torch.int32, "g_idx")
+        _req(qweight.size(1) == qzeros.size(1) * 8, "qweight and qzeros have incompatible shapes")
+        _req(scales.size(1) == qweight.size(1), "scales and qweight have incompatible shapes")
+        _req(qzeros.size(0) == scales.size(0), "qzeros and scales have incompatible shapes")
+        for t, n in ((qweight, "qweight"), (qzeros, "qzeros"), (scales, "scales")):
+            _req_cuda(t, n)
+        _req(device is not None and device >= 0, "no device index")
+        g_host = None
+        if not _is_none(g_idx):
+            g_host = g_idx.detach().to("cpu").contiguous()          # the reference passes the CPU tensor (model.py:144)
+            _req(g_host.numel() == qweight.size(0) * 8, "g_idx and qweight have incompatible shapes")
+        handle = C.c_void_p()
+        with _Guard(device):
+            check(self._lib.exl_make_q4(int(device), qweight.size(0) * 8, qweight.size(1), qzeros.size(0),
+                                        qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(),
+                                        None if g_host is None else g_host.data_ptr(), _stream(qweight),
+                                        C.byref(handle)), "make_q4")
+        return handle.value
+
+    def q4_info(self, w):
+        vals = [C.c_int() for _ in range(5)]
+        xm = C.c_void_p()
+        check(self._lib.exl_q4_info(w, *[C.byref(v) for v in vals], C.byref(xm)), "q4_info")
+        keys = ("device", "height", "width", "groups", "groupsize")
+        d = {k: v.value for k, v in zip(keys, vals)}
+        d["x_map"] = xm.value
+        return d
+
+    def _check_mm(self, x, w, out):
+        _req_dtype(x, torch.float16, "x")
+        _req_dtype(out, torch.float16, "out")
+        _req_cuda(x, "x")
+        _req_cuda(out, "out")
+        _req(x.size(0) == out.size(0), "x and out have incompatible shapes")
+        info = self.q4_info(w)
+        _req(info["height"] == x.size(-1), "x and w have incompatible shapes")
+        _req(out.size(-1) == info["width"], "out and w have incompatible shapes")
+
+    # -- exllama_ext.cpp:199-240
+    def q4_matmul(self, x, w, out):
+        self._check_mm(x, w, out)
+        with _Guard(x.device):
+            check(self._lib.exl_q4_matmul(w, x.data_ptr(), x.size(0), out.data_ptr(), 0, _stream(x)), "q4_matmul")
+
+    # individual kernels (used by tests and by -v style A/B comparisons)
+    def q4_matmul_gemv(self, x, w, out, no_zero=False):
+        self._check_mm(x, w, out)
+        with _Guard(x.device):
+            check(self._lib.exl_q4_matmul_gemv(w, x.data_ptr(), x.size(0), out.data_ptr(), int(no_zero), _stream(x)), "q4_matmul_gemv")
+
+    def q4_matmul_gemm(self, x, w, out, no_zero=False):
+        self._check_mm(x, w, out)
+        with _Guard(x.device):
+            check(self._lib.exl_q4_matmul_gemm(w, x.data_ptr(), x.size(0), out.data_ptr(), int(no_zero), _stream(x)), "q4_matmul_gemm")
+
+    def q4_reconstruct(self, w, out):
+        _req_dtype(out, torch.float16, "out")
+        _req_cuda(out, "out")
+        info = self.q4_info(w)
+        _req(out.numel() >= info["height"] * info["width"], "out is too small")
+        with _Guard(out.device):
+            check(self._lib.exl_q4_reconstruct(w, out.data_ptr(), _stream(out)), "q4_reconstruct")
+
+    # -- exllama_ext.cpp:245-324
+    def q4_matmul_lora(self, x, w, out, lora_A, lora_B, lora_temp):
+        self._check_mm(x, w, out)
+        _req(x.size(0) == lora_temp.size(0), "x and lora_temp have incompatible shapes")
+        _req(x.size(1) == lora_A.size(0), "x and lora_A have incompatible shapes")
+        _req(lora_A.size(1) == lora_B.size(0), "lora_A and lora_B have incompatible shapes")
+        _req(lora_B.size(1) == out.size(1), "lora_B and out have incompatible shapes")
+        for t, n in ((lora_A, "lora_A"), (lora_B, "lora_B"), (lora_temp, "lora_temp")):
+            _req_dtype(t, torch.float16, n)
+            _req_cuda(t, n)
+        with _Guard(x.device):
+            check(self._lib.exl_q4_matmul_lora(w, x.data_ptr(), x.size(0), out.data_ptr(), lora_A.data_ptr(),
+                                               lora_B.data_ptr(), lora_A.size(1), lora_temp.data_ptr(), _stream(x)),
+                  "q4_matmul_lora")
+
+    # -- exllama_ext.cpp:328-358
+    def column_remap(self, x, x_new, x_map):
+        _req_dtype(x, torch.float16, "x")
+        _req_dtype(x_new, torch.float16, "x_new")
+        _req_dtype(x_map, torch.int32, "x_map")
+        _req(x_map.size(0) == x.size(1), "x_map and x have incompatible shapes")
+        _req(x_new.numel() >= x.size(0) * x.size(1), "x_new is too small")
+        for t, n in ((x, "x"), (x_new, "x_new"), (x_map, "x_map")):
+            _req_cuda(t, n)
+        with _Guard(x.device):
+            check(self._lib.exl_column_remap(x.data_ptr(), x_new.data_ptr(), x.size(0), x.size(1), x_map.data_ptr(),
+                                             _stream(x)), "column_remap")
+
+    # -- exllama_ext.cpp:362-422.  half_matmul expects a pre-zeroed `out` and accumulates (the reference's split-K
+    #    atomics do); half_matmul_cublas overwrites.
+    def _half_mm(self, x, w, out, no_zero, name):
+        for t, n in ((x, "x"), (w, "w"), (out, "out")):
+            _req_dtype(t, torch.float16, n)
+            _req_cuda(t, n)
+        _req(x.size(1) == w.size(0), "x and w have incompatible shapes")
+        with _Guard(x.device):
+            check(self._lib.exl_half_matmul(x.data_ptr(), w.data_ptr(), out.data_ptr(), x.size(0), x.size(1), w.size(1),
+                                            int(no_zero), _stream(x)), name)
+
+    def half_matmul(self, x, w, out):
+        self._half_mm(x, w, out, True, "half_matmul")
+
+    def half_matmul_cublas(self, x, w, out):
+        self._half_mm(x, w, out, False, "half_matmul_cublas")
+
+    # -- exllama_ext.cpp:606-643
+    def rms_norm(self, x, w, out, epsilon):
+        for t, n in ((x, "x"), (w, "w"), (out, "out")):
+            _req_dtype(t, torch.float16, n)
+            _req_cuda(t, n)
+        _req(x.size(1) == w.size(0), "x and w have incompatible shapes")
+        _req(x.size(0) == out.size(0) and x.size(1) == out.size(1), "x and out have incompatible shapes")
+        with _Guard(x.device):
+            check(self._lib.exl_rms_norm(x.data_ptr(), w.data_ptr(), out.data_ptr(), float(epsilon), x.size(0), x.size(1),
+                                         _stream(x)), "rms_norm")
+
+    # -- exllama_ext.cpp:647-680
+    def rope_(self, x, sin, cos, past_len, num_heads, head_dim, past_len_dev=None):
+        for t, n in ((x, "x"), (sin, "sin"), (cos, "cos")):
+            _req_dtype(t, torch.float16, n)
+            _req_cuda(t, n)
+        _req(head_dim == cos.size(-1), "cos table does not match head_dim")
+        _req(head_dim == sin.size(-1), "sin table does not match head_dim")
+        bsz = x.size(0)
+        rows_per_batch = x.numel() // head_dim // bsz
+        with _Guard(x.device):
+            check(self._lib.exl_rope(x.data_ptr(), sin.data_ptr(), cos.data_ptr(), bsz, rows_per_batch, head_dim,
+                                     num_heads, int(past_len), _ptr(past_len_dev), _stream(x)), "rope_")
+
+    def silu_mul(self, x, y):
+        for t, n in ((x, "x"), (y, "y")):
+            _req_dtype(t, torch.float16, n)
+            _req_cuda(t, n)
+        _req(x.shape == y.shape, "x and y have incompatible shapes")
+        with _Guard(x.device):
+            check(self._lib.exl_silu_mul(x.data_ptr(), y.data_ptr(), x.numel() // x.size(-1), x.size(-1), _stream(x)), "silu_mul")
+
+    def update_cache(self, key_states, value_states, key_cache, value_cache, past_len, past_len_dev=None):
+        bsz, q_len, _ = key_states.shape
+        kvh, max_seq, hd = key_cache.size(1), key_cache.size(2), key_cache.size(3)
+        for t, n in ((key_states, "key_states"), (value_states, "value_states"), (key_cache, "key_cache"), (value_cache, "value_cache")):
+            _req_dtype(t, torch.float16, n)
+            _req_cuda(t, n)
+        with _Guard(key_states.device):
+            check(self._lib.exl_update_cache(key_states.data_ptr(), value_states.data_ptr(), key_cache.data_ptr(),
+                                             value_cache.data_ptr(), bsz, q_len, kvh, hd, max_seq, int(past_len),
+                                             _ptr(past_len_dev), _stream(key_states)), "update_cache")
+
+    def attention(self, q, key_cache, value_cache, out, past_len, num_heads, mask=None, past_len_dev=None):
+        """q/out: [bsz, q_len, heads*hd]; caches [>=bsz, kv_heads, max_seq, hd]."""
+        bsz, q_len, _ = q.shape
+        kvh, max_seq, hd = key_cache.size(1), key_cache.size(2), key_cache.size(3)
+        for t, n in ((q, "q"), (key_cache, "key_cache"), (value_cache, "value_cache"), (out, "out")):
+            _req_dtype(t, torch.float16, n)
+            _req_cuda(t, n)
+        _req(q.size(2) == num_heads * hd, "q does not match num_heads * head_dim")
+        if bsz > 1:
+            _req(key_cache.size(0) == bsz, "cache batch size must equal bsz when bsz > 1")
+        if mask is not None:
+            _req_dtype(mask, torch.float16, "mask")
+            _req_cuda(mask, "mask")
+            _req(mask.numel() == bsz * q_len * (past_len + q_len), "mask has the wrong shape")
+        with _Guard(q.device):
+            check(self._lib.exl_attention(q.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), out.data_ptr(),
+                                          _ptr(mask), bsz, q_len, num_heads, kvh, hd, max_seq, int(past_len),
+                                          _ptr(past_len_dev), _stream(q)), "attention")
+
+    # -- exllama_ext.cpp:424-528
+    def q4_attn(self, x, rms_norm_weight, epsilon, query_states, key_states, value_states, q_proj, k_proj, v_proj,
+                sin, cos, q_len, past_len, num_heads, num_kv_heads, head_dim, key_cache, value_cache, max_seq_len,
+                q_a, q_b, k_a, k_b, v_a, v_b, lora_temp, past_len_dev=None):
+        _req_dtype(query_states, torch.float16, "query_states")
+        _req_dtype(key_states, torch.float16, "key_states")
+        for t, n in ((x, "x"), (rms_norm_weight, "rms_norm_weight"), (query_states, "query_states"),
+                     (key_states, "key_states"), (value_states, "value_states"), (key_cache, "key_cache"),
+                     (value_cache, "value_cache"), (sin, "sin"), (cos, "cos")):
+            _req_cuda(t, n)
+        bsz = query_states.size(0)
+        dim = query_states.size(2)
+        device_index = x.device.index
+        _req(device_index is not None and device_index >= 0, "no device index")
+        q_rank = 0 if _is_none(q_a) else q_a.size(1)
+        k_rank = 0 if _is_none(k_a) else k_a.size(1)
+        v_rank = 0 if _is_none(v_a) else v_a.size(1)
+        with _Guard(x.device):
+            check(self._lib.exl_q4_attn(device_index, x.data_ptr(), rms_norm_weight.data_ptr(), float(epsilon),
+                                        query_states.data_ptr(), key_states.data_ptr(), value_states.data_ptr(),
+                                        q_proj, k_proj, v_proj, sin.data_ptr(), cos.data_ptr(), bsz, q_len, dim, head_dim,
+                                        num_heads, num_kv_heads, int(past_len), _ptr(past_len_dev), key_cache.data_ptr(),
+                                        value_cache.data_ptr(), max_seq_len, _ptr(q_a), _ptr(q_b), q_rank, _ptr(k_a),
+                                        _ptr(k_b), k_rank, _ptr(v_a), _ptr(v_b), v_rank, _ptr(lora_temp), _stream(x)),
+                  "q4_attn")
+
+    # -- exllama_ext.cpp:530-563
+    def q4_attn_2(self, x, attn_output, o_proj, o_a, o_b, lora_temp):
+        _req_dtype(x, torch.float16, "x")
+        _req_dtype(attn_output, torch.float16, "attn_output")
+        _req_cuda(x, "x")
+        _req_cuda(attn_output, "attn_output")
+        # the reference passes x [bsz, q_len, dim] and uses x.size(0) as the row count (rows == 1 there)
+        height = attn_output.numel() // attn_output.size(-1)
+        o_rank = 0 if _is_none(o_a) else o_a.size(1)
+        with _Guard(x.device):
+            check(self._lib.exl_q4_attn_2(x.data_ptr(), attn_output.data_ptr(), o_proj, height, _ptr(o_a), _ptr(o_b),
+                                          o_rank, _ptr(lora_temp), _stream(x)), "q4_attn_2")
+
+    # -- exllama_ext.cpp:567-602
+    def q4_mlp(self, x, rms_norm_weight, epsilon, gate, up, down, gate_a, gate_b, up_a, up_b, down_a, down_b, lora_temp):
+        _req_dtype(x, torch.float16, "x")
+        _req_dtype(rms_norm_weight, torch.float16, "rms_norm_weight")
+        _req_cuda(x, "x")
+        _req_cuda(rms_norm_weight, "rms_norm_weight")
+        height, dim = x.size(0), x.size(1)
+        device_index = x.device.index
+        _req(device_index is not None and device_index >= 0, "no device index")
+        gr = 0 if _is_none(gate_a) else gate_a.size(1)
+        ur = 0 if _is_none(up_a) else up_a.size(1)
+        dr = 0 if _is_none(down_a) else down_a.size(1)
+        with _Guard(x.device):
+            check(self._lib.exl_q4_mlp(device_index, x.data_ptr(), rms_norm_weight.data_ptr(), float(epsilon), gate, up, down,
+                                       height, dim, _ptr(gate_a), _ptr(gate_b), gr, _ptr(up_a), _ptr(up_b), ur,
+                                       _ptr(down_a), _ptr(down_b), dr, _ptr(lora_temp), _stream(x)), "q4_mlp")
+
+    # -- exllama_ext.cpp:684-741 (host tensors)
+    def rep_penalty(self, sequence, rep_mask, penalty_max, sustain, decay):
+        _req_dtype(sequence, torch.int64, "sequence")
+        _req_dtype(rep_mask, torch.float32, "rep_mask")
+        _req(not sequence.is_cuda and not rep_mask.is_cuda, "rep_penalty works on CPU tensors")
+        sequence = sequence.contiguous()
+        check(self._lib.exl_rep_penalty(rep_mask.size(0), sequence.data_ptr(), rep_mask.data_ptr(), float(penalty_max),
+                                        int(sustain), int(decay), sequence.size(-1)), "rep_penalty")
+
+    def apply_rep_penalty(self, sequence, penalty_max, sustain, decay, logits):
+        _req_dtype(sequence, torch.int64, "sequence")
+        _req_dtype(logits, torch.float32, "logits")
+        _req(not sequence.is_cuda and not logits.is_cuda, "apply_rep_penalty works on CPU tensors")
+        _req(sequence.size(0) == logits.size(0), "sequence and logits have incompatible shapes")
+        _req(logits.is_contiguous(), "logits must be contiguous")
+        sequence = sequence.contiguous()
+        check(self._lib.exl_apply_rep_penalty(logits.size(-1), sequence.data_ptr(), float(penalty_max), int(sustain),
+                                              int(decay), sequence.size(-1), sequence.size(0), logits.data_ptr()),
+              "apply_rep_penalty")
+
+
+exllama_ext = _ExllamaExt()
+
+# re-exports at module level, as the reference does (cuda_ext.py:66-77)
+make_q4 = exllama_ext.make_q4
+q4_matmul = exllama_ext.q4_matmul
+q4_matmul_lora = exllama_ext.q4_matmul_lora
+half_matmul = exllama_ext.half_matmul
+half_matmul_cublas = exllama_ext.half_matmul_cublas
+rms_norm = exllama_ext.rms_norm
+rope_ = exllama_ext.rope_
+rep_penalty = exllama_ext.rep_penalty
+apply_rep_penalty = exllama_ext.apply_rep_penalty
+
+
+# ---- Python wrappers (reference: cuda_ext.py:87-166) -------------------------------------------------------
+
+def ext_make_q4(qweight, qzeros, scales, g_idx, device):
+    """Construct Q4Matrix, return handle."""
+    return make_q4(qweight, qzeros, scales, g_idx if g_idx is not None else none_tensor, device)
+
+
+def ext_q4_matmul(x, q4, q4_width, lora_A=None, lora_B=None):
+    """Matrix multiplication, returns x @ q4."""
+    outshape = x.shape[:-1] + (q4_width,)
+    x = x.view(-1, x.shape[-1])
+    output = torch.empty((x.shape[0], q4_width), dtype=torch.float16, device=x.device)
+    if lora_A is None:
+        q4_matmul(x, q4, output)
+    else:
+        lora_temp = torch.empty((x.shape[0], lora_A.shape[1]), dtype=torch.float16, device=x.device)
+        q4_matmul_lora(x, q4, output, lora_A, lora_B, lora_temp)
+    return output.view(outshape)
+
+
+def ext_half_matmul(x, w, cublas=False):
+    """Matrix multiplication, returns x @ w, both half-precision tensors."""
+    outshape = x.shape[:-1] + (w.shape[1],)
+    x = x.view(-1, x.shape[-1])
+    if cublas:
+        output = torch.empty((x.shape[0], w.shape[1]), dtype=torch.float16, device=x.device)
+        half_matmul_cublas(x, w, output)
+    else:
+        output = torch.zeros((x.shape[0], w.shape[1]), dtype=torch.float16, device=x.device)
+        half_matmul(x, w, output)
+    return output.view(outshape)
+
+
+def ext_rope_(x, sin, cos, past_len, num_heads, head_dim):
+    """RoPE embeddings, in place."""
+    rope_(x, sin, cos, past_len, num_heads, head_dim)
+
+
+def ext_rms_norm(x, w, epsilon):
+    """RMS norm: x * w / sqrt(row_mean(x * x) + epsilon)."""
+    outshape = x.shape
+    x = x.view(-1, x.shape[-1])
+    output = torch.empty_like(x)
+    rms_norm(x, w, output, epsilon)
+    return output.view(outshape)
+
+
+def ext_rms_norm_(x, w, epsilon):
+    x = x.view(-1, x.shape[-1])
+    rms_norm(x, w, x, epsilon)
+
+
+def ext_rep_penalty_mask_cpu(vocab_size, sequence, penalty_max, sustain, decay):
+    rep_mask = torch.empty(vocab_size, dtype=torch.float32)
+    rep_penalty(sequence, rep_mask, penalty_max, sustain, decay)
+    return rep_mask
+
+
+def ext_apply_rep_penalty_mask_cpu(sequence, penalty_max, sustain, decay, logits):
+    apply_rep_penalty(sequence, penalty_max, sustain, decay, logits)

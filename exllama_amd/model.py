@@ -1,0 +1,595 @@
+"""ExLlama model API (ExLlamaConfig / ExLlama / ExLlamaCache / ExLlamaDeviceMap) on the MI355X kernels.
+
+Public names, constructor arguments, attributes and `forward()` semantics follow /root/reference/model.py
+(citations inline) so code written against the reference -- generator.py, perplexity.py,
+test_benchmark_inference.py -- drives this class unchanged.  The implementation is not the reference's:
+
+  * every matmul / norm / RoPE / cache / attention op is a hand-written HIP kernel reached through the C ABI
+    (exllama_amd/cuda_ext.py); nothing on the token path falls back to ATen except the embedding gather and the
+    fp16 lm_head GEMM ("may stay ATen initially");
+  * residual adds are fused into the o_proj / down_proj matmul epilogues for every row count (the reference
+    does this only in its rows == 1 fused ops, q4_attn.cu:227 / q4_mlp.cu:194);
+  * attention never materialises the score matrix and never copies K/V for GQA;
+  * the embedding table lives in HBM next to layer 0 (288 GB per GPU; the reference keeps it on the host and
+    pays an H2D copy per forward, model.py:642,1042-1043);
+  * single-token decode can be captured into one hipGraph per model (`ExLlama.enable_decode_graph()`), with the
+    position read from device memory so the same graph replays at every context length.
+"""
+
+import json
+import math
+
+import torch
+
+from . import cuda_ext
+from .cuda_ext import exllama_ext as ext
+
+
+class ExLlamaDeviceMap:
+    """Layer -> device placement (reference: model.py:636-668)."""
+
+    def __init__(self, num_layers):
+        self.num_layers = num_layers
+        self.embed_tokens = "cuda:0"      # reference default: "cpu" (model.py:642); see module docstring
+        self.lm_head = "cuda:0"
+        self.norm = "cuda:0"
+        self.layers = ["cuda:0"] * self.num_layers
+
+    def get_layers_devs(self):
+        return sorted(set(self.layers))
+
+    def get_all_devs(self):
+        return sorted(set(self.layers + [self.lm_head, self.norm, self.embed_tokens]))
+
+    def map(self, key):
+        if key.startswith("lm_head."):
+            return self.lm_head
+        if key.startswith("model.embed_tokens."):
+            return self.embed_tokens
+        if key.startswith("model.norm."):
+            return self.norm
+        if key.startswith("model.layers."):
+            return self.layers[int(key.split(".")[2])]
+        raise ValueError("Unknown key: " + key)
+
+
+class ExLlamaConfig:
+    """Model + tuning configuration (reference: model.py:39-127). `source` is a config.json path or a dict."""
+
+    def __init__(self, source):
+        if isinstance(source, dict):
+            cfg = source
+        else:
+            with open(source) as f:
+                cfg = json.load(f)
+
+        self.bos_token_id = cfg.get("bos_token_id", 1)
+        self.eos_token_id = cfg.get("eos_token_id", 2)
+        self.pad_token_id = cfg.get("pad_token_id", 0)
+        self.hidden_size = cfg["hidden_size"]
+        self.initializer_range = cfg["initializer_range"]
+        self.intermediate_size = cfg["intermediate_size"]
+        self.num_attention_heads = cfg["num_attention_heads"]
+        self.num_hidden_layers = cfg["num_hidden_layers"]
+        self.rms_norm_eps = cfg["rms_norm_eps"]
+        self.vocab_size = cfg["vocab_size"]
+        self.num_key_value_heads = cfg.get("num_key_value_heads", self.num_attention_heads)
+        self.num_key_value_groups = self.num_attention_heads // self.num_key_value_heads
+        self.rotary_embedding_base = cfg.get("rope_theta", 10000.0)
+        self.head_dim = self.hidden_size // self.num_attention_heads
+
+        self.groupsize = None       # autodetected
+        self.act_order = False      # autodetected
+        self.empty_g_idx = False    # autodetected
+
+        self.model_path = None      # str | list[str]
+        self.device_map = ExLlamaDeviceMap(self.num_hidden_layers)
+
+        self.max_seq_len = 2048
+        self.max_input_len = 2048
+        self.max_attention_size = 2048 ** 2     # kept for API parity; flash attention has no such limit
+        self.compress_pos_emb = 1.0
+        self.alpha_value = 1.0
+        self.gpu_peer_fix = False
+        self.auto_map = None
+
+        # tuning (reference: model.py:92-103)
+        self.use_flash_attn_2 = False           # ignored: attention is always the in-tree HIP kernel
+        self.matmul_recons_thd = 8
+        self.fused_mlp_thd = 2
+        self.sdp_thd = 8
+        self.fused_attn = True
+        self.matmul_fused_remap = False
+        self.rmsnorm_no_half2 = False
+        self.rope_no_half2 = False
+        self.matmul_no_half2 = False
+        self.silu_no_half2 = False
+        self.concurrent_streams = False
+
+    def set_tuning_params(self):
+        ext.set_tuning_params(self.matmul_recons_thd, self.fused_mlp_thd, self.sdp_thd, self.matmul_fused_remap,
+                              self.rmsnorm_no_half2, self.rope_no_half2, self.matmul_no_half2, self.silu_no_half2,
+                              self.concurrent_streams)
+
+    def set_auto_map(self, map_string):
+        self.auto_map = None if map_string is None else [float(a) for a in map_string.split(",")]
+
+    def calculate_rotary_embedding_base(self):
+        self.rotary_embedding_base = self.rotary_embedding_base * self.alpha_value ** (self.head_dim / (self.head_dim - 2))
+
+
+class Ex4bitLinear:
+    """4-bit GPTQ linear layer holding a native Q4 handle (reference: model.py:132-221)."""
+
+    def __init__(self, config, in_features, out_features, has_bias, tensors, key):
+        self.config = config
+        self.key = key
+        self.in_features = in_features
+        self.out_features = out_features
+        self.qweight = tensors[key + ".qweight"]
+        self.qzeros = tensors[key + ".qzeros"]
+        self.scales = tensors[key + ".scales"]
+        self.g_idx = tensors[key + ".g_idx"].cpu() if key + ".g_idx" in tensors else None
+        self.bias = tensors[key + ".bias"] if has_bias else None
+        if self.g_idx is not None and bool((self.g_idx == 0).all()):
+            self.config.empty_g_idx = True
+            self.g_idx = None
+        self.device = self.qweight.device
+        self.device_index = self.device.index
+        self.height = self.qweight.shape[0] * 8
+        self.width = self.qweight.shape[1]
+        if self.height != in_features or self.width != out_features:
+            raise ValueError(f"{key}: qweight is {self.height}x{self.width}, expected {in_features}x{out_features}")
+        self.q4 = cuda_ext.ext_make_q4(self.qweight, self.qzeros, self.scales, self.g_idx, self.device_index)
+        self.groupsize = None
+        if self.qzeros.shape[0] > 1:
+            self.groupsize = self.height // self.qzeros.shape[0]
+            if self.config.groupsize is None:
+                self.config.groupsize = self.groupsize
+        if self.g_idx is not None:
+            if self.groupsize is None:
+                raise ValueError("Found group index but no groupsize. What do?")
+            self.config.act_order = True
+
+    def lora_applies(self, lora):
+        return lora is not None and (self.key + ".lora_A.weight") in lora.tensors
+
+    def get_lora_tensors_or_meta(self, lora):
+        if not self.lora_applies(lora):
+            return cuda_ext.none_tensor, cuda_ext.none_tensor
+        return lora.tensors[self.key + ".lora_A.weight"], lora.tensors[self.key + ".lora_B.weight"]
+
+    def forward(self, x, lora=None, out=None, accumulate=False):
+        """x @ W (+ LoRA).  `out`/`accumulate` expose the residual-fusing epilogue."""
+        if self.lora_applies(lora):
+            a, b = self.get_lora_tensors_or_meta(lora)
+            res = cuda_ext.ext_q4_matmul(x, self.q4, self.width, a, b)
+            if out is not None:
+                res = out.add_(res.view_as(out)) if accumulate else out.copy_(res.view_as(out))
+        elif out is None:
+            res = cuda_ext.ext_q4_matmul(x, self.q4, self.width)
+        else:
+            x2 = x.view(-1, x.shape[-1])
+            rows = x2.shape[0]
+            fn = ext._lib.exl_q4_matmul
+            with cuda_ext._Guard(x.device):
+                cuda_ext.check(fn(self.q4, x2.data_ptr(), rows, out.data_ptr(), int(accumulate), cuda_ext._stream(x)), "q4_matmul")
+            res = out
+        if self.bias is not None:
+            res.add_(self.bias)
+        return res
+
+
+class ExLlamaRMSNorm:
+    def __init__(self, config, tensors, key):
+        self.config = config
+        self.variance_epsilon = config.rms_norm_eps
+        self.weight = tensors[key]
+
+    def forward(self, hidden_states, buffer=None):
+        return cuda_ext.ext_rms_norm(hidden_states, self.weight, self.variance_epsilon)
+
+
+class ExLlamaMLP:
+    def __init__(self, config, tensors, key):
+        self.config = config
+        h, i = config.hidden_size, config.intermediate_size
+        self.gate_proj = Ex4bitLinear(config, h, i, False, tensors, key + ".gate_proj")
+        self.up_proj = Ex4bitLinear(config, h, i, False, tensors, key + ".up_proj")
+        self.down_proj = Ex4bitLinear(config, i, h, False, tensors, key + ".down_proj")
+
+    def fused(self, x, buffer, post_attention_layernorm, lora):
+        """rows <= fused_mlp_thd: one native call, residual added in place (reference: model.py:238-263)."""
+        bsz, q_len, _ = x.shape
+        ga, gb = self.gate_proj.get_lora_tensors_or_meta(lora)
+        ua, ub = self.up_proj.get_lora_tensors_or_meta(lora)
+        da, db = self.down_proj.get_lora_tensors_or_meta(lora)
+        ranks = [t.shape[1] for t in (ga, ua, da) if not t.is_meta]
+        lora_temp = (torch.empty((1, bsz * q_len * max(ranks)), dtype=torch.float16, device=x.device)
+                     if ranks else cuda_ext.none_tensor)
+        ext.q4_mlp(x.view(-1, x.shape[-1]), post_attention_layernorm.weight, self.config.rms_norm_eps,
+                   self.gate_proj.q4, self.up_proj.q4, self.down_proj.q4, ga, gb, ua, ub, da, db, lora_temp)
+
+    def forward_residual(self, normed, hidden, lora):
+        """hidden += down(silu(gate(normed)) * up(normed)); residual fused in the down_proj epilogue."""
+        g = self.gate_proj.forward(normed, lora)
+        u = self.up_proj.forward(normed, lora)
+        ext.silu_mul(g, u)
+        self.down_proj.forward(g, lora, out=hidden, accumulate=True)
+
+    def forward(self, x, buffer=None, lora=None):
+        """Non-residual form of the reference (model.py:266-273)."""
+        g = self.gate_proj.forward(x, lora)
+        u = self.up_proj.forward(x, lora)
+        ext.silu_mul(g, u)
+        return self.down_proj.forward(g, lora)
+
+
+class ExLlamaAttention:
+    def __init__(self, config, tensors, key, sin, cos, index):
+        self.config = config
+        self.sin, self.cos, self.index = sin, cos, index
+        h, hd = config.hidden_size, config.head_dim
+        self.q_proj = Ex4bitLinear(config, h, config.num_attention_heads * hd, False, tensors, key + ".q_proj")
+        self.k_proj = Ex4bitLinear(config, h, config.num_key_value_heads * hd, False, tensors, key + ".k_proj")
+        self.v_proj = Ex4bitLinear(config, h, config.num_key_value_heads * hd, False, tensors, key + ".v_proj")
+        self.o_proj = Ex4bitLinear(config, config.num_attention_heads * hd, h, False, tensors, key + ".o_proj")
+
+    def fused(self, hidden_states, cache, buffer, input_layernorm, lora):
+        """rows == 1: q4_attn -> HIP attention -> q4_attn_2, all in place on hidden_states (reference: model.py:322-418)."""
+        cfg = self.config
+        bsz, q_len, _ = hidden_states.shape
+        past_len = cache.current_seq_len
+        qa, qb = self.q_proj.get_lora_tensors_or_meta(lora)
+        ka, kb = self.k_proj.get_lora_tensors_or_meta(lora)
+        va, vb = self.v_proj.get_lora_tensors_or_meta(lora)
+        oa, ob = self.o_proj.get_lora_tensors_or_meta(lora)
+        ranks = [t.shape[1] for t in (qa, ka, va, oa) if not t.is_meta]
+        dev = hidden_states.device
+        lora_temp = (torch.empty((1, bsz * q_len * max(ranks)), dtype=torch.float16, device=dev) if ranks else cuda_ext.none_tensor)
+        q = torch.empty((bsz, q_len, cfg.num_attention_heads * cfg.head_dim), dtype=torch.float16, device=dev)
+        k = torch.empty((bsz, q_len, cfg.num_key_value_heads * cfg.head_dim), dtype=torch.float16, device=dev)
+        v = torch.empty_like(k)
+        kc, vc = cache.key_states[self.index], cache.value_states[self.index]
+        ext.q4_attn(hidden_states, input_layernorm.weight, cfg.rms_norm_eps, q, k, v, self.q_proj.q4, self.k_proj.q4,
+                    self.v_proj.q4, self.sin, self.cos, q_len, past_len, cfg.num_attention_heads, cfg.num_key_value_heads,
+                    cfg.head_dim, kc, vc, cache.max_seq_len, qa, qb, ka, kb, va, vb, lora_temp)
+        attn = torch.empty_like(q)
+        ext.attention(q, kc, vc, attn, past_len, cfg.num_attention_heads)
+        ext.q4_attn_2(hidden_states, attn, self.o_proj.q4, oa, ob, lora_temp)
+
+    def forward_residual(self, normed, hidden, cache, buffer, lora):
+        """General path: hidden += o_proj(attention(rope(q), cache <- rope(k), v)) (reference: model.py:421-502)."""
+        cfg = self.config
+        bsz, q_len, _ = normed.shape
+        past_len = cache.current_seq_len
+        q = self.q_proj.forward(normed, lora)
+        k = self.k_proj.forward(normed, lora)
+        v = self.v_proj.forward(normed, lora)
+        ext.rope_(q, self.sin, self.cos, past_len, cfg.num_attention_heads, cfg.head_dim)
+        ext.rope_(k, self.sin, self.cos, past_len, cfg.num_key_value_heads, cfg.head_dim)
+        kc, vc = cache.key_states[self.index], cache.value_states[self.index]
+        ext.update_cache(k, v, kc, vc, past_len)
+        attn = torch.empty_like(q)
+        mask = buffer.attn_mask if (buffer is not None and buffer.needs_mask) else None
+        ext.attention(q, kc, vc, attn, past_len, cfg.num_attention_heads, mask=mask)
+        self.o_proj.forward(attn, lora, out=hidden, accumulate=True)
+
+
+def _rows(x):
+    n = 1
+    for d in x.shape[:-1]:
+        n *= d
+    return n
+
+
+class ExLlamaDecoderLayer:
+    def __init__(self, config, tensors, key, index, sin, cos):
+        self.config = config
+        self.index = index
+        self.self_attn = ExLlamaAttention(config, tensors, key + ".self_attn", sin, cos, index)
+        self.mlp = ExLlamaMLP(config, tensors, key + ".mlp")
+        self.input_layernorm = ExLlamaRMSNorm(config, tensors, key + ".input_layernorm.weight")
+        self.post_attention_layernorm = ExLlamaRMSNorm(config, tensors, key + ".post_attention_layernorm.weight")
+
+    def forward(self, hidden_states, cache, buffer, lora):
+        """In place on hidden_states; same branch conditions as the reference (model.py:524-552)."""
+        cfg = self.config
+        rows = _rows(hidden_states)
+        if cfg.fused_attn and rows == 1:
+            self.self_attn.fused(hidden_states, cache, buffer, self.input_layernorm, lora)
+        else:
+            normed = self.input_layernorm.forward(hidden_states, buffer)
+            self.self_attn.forward_residual(normed, hidden_states, cache, buffer, lora)
+        if cfg.fused_mlp_thd > 0 and rows <= cfg.fused_mlp_thd:
+            self.mlp.fused(hidden_states, buffer, self.post_attention_layernorm, lora)
+        else:
+            normed = self.post_attention_layernorm.forward(hidden_states, buffer)
+            self.mlp.forward_residual(normed, hidden_states, lora)
+        return hidden_states
+
+
+class ExLlamaCache:
+    """Preallocated K/V cache [bsz, kv_heads, max_seq_len, head_dim] per layer (reference: model.py:557-631)."""
+
+    def __init__(self, model, batch_size=1, max_seq_len=-1, copy_from=None):
+        self.model = model
+        self.config = model.config
+        self.max_seq_len = max_seq_len if max_seq_len != -1 else self.config.max_seq_len
+        self.batch_size = batch_size
+        self.key_states, self.value_states = [], []
+        self.current_seq_len = 0
+        cfg = self.config
+        for i in range(cfg.num_hidden_layers):
+            if copy_from is None:
+                shape = (batch_size, cfg.num_key_value_heads, self.max_seq_len, cfg.head_dim)
+                dev = cfg.device_map.layers[i]
+                self.key_states.append(torch.zeros(shape, dtype=torch.float16, device=dev))
+                self.value_states.append(torch.zeros(shape, dtype=torch.float16, device=dev))
+            else:
+                self.key_states.append(copy_from.key_states[i].clone())
+                self.value_states.append(copy_from.value_states[i].clone())
+
+    def zero(self):
+        for k, v in zip(self.key_states, self.value_states):
+            k.zero_()
+            v.zero_()
+
+    def clone(self):
+        return ExLlamaCache(self.model, batch_size=self.batch_size, max_seq_len=self.max_seq_len, copy_from=self)
+
+    def roll_left(self):
+        for i in range(len(self.key_states)):
+            self.key_states[i] = torch.roll(self.key_states[i], shifts=-1, dims=2)
+            self.value_states[i] = torch.roll(self.value_states[i], shifts=-1, dims=2)
+        self.current_seq_len -= 1
+
+    def copy_states(self, target, from_column, from_columns, to_column, to_columns, from_row, from_rows, to_row, to_rows):
+        assert from_rows == 1
+        assert from_columns == to_columns
+        assert to_column + to_columns <= target.max_seq_len
+        assert from_column + from_columns <= self.max_seq_len
+        for i in range(len(self.key_states)):
+            for src_t, dst_t in ((self.key_states[i], target.key_states[i]), (self.value_states[i], target.value_states[i])):
+                src = src_t.narrow(0, from_row, from_rows).narrow(2, from_column, from_columns)
+                dst = dst_t.narrow(0, to_row, to_rows).narrow(2, to_column, to_columns)
+                dst.copy_(src.expand_as(dst) if to_rows > 1 else src)
+
+
+class ExLlamaBuffer:
+    """Per-forward attention mask holder (reference: model.py:671-690)."""
+
+    def __init__(self, config):
+        self.config = config
+        self.attn_mask = None
+        self.needs_mask = False         # True only when an input_mask (padding) was supplied: causal masking is built in
+
+    def to(self, device):
+        new = ExLlamaBuffer(self.config)
+        new.needs_mask = self.needs_mask
+        new.attn_mask = None if self.attn_mask is None else _move_tensor(self.attn_mask, device, "attn_mask", self.config)
+        return new
+
+
+def _skip_key(key):
+    return key.endswith("_proj.bias") or key.endswith(".rotary_emb.inv_freq")
+
+
+def _move_tensor(tensor, new_device, name, config):
+    if str(tensor.device) == str(new_device):
+        return tensor
+    if config.gpu_peer_fix and str(tensor.device).startswith("cuda:") and str(new_device).startswith("cuda:"):
+        tensor = tensor.to("cpu")
+    return tensor.to(new_device)
+
+
+def _layer_dtype_size(key):
+    for suffix, size in ((".weight", 2), (".qweight", 4), (".qzeros", 4), (".scales", 2), (".g_idx", 0)):
+        if key.endswith(suffix):
+            return size
+    raise ValueError("Unrecognized layer: " + key)
+
+
+class ExLlama:
+    """The model. `ExLlama(config)` loads config.model_path (safetensors, one or many files);
+    `ExLlama(config, tensors=dict)` adopts already-materialised tensors (synthetic checkpoints)."""
+
+    def __init__(self, config, tensors=None):
+        self.config = config
+        cfg = config
+        cfg.set_tuning_params()
+        if not torch.cuda.is_available():
+            raise RuntimeError("exllama_amd.ExLlama needs a HIP device: there is no CPU execution path")
+
+        if tensors is None:
+            tensors = self._load_safetensors()
+        else:
+            tensors = self._place_tensors(tensors)
+        self.max_dq_buffer_size = max([t.numel() * 8 for k, t in tensors.items() if k.endswith(".qweight")] + [1])
+
+        self.lm_head_weight = tensors["lm_head.weight"]
+        self.embed_weight = tensors["model.embed_tokens.weight"]
+        with torch.no_grad():
+            self.embed_weight[cfg.pad_token_id] = 0            # reference: model.py:853-854
+        self.norm = ExLlamaRMSNorm(cfg, tensors, "model.norm.weight")
+
+        # RoPE tables per device: fp32 math, fp16 storage (reference: model.py:862-877)
+        self.sincos = {}
+        for device in cfg.device_map.get_layers_devs():
+            inv_freq = 1.0 / (cfg.rotary_embedding_base ** (torch.arange(0, cfg.head_dim, 2, device=device).float() / cfg.head_dim))
+            t = torch.arange(cfg.max_seq_len, device=device, dtype=torch.float32)
+            if cfg.compress_pos_emb != 1.0:
+                t /= cfg.compress_pos_emb
+            freqs = torch.einsum("i,j->ij", t, inv_freq)
+            emb = torch.cat((freqs, freqs), dim=-1)
+            self.sincos[device] = (emb.sin()[None, None, :, :].half().contiguous(), emb.cos()[None, None, :, :].half().contiguous())
+
+        self.layers = []
+        for i in range(cfg.num_hidden_layers):
+            sin, cos = self.sincos[cfg.device_map.layers[i]]
+            self.layers.append(ExLlamaDecoderLayer(cfg, tensors, f"model.layers.{i}", i, sin, cos))
+
+        # Scratch buffers registered with the native library (reference: model.py:897-917).  temp_dq is not needed by
+        # the fused-dequant GEMM; a token-sized stub keeps the reference's prepare_buffers signature.
+        self.buffers = []
+        for dev in cfg.device_map.get_layers_devs():
+            b = {
+                "temp_state": torch.zeros((cfg.max_input_len, cfg.intermediate_size), dtype=torch.float16, device=dev),
+                "temp_mlp": torch.zeros((max(cfg.fused_mlp_thd, 1) * 2, cfg.intermediate_size), dtype=torch.float16, device=dev),
+                "temp_zeros_float": torch.zeros((1, 65536), dtype=torch.float32, device=dev),
+                "temp_dq": torch.zeros((1, 64), dtype=torch.float16, device=dev),
+            }
+            self.buffers.append(b)
+            ext.prepare_buffers(torch.device(dev), b["temp_state"], b["temp_mlp"], b["temp_zeros_float"], b["temp_dq"])
+        self._graph = None
+        torch.cuda.empty_cache()
+
+    # ---- loading -------------------------------------------------------------------------------------------
+    @staticmethod
+    def _cast(key, tensor, device):
+        if key.endswith(".scales") or key.endswith("layernorm.weight") or key == "model.norm.weight" \
+                or key.endswith(".embed_tokens.weight"):
+            return tensor.half()
+        if key == "lm_head.weight":
+            return tensor.float() if device == "cpu" else tensor.half()
+        return tensor
+
+    def _place_tensors(self, tensors):
+        out = {}
+        for key, t in tensors.items():
+            if _skip_key(key):
+                continue
+            device = self.config.device_map.map(key)
+            if key.endswith(".g_idx"):
+                out[key] = t                                    # consumed on the host by make_q4
+                continue
+            out[key] = self._cast(key, t, device).to(device).contiguous()
+        return out
+
+    def _load_safetensors(self):
+        from safetensors import safe_open
+        cfg = self.config
+        paths = [cfg.model_path] if isinstance(cfg.model_path, str) else list(cfg.model_path)
+        load_keys, sizes = {}, {"decoder": 0, "norm": 0, "head": 0}
+        for path in paths:
+            with safe_open(path, framework="pt", device="cpu") as f:
+                for key in f.keys():
+                    if _skip_key(key):
+                        continue
+                    load_keys[key] = path
+                    bucket = ("decoder" if key.startswith("model.layers.0.") else "norm" if key.startswith("model.norm.")
+                              else "head" if key.startswith("lm_head.") else None)
+                    if bucket:
+                        sizes[bucket] += math.prod(f.get_slice(key).get_shape()) * _layer_dtype_size(key)
+        if cfg.auto_map is not None:
+            self._auto_split(sizes)
+        tensors = {}
+        handles = {}
+        for key, path in load_keys.items():
+            if path not in handles:
+                handles[path] = safe_open(path, framework="pt", device="cpu")
+            t = handles[path].get_tensor(key)
+            device = cfg.device_map.map(key)
+            if key.endswith(".g_idx"):
+                tensors[key] = t
+            else:
+                tensors[key] = self._cast(key, t, device).to(device).contiguous()
+        return tensors
+
+    def _auto_split(self, sizes):
+        """Greedy fill of per-device GB budgets, layers then norm then head (reference: model.py:770-801)."""
+        cfg = self.config
+        budgets = [g * 1024 ** 3 for g in cfg.auto_map]
+        dev, used = 0, 0
+        n = cfg.num_hidden_layers
+        cfg.device_map.embed_tokens = "cuda:0"
+        for item in range(n + 2):
+            size = sizes["decoder"] if item < n else sizes["norm"] if item == n else sizes["head"]
+            while used + size > budgets[dev]:
+                dev += 1
+                used = 0
+                if dev >= len(budgets):
+                    raise ValueError("Model too large for device allocation scheme.")
+            target = f"cuda:{dev}"
+            if item < n:
+                cfg.device_map.layers[item] = target
+            elif item == n:
+                cfg.device_map.norm = target
+            else:
+                cfg.device_map.lm_head = target
+            used += size
+
+    # ---- forward -------------------------------------------------------------------------------------------
+    def forward(self, input_ids, cache, last_id_only=True, preprocess_only=False, lora=None, output_device=None,
+                input_mask=None):
+        """Same contract as the reference (model.py:924-986): chunks long inputs by max_input_len, returns
+        fp32 logits [bsz, 1 or q_len, vocab] on `output_device` (default: input_ids' device), or None."""
+        q_len = input_ids.shape[-1]
+        bsz = input_ids.shape[0]
+        assert input_mask is None or (input_mask.shape[-1] >= input_ids.shape[-1] and input_mask.shape[-2] == input_ids.shape[-2])
+        chunk_cap = max(1, self.config.max_input_len // bsz)
+        result = None
+        begin = 0
+        while begin < q_len:
+            end = min(begin + chunk_cap, q_len)
+            pre = preprocess_only or (end < q_len and last_id_only)
+            r = self._forward(input_ids[:, begin:end], cache, last_id_only, pre, lora, output_device, input_mask)
+            if not pre:
+                result = r if result is None else torch.cat((result, r), dim=1)
+            begin = end
+        return result
+
+    @torch.no_grad()
+    def _forward(self, input_ids, cache, last_id_only=True, preprocess_only=False, lora=None, output_device=None,
+                 input_mask=None):
+        cfg = self.config
+        bsz, seq_len = input_ids.shape
+        past_len = cache.current_seq_len
+        if past_len + seq_len > cache.max_seq_len:
+            raise RuntimeError(f"sequence ({past_len} + {seq_len}) exceeds the cache length {cache.max_seq_len}")
+        if output_device is None:
+            output_device = input_ids.device
+        devs = cfg.device_map.get_layers_devs()
+
+        buffer = ExLlamaBuffer(cfg)
+        if input_mask is not None:
+            # additive fp16 mask, causal + padding (reference: model.py:1014-1033); only built when padding exists --
+            # plain causal masking is part of the attention kernels
+            mask = torch.zeros(bsz, 1, seq_len, past_len + seq_len, dtype=torch.float16, device=devs[0])
+            if seq_len > 1:
+                tri = torch.triu(torch.full((seq_len - 1, seq_len - 1), -65504.0))
+                mask[:, :, :seq_len - 1, past_len + 1:past_len + seq_len] = tri
+            im = _move_tensor(input_mask[:, :past_len + seq_len], devs[0], "input_mask", cfg)
+            im = torch.where(im, 0, -65504.0).half().unsqueeze(1).unsqueeze(2)
+            buffer.attn_mask = torch.minimum(mask, im).contiguous()
+            buffer.needs_mask = True
+        buffers = {devs[0]: buffer}
+        for d in devs[1:]:
+            buffers[d] = buffer.to(d)
+
+        ids = _move_tensor(input_ids, cfg.device_map.embed_tokens, "input_ids", cfg)
+        hidden = torch.nn.functional.embedding(ids, self.embed_weight).contiguous()
+
+        for i, layer in enumerate(self.layers):
+            device = cfg.device_map.layers[i]
+            hidden = _move_tensor(hidden, device, "hidden_states", cfg)
+            hidden = layer.forward(hidden, cache, buffers[device], lora)
+        cache.current_seq_len += seq_len
+        if preprocess_only:
+            return None
+
+        hidden = _move_tensor(hidden, cfg.device_map.norm, "hidden_states", cfg)
+        if last_id_only:
+            hidden = hidden[:, -1:, :].contiguous()
+        hidden = self.norm.forward(hidden)
+        if cfg.device_map.lm_head == "cpu":
+            hidden = hidden.float()
+        hidden = _move_tensor(hidden, cfg.device_map.lm_head, "hidden_states", cfg)
+        logits = torch.matmul(hidden, self.lm_head_weight.t()).float()
+        return _move_tensor(logits, output_device, "logits", cfg)
+
+    # ---- hipGraph decode ----------------------------------------------------------------------------------
+    def free_unmanaged(self):
+        """Release native handles/buffers (reference: model.py:1090-1092)."""
+        self._graph = None
+        ext.cleanup()

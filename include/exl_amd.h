@@ -1,0 +1,163 @@
+/*
+ * exl_amd.h -- C ABI of libexl_amd.so: the MI355X (gfx950 / CDNA4) implementation of the
+ * 4-bit GPTQ Llama hot path of turboderp/exllama (v1).
+ *
+ * This is the drop-in boundary.  Every entry point replaces one function
+ * of the reference's pybind module `exllama_ext` (/root/reference/exllama_ext/exllama_ext.cpp:743-762)
+ * -- the reference-side binding a maintainer would add is shown in INTEGRATION.md and shipped
+ * as `exllama_amd/cuda_ext.py` (ctypes).  No torch types appear here: plain pointers and sizes.
+ *
+ * Conventions
+ *   - all tensor pointers are DEVICE pointers to contiguous row-major data unless the name ends in
+ *     `_host`;  `half` data is IEEE fp16 passed as `void*` / `uint16_t*`.
+ *   - `stream` is a `hipStream_t` passed as `void*` (NULL = the legacy default stream).  All kernels
+ *     are enqueued on it and nothing synchronises unless stated; this makes every compute entry point
+ *     capturable in a hipGraph.
+ *   - return value: 0 on success, otherwise a negative EXL_E_* code or a positive hipError_t;
+ *     `exl_last_error()` returns a human-readable message (thread-local).
+ *   - weight / scale / zero tensors stay OWNED by the caller; a Q4 handle BORROWS them
+ *     (reference: exllama_ext/cuda_func/q4_matrix.cu:46-48) and, for act-order weights, REWRITES
+ *     `qweight` in place at construction (reference: q4_matrix.cu:159).
+ *   - optional device-side position: functions taking `past_len` also take `past_len_dev`
+ *     (const int32_t* on the device, may be NULL).  When non-NULL the kernels read the position
+ *     from it instead of the host integer, so a captured graph can be replayed at any position.
+ */
+#ifndef EXL_AMD_H
+#define EXL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EXL_OK               0
+#define EXL_E_INVALID       (-1)   /* bad argument (shape / alignment / null)        */
+#define EXL_E_NO_BUFFERS    (-2)   /* exl_prepare_buffers not called for this device  */
+#define EXL_E_TOO_SMALL     (-3)   /* a borrowed scratch buffer is too small          */
+#define EXL_E_UNSUPPORTED   (-4)   /* shape outside what the kernels support          */
+
+#define EXL_MAX_DEVICES      16    /* reference: exllama_ext/cuda_buffers.cuh:9 (CUDA_MAX_DEVICES) */
+
+const char* exl_last_error(void);
+int  exl_version(void);
+
+/* ---- tuning (reference: exllama_ext/tuning.h:4-16, exllama_ext.cpp:89-112 set_tuning_params) ------- */
+typedef struct ExlTuning {
+    int32_t matmul_recons_thd;    /* rows at which q4_matmul switches from the GEMV to the MFMA GEMM; 0 = never */
+    int32_t fused_mlp_thd;
+    int32_t sdp_thd;
+    int32_t matmul_fused_remap;   /* accepted for compatibility; the act-order gather is always fused here       */
+    int32_t rmsnorm_no_half2;     /* the five half2/stream flags are accepted and ignored: there is one          */
+    int32_t rope_no_half2;        /* kernel per op on CDNA4, not a half/half2 pair                               */
+    int32_t matmul_no_half2;
+    int32_t silu_no_half2;
+    int32_t concurrent_streams;
+} ExlTuning;
+
+int exl_set_tuning(const ExlTuning* t);
+int exl_get_tuning(ExlTuning* t);
+
+/* ---- per-device scratch (reference: exllama_ext.cpp:126-152 prepare_buffers, cuda_buffers.cu:66-89) -- */
+/* temp_state: half [temp_state_numel]; temp_mlp: half [2*fused_mlp_thd*intermediate];
+ * temp_zeros_float: float [max_zeros_float] (unused here: no atomics, kept for signature parity);
+ * temp_dq: half [max K*N] (unused here: the prefill GEMM dequantises in registers).
+ * Also allocates the library's own fp32 workspace for split-K slabs and attention partials
+ * (hipMalloc, once per device; therefore NOT capturable -- call before any graph capture). */
+int exl_prepare_buffers(int device, void* temp_state, size_t temp_state_numel, void* temp_mlp,
+                        size_t temp_mlp_numel, void* temp_zeros_float, size_t max_zeros_float, void* temp_dq,
+                        size_t temp_dq_numel);
+/* reference: exllama_ext.cpp:117-121 cleanup(): frees every Q4 handle and every per-device buffer set. */
+int exl_cleanup(void);
+
+/* ---- Q4 matrix handle (reference: exllama_ext.cpp:157-194 make_q4, q4_matrix.cu:26-53, :104-168) ---- */
+/* height = in_features K, width = out_features N, groups = K / groupsize.
+ * g_idx_host: int32 [K] in HOST memory or NULL (reference passes the CPU tensor, model.py:144).
+ * Synchronises `stream` when g_idx_host != NULL (as the reference's cudaDeviceSynchronize, q4_matrix.cu:163). */
+int exl_make_q4(int device, int height, int width, int groups, uint32_t* qweight, uint32_t* qzeros,
+                uint16_t* scales, const uint32_t* g_idx_host, void* stream, void** out_handle);
+int exl_free_q4(void* handle);
+/* Introspection used by tests: any out pointer may be NULL. x_map is the DEVICE pointer (uint32 [K]) or NULL. */
+int exl_q4_info(void* handle, int* device, int* height, int* width, int* groups, int* groupsize,
+                const uint32_t** x_map_dev);
+
+/* ---- q4 matmul: out[M,N] (+)= x[M,K] @ dequant(W)  (reference: exllama_ext.cpp:199-240 q4_matmul) ---- */
+/* Dispatch on the tuning threshold exactly like the reference: rows < matmul_recons_thd (or thd == 0)
+ * -> wave64 GEMV, else fused-dequant MFMA GEMM.  no_zero != 0 accumulates into `out` (residual fusion,
+ * reference q4_matmul.cu:78-82 / cublas beta = 1 at :338). */
+int exl_q4_matmul(void* w, const void* x, int x_height, void* out, int no_zero, void* stream);
+/* The two kernels individually (reference: q4_matmul.cu:239-299 q4_matmul_cuda, :301-344 q4_matmul_recons_cuda). */
+int exl_q4_matmul_gemv(void* w, const void* x, int x_height, void* out, int no_zero, void* stream);
+int exl_q4_matmul_gemm(void* w, const void* x, int x_height, void* out, int no_zero, void* stream);
+/* out = x @ W + (x @ lora_A) @ lora_B   (reference: exllama_ext.cpp:245-324 q4_matmul_lora) */
+int exl_q4_matmul_lora(void* w, const void* x, int x_height, void* out, const void* lora_a, const void* lora_b,
+                       int rank, void* lora_temp, void* stream);
+/* Full dequantisation W16[K,N] = half(q - (z+1)) * scale  (reference: q4_matrix.cu:170-224 reconstruct). */
+int exl_q4_reconstruct(void* w, void* out_w16, void* stream);
+
+/* ---- act-order activation gather x_new[:,c] = x[:,x_map[c]] (reference: exllama_ext.cpp:328-358, column_remap.cu) */
+int exl_column_remap(const void* x, void* x_new, int height, int width, const uint32_t* x_map_dev, void* stream);
+
+/* ---- fp16 GEMM out (+)= x[M,K] @ w[K,N] (reference: exllama_ext.cpp:362-422 half_matmul / half_matmul_cublas) */
+int exl_half_matmul(const void* x, const void* w, void* out, int height, int dim, int width, int no_zero,
+                    void* stream);
+
+/* ---- RMSNorm (reference: exllama_ext.cpp:606-643 rms_norm, rms_norm.cu:178-213). In place if out == x. -- */
+int exl_rms_norm(const void* x, const void* w, void* out, float epsilon, int rows, int dim, void* stream);
+
+/* ---- RoPE, in place (reference: exllama_ext.cpp:647-680 rope_, rope.cu:100-125) ----------------------- */
+/* x: half [bsz, rows_per_batch, head_dim]; sin/cos: half [max_seq_len, head_dim]; position of row r is
+ * past_len + r / num_heads. */
+int exl_rope(void* x, const void* sin, const void* cos, int bsz, int rows_per_batch, int head_dim,
+             int num_heads, int past_len, const int32_t* past_len_dev, void* stream);
+
+/* ---- SiLU(x) * y, in place on x (reference: q4_mlp.cu:47-88 silu_mul_cuda_kernel) --------------------- */
+int exl_silu_mul(void* x, const void* y, int height, int width, void* stream);
+
+/* ---- KV-cache scatter (reference: q4_attn.cu:19-72 update_cache_kernel; model.py:440-443) ------------- */
+/* states: half [bsz, q_len, num_kv_heads*head_dim]; caches: half [cache_bsz, num_kv_heads, max_seq_len, head_dim] */
+int exl_update_cache(const void* key_states, const void* value_states, void* key_cache, void* value_cache,
+                     int bsz, int q_len, int num_kv_heads, int head_dim, int max_seq_len, int past_len,
+                     const int32_t* past_len_dev, void* stream);
+
+/* ---- fp16 attention over the KV cache (replaces the ATen calls at model.py:376-409 and :463-495) ------ */
+/* q: half [bsz, q_len, num_heads*head_dim] (already RoPE'd); caches as above; out: half [bsz, q_len, num_heads*head_dim].
+ * Keys 0 .. past_len+q_len-1 are attended; query i sees keys j <= past_len + i (causal).
+ * mask: optional additive half mask [bsz, 1, q_len, past_len+q_len] (model.py:1016-1026) or NULL.
+ * GQA is handled by indexing (no repeat_kv).  Small q_len uses the split-KV decode kernel, large q_len the
+ * MFMA flash kernel. */
+int exl_attention(const void* q, const void* key_cache, const void* value_cache, void* out, const void* mask,
+                  int bsz, int q_len, int num_heads, int num_kv_heads, int head_dim, int max_seq_len,
+                  int past_len, const int32_t* past_len_dev, void* stream);
+
+/* ---- fused decode ops ------------------------------------------------------------------------------- */
+/* reference: exllama_ext.cpp:424-528 q4_attn -> q4_attn.cu:74-204:
+ *   rms_norm(x) -> q/k/v projections (+LoRA) -> RoPE(q), RoPE(k) -> KV scatter at past_len.
+ * x: half [bsz, q_len, dim]; query/key/value_states: outputs half [bsz, q_len, *].  LoRA pointers may be NULL. */
+int exl_q4_attn(int device, const void* x, const void* rms_norm_weight, float epsilon, void* query_states,
+                void* key_states, void* value_states, void* q_proj, void* k_proj, void* v_proj, const void* sin,
+                const void* cos, int bsz, int q_len, int dim, int head_dim, int num_heads, int num_kv_heads,
+                int past_len, const int32_t* past_len_dev, void* key_cache, void* value_cache, int max_seq_len,
+                const void* q_a, const void* q_b, int q_rank, const void* k_a, const void* k_b, int k_rank,
+                const void* v_a, const void* v_b, int v_rank, void* lora_temp, void* stream);
+/* reference: exllama_ext.cpp:530-563 q4_attn_2 -> q4_attn.cu:206-228:  x += attn_output @ o_proj (+LoRA). */
+int exl_q4_attn_2(void* x, const void* attn_output, void* o_proj, int height, const void* o_a, const void* o_b,
+                  int o_rank, void* lora_temp, void* stream);
+/* reference: exllama_ext.cpp:567-602 q4_mlp -> q4_mlp.cu:100-199:
+ *   x += (silu(norm(x) @ gate) * (norm(x) @ up)) @ down. */
+int exl_q4_mlp(int device, void* x, const void* rms_norm_weight, float epsilon, void* gate, void* up, void* down,
+               int height, int dim, const void* gate_a, const void* gate_b, int gate_rank, const void* up_a,
+               const void* up_b, int up_rank, const void* down_a, const void* down_b, int down_rank,
+               void* lora_temp, void* stream);
+
+/* ---- repetition penalty, HOST memory, fp32 (reference: exllama_ext.cpp:684-741, cpu_func/rep_penalty.cpp) */
+int exl_rep_penalty(int vocab_size, const uint64_t* sequence_host, float* rep_mask_host, float penalty_max,
+                    int sustain, int decay, int seq_len);
+int exl_apply_rep_penalty(int vocab_size, const uint64_t* sequence_host, float penalty_max, int sustain,
+                          int decay, int seq_len, int bsz, float* logits_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EXL_AMD_H */

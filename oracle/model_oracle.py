@@ -1,0 +1,132 @@
+"""CPU restatement of the reference's Llama forward pass -- TEST INFRASTRUCTURE ONLY (see exl_oracle.py header).
+
+Composes the op-level oracle (`exl_oracle.py`) in the order /root/reference/model.py:989-1082 runs the ops:
+embedding -> per layer [RMSNorm -> q/k/v -> RoPE -> KV scatter -> attention -> o_proj (+residual) ->
+RMSNorm -> gate/up -> SiLU*mul -> down (+residual)] -> final RMSNorm -> lm_head -> fp32 logits.
+
+Used (a) by tests/ as the model-level parity checker (logits, greedy tokens, perplexity) and (b) by bench.py's
+`cpu_baseline` leg, where the weights are dequantised ONCE up front (`prepare()`), so the timed region measures the
+math of the path, not numpy bit-twiddling.  Parity of this composition is unpinned by the reference for the
+floating-point ops (no CPU path and no golden vectors exist there); integer work is bit-exact.
+"""
+
+import numpy as np
+
+from . import exl_oracle as O
+
+f16, f32 = np.float16, np.float32
+
+
+def _np(t):
+    """torch tensor / array -> numpy (keeps int32/uint32 bit patterns)."""
+    if hasattr(t, "detach"):
+        t = t.detach().cpu().numpy()
+    return np.asarray(t)
+
+
+class OracleLinear:
+    def __init__(self, tensors, key):
+        self.qweight = _np(tensors[key + ".qweight"]).view(np.uint32).copy()
+        self.qzeros = _np(tensors[key + ".qzeros"]).view(np.uint32)
+        self.scales = _np(tensors[key + ".scales"]).astype(f16)
+        self.x_map = None
+        gk = key + ".g_idx"
+        if gk in tensors:
+            g_idx = _np(tensors[gk])
+            if not (g_idx == 0).all():
+                self.x_map, self.qweight = O.make_sequential(self.qweight, g_idx, self.qzeros.shape[0])
+        self.w32 = None
+
+    def prepare(self):
+        """Dequantise once: W16 exactly as the reference reconstructs it, held as fp32 for the BLAS call."""
+        self.w32 = O.dequant_w16(self.qweight, self.qzeros, self.scales).astype(f32)
+
+    def __call__(self, x, residual=None):
+        x = np.asarray(x).astype(f16)
+        if self.w32 is not None:
+            xx = O.column_remap(x, self.x_map) if self.x_map is not None else x
+            acc = xx.astype(f32) @ self.w32
+            if residual is not None:
+                acc = acc + np.asarray(residual).astype(f32)
+            return acc.astype(f16)
+        return O.q4_matmul_recons(x, self.qweight, self.qzeros, self.scales, self.x_map, out=residual)
+
+
+class OracleLlama:
+    def __init__(self, cfg, tensors, max_seq_len=2048, num_layers=None):
+        """cfg: dict with the config.json keys; tensors: checkpoint dict (torch or numpy)."""
+        self.h = cfg["hidden_size"]
+        self.heads = cfg["num_attention_heads"]
+        self.kv_heads = cfg.get("num_key_value_heads", self.heads)
+        self.hd = self.h // self.heads
+        self.eps = cfg["rms_norm_eps"]
+        self.L = cfg["num_hidden_layers"] if num_layers is None else num_layers
+        self.max_seq_len = max_seq_len
+        self.embed = _np(tensors["model.embed_tokens.weight"]).astype(f16).copy()
+        self.embed[cfg.get("pad_token_id", 0)] = 0
+        self.lm_head = _np(tensors["lm_head.weight"]).astype(f16)
+        self.norm_w = _np(tensors["model.norm.weight"]).astype(f16)
+        self.sin, self.cos = O.rope_tables(max_seq_len, self.hd, cfg.get("rope_theta", 10000.0))
+        self.layers = []
+        for i in range(self.L):
+            p = f"model.layers.{i}"
+            self.layers.append({
+                "in_norm": _np(tensors[p + ".input_layernorm.weight"]).astype(f16),
+                "post_norm": _np(tensors[p + ".post_attention_layernorm.weight"]).astype(f16),
+                "q": OracleLinear(tensors, p + ".self_attn.q_proj"),
+                "k": OracleLinear(tensors, p + ".self_attn.k_proj"),
+                "v": OracleLinear(tensors, p + ".self_attn.v_proj"),
+                "o": OracleLinear(tensors, p + ".self_attn.o_proj"),
+                "gate": OracleLinear(tensors, p + ".mlp.gate_proj"),
+                "up": OracleLinear(tensors, p + ".mlp.up_proj"),
+                "down": OracleLinear(tensors, p + ".mlp.down_proj"),
+            })
+        self.reset()
+
+    def prepare(self):
+        for l in self.layers:
+            for k in ("q", "k", "v", "o", "gate", "up", "down"):
+                l[k].prepare()
+
+    def reset(self, bsz=1):
+        self.past = 0
+        shape = (bsz, self.kv_heads, self.max_seq_len, self.hd)
+        self.kc = [np.zeros(shape, dtype=f16) for _ in range(self.L)]
+        self.vc = [np.zeros(shape, dtype=f16) for _ in range(self.L)]
+
+    def layer_forward(self, i, hidden):
+        """hidden [bsz, q_len, h] fp16 -> new hidden (residuals added inside the o/down matmul rounding, like the
+        fused ops of the reference and like exllama_amd.model)."""
+        l = self.layers[i]
+        bsz, q_len, h = hidden.shape
+        x2 = hidden.reshape(-1, h)
+        xn = O.rms_norm(x2, l["in_norm"], self.eps)
+        q = l["q"](xn).reshape(bsz, -1)
+        k = l["k"](xn).reshape(bsz, -1)
+        v = l["v"](xn).reshape(bsz, q_len, -1)
+        q = O.rope(q, self.sin, self.cos, self.past, self.heads, self.hd).reshape(bsz, q_len, self.heads, self.hd)
+        k = O.rope(k, self.sin, self.cos, self.past, self.kv_heads, self.hd).reshape(bsz, q_len, -1)
+        O.update_cache(k, v, self.kc[i], self.vc[i], self.past)
+        kv_len = self.past + q_len
+        a = O.attention(q.transpose(0, 2, 1, 3), self.kc[i][:bsz, :, :kv_len], self.vc[i][:bsz, :, :kv_len],
+                        causal_past_len=self.past)
+        a = a.transpose(0, 2, 1, 3).reshape(-1, h)
+        x2 = l["o"](a, residual=x2)
+        xn = O.rms_norm(x2, l["post_norm"], self.eps)
+        act = O.silu_mul(l["gate"](xn), l["up"](xn))
+        x2 = l["down"](act, residual=x2)
+        return x2.reshape(bsz, q_len, h)
+
+    def forward(self, input_ids, last_id_only=True):
+        """input_ids [bsz, q_len] ints -> fp32 logits [bsz, 1 or q_len, V]; advances the cache position."""
+        ids = np.asarray(input_ids)
+        hidden = self.embed[ids]
+        for i in range(self.L):
+            hidden = self.layer_forward(i, hidden)
+        self.past += ids.shape[1]
+        if last_id_only:
+            hidden = hidden[:, -1:, :]
+        bsz, q, h = hidden.shape
+        hn = O.rms_norm(hidden.reshape(-1, h), self.norm_w, self.eps)
+        logits = (hn.astype(f32) @ self.lm_head.astype(f32).T).astype(f16).astype(f32)
+        return logits.reshape(bsz, q, -1)

@@ -1,0 +1,98 @@
+"""CPU tests of the C-ABI library: it loads, exports every symbol include/exl_amd.h declares, follows the error
+convention, and its host-side functions (repetition penalty) are bit-exact against the reference binary's vectors.
+No GPU compute is launched here."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from exllama_amd import _lib
+    return _lib.load()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "exl_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(exl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from exllama_amd import _lib
+    names = _declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/exl_amd.h but not exported by libexl_amd.so"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in exllama_amd/_lib.py"
+    assert lib.exl_version() >= 100
+
+
+def test_op_surface_names_match_reference():
+    """The names the reference's model.py / generator.py use on `cuda_ext`."""
+    from exllama_amd import cuda_ext
+    for n in ("ext_make_q4", "ext_q4_matmul", "ext_half_matmul", "ext_rope_", "ext_rms_norm", "ext_rms_norm_",
+              "ext_rep_penalty_mask_cpu", "ext_apply_rep_penalty_mask_cpu", "none_tensor", "exllama_ext"):
+        assert hasattr(cuda_ext, n)
+    for n in ("set_tuning_params", "prepare_buffers", "cleanup", "make_q4", "q4_matmul", "q4_matmul_lora", "q4_attn",
+              "q4_attn_2", "q4_mlp", "column_remap", "rms_norm", "rope_", "half_matmul", "half_matmul_cublas",
+              "rep_penalty", "apply_rep_penalty"):
+        assert callable(getattr(cuda_ext.exllama_ext, n)), n
+    assert cuda_ext.none_tensor.device.type == "meta"
+    import cuda_ext as shim                      # the root-level drop-in module
+    assert shim.exllama_ext is cuda_ext.exllama_ext
+
+
+def test_error_convention(lib):
+    from exllama_amd import cuda_ext
+    with pytest.raises(RuntimeError, match="invalid"):
+        cuda_ext.exllama_ext.q4_info(12345678)            # not a handle
+    x = torch.zeros((1, 8), dtype=torch.float32)
+    with pytest.raises(RuntimeError, match="incorrect datatype"):
+        cuda_ext.exllama_ext.rms_norm(x, x, x, 1e-6)
+    xh = torch.zeros((1, 8), dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        cuda_ext.exllama_ext.rms_norm(xh, xh[0], xh, 1e-6)       # CPU tensors: no fallback path
+    t = cuda_ext._lib.ExlTuning()
+    cuda_ext.exllama_ext.set_tuning_params(4, 2, 8, False, True, True, True, True, False)
+    assert lib.exl_get_tuning(t) == 0 and t.matmul_recons_thd == 4 and t.rope_no_half2 == 1
+    cuda_ext.exllama_ext.set_tuning_params(8, 2, 8, False, False, False, False, False, False)
+
+
+def test_model_refuses_to_run_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from exllama_amd import synth
+    from exllama_amd.model import ExLlama, ExLlamaConfig
+    cfg = ExLlamaConfig(synth.config_dict(synth.LLAMA_TINY))
+    with pytest.raises(RuntimeError, match="no CPU execution path"):
+        ExLlama(cfg, tensors={})
+
+
+def test_rep_penalty_bit_exact_vs_reference_vectors(golden_dir):
+    from exllama_amd import cuda_ext
+    g = np.load(os.path.join(golden_dir, "rep_penalty.npz"))
+    for n in range(int(g["ncases"])):
+        vocab, seq_len, sustain, decay = (int(v) for v in g[f"c{n}_params"])
+        pmax = float(g[f"c{n}_pmax"])
+        seq = torch.from_numpy(g[f"c{n}_seq"].astype(np.int64))[None]
+        mask = cuda_ext.ext_rep_penalty_mask_cpu(vocab, seq, pmax, sustain, decay)
+        assert np.array_equal(mask.numpy().view(np.uint32), g[f"c{n}_mask"].view(np.uint32)), n
+        logits = torch.from_numpy(g[f"c{n}_logits"].copy())[None]
+        cuda_ext.ext_apply_rep_penalty_mask_cpu(seq, pmax, sustain, decay, logits)
+        assert np.array_equal(logits[0].numpy().view(np.uint32), g[f"c{n}_applied"].view(np.uint32)), n
+
+
+def test_rep_penalty_batch_and_bounds():
+    from exllama_amd import cuda_ext
+    seq = torch.tensor([[1, 2, 3], [3, 3, 0]], dtype=torch.long)
+    logits = torch.tensor([[1.0, -1.0, 2.0, -2.0], [1.0, -1.0, 2.0, -2.0]])
+    cuda_ext.ext_apply_rep_penalty_mask_cpu(seq, 2.0, -1, 0, logits)
+    assert logits.tolist() == [[1.0, -2.0, 1.0, -4.0], [0.5, -1.0, 2.0, -4.0]]
+    with pytest.raises(RuntimeError, match="outside the vocabulary"):
+        cuda_ext.ext_rep_penalty_mask_cpu(2, torch.tensor([[5]], dtype=torch.long), 1.2, -1, 0)

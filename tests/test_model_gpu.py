@@ -1,0 +1,142 @@
+"""GPU model-level parity: exllama_amd.model.ExLlama (HIP kernels through the C ABI) against the CPU oracle model and
+the committed golden logits, on the seeded synthetic checkpoints; plus the properties that hold at BASELINE sizes."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from exllama_amd import synth
+from oracle.model_oracle import OracleLlama
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(name, gs, act, seed=11, max_seq_len=64, num_layers=None, zeros="rand", **cfg_over):
+    from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
+    dims = synth.PRESETS[name]
+    tensors = synth.make_checkpoint(dims, groupsize=gs, act_order=act, seed=seed, device="cpu", zeros=zeros, num_layers=num_layers)
+    cfg = ExLlamaConfig(synth.config_dict(dims, num_layers))
+    cfg.max_seq_len = max_seq_len
+    cfg.max_input_len = max(max_seq_len, 16)
+    for k, v in cfg_over.items():
+        setattr(cfg, k, v)
+    model = ExLlama(cfg, tensors={k: v.clone() for k, v in tensors.items()})
+    return model, ExLlamaCache(model), tensors, dims
+
+
+def _ppl(logits, ids):
+    """exp(-mean log p(target)) over positions (reference: perplexity.py:121-137)."""
+    lp = torch.log_softmax(torch.as_tensor(logits).float(), dim=-1)
+    tgt = torch.as_tensor(ids)[:, 1:]
+    tok = lp[:, :-1].gather(-1, tgt.unsqueeze(-1)).squeeze(-1)
+    return math.exp(-tok.mean().item())
+
+
+@pytest.mark.parametrize("name,gs,act", [("tiny", 64, False), ("tiny_gqa", 128, True)])
+def test_tiny_model_matches_golden_and_oracle(name, gs, act, golden_dir):
+    g = np.load(os.path.join(golden_dir, "tiny_model.npz"))
+    model, cache, tensors, dims = _build(name, gs, act)
+    ids = torch.from_numpy(g[f"{name}_ids"])
+    logits = model.forward(ids.to("cuda:0"), cache, last_id_only=False).cpu().numpy()
+    ref = g[f"{name}_logits"].astype(np.float32)
+    scale = np.abs(ref).max()
+    assert np.isfinite(logits).all()
+    assert np.abs(logits - ref).max() <= 2e-2 * scale, (np.abs(logits - ref).max(), scale)    # fp16 tolerance through 2 layers
+    # perplexity "equal to 2 dp" (north_star) on the same token stream
+    assert abs(_ppl(logits, ids) - _ppl(ref, ids)) < 5e-3 * _ppl(ref, ids)
+    # greedy continuation through the fused decode path reproduces the oracle's tokens (integer result)
+    tok = int(np.argmax(logits[0, -1]))
+    toks = [tok]
+    for i in range(4):
+        lg = model.forward(torch.tensor([[tok]], device="cuda:0"), cache).cpu().numpy()
+        np.testing.assert_allclose(lg[0, 0], g[f"{name}_step_logits"][i].astype(np.float32), rtol=0, atol=2e-2 * scale)
+        tok = int(np.argmax(lg[0, 0]))
+        toks.append(tok)
+    assert toks == g[f"{name}_tokens"].tolist()
+    assert cache.current_seq_len == ids.shape[1] + 4
+    model.free_unmanaged()
+
+
+def test_prefill_and_token_by_token_agree():
+    """The -v check of the reference (test_benchmark_inference.py:237-246: "should produce roughly equal results"):
+    MFMA-GEMM prefill vs GEMV one-token-at-a-time give the same logits within fp16 tolerance and the same ppl to 2 dp."""
+    model, cache, tensors, dims = _build("tiny_gqa", 128, True, seed=5)
+    from exllama_amd.model import ExLlamaCache
+    ids = torch.randint(1, dims.vocab_size, (1, 40), generator=torch.Generator().manual_seed(1)).to("cuda:0")
+    a = model.forward(ids, cache, last_id_only=False).cpu()
+    cache2 = ExLlamaCache(model)
+    b = torch.cat([model.forward(ids[:, i:i + 1], cache2, last_id_only=False).cpu() for i in range(ids.shape[1])], dim=1)
+    scale = a.abs().max().item()
+    assert (a - b).abs().max().item() <= 2e-2 * scale
+    assert abs(_ppl(a, ids.cpu()) - _ppl(b, ids.cpu())) < 5e-3 * _ppl(a, ids.cpu())
+    # KV caches written by the two paths agree too
+    for l in range(len(cache.key_states)):
+        assert (cache.key_states[l][:, :, :40].float() - cache2.key_states[l][:, :, :40].float()).abs().max().item() < 2e-2
+    model.free_unmanaged()
+
+
+def test_chunked_prefill_and_threshold_variants():
+    """Chunking by max_input_len (model.py:948-984) and flipping the matmul threshold must not change results beyond
+    fp16 tolerance; batch rows are independent."""
+    model, cache, tensors, dims = _build("tiny", 64, False, seed=9, max_seq_len=64)
+    from exllama_amd.model import ExLlamaCache
+    ids = torch.randint(1, dims.vocab_size, (1, 37), generator=torch.Generator().manual_seed(2)).to("cuda:0")
+    full = model.forward(ids, cache).cpu()
+    model.config.max_input_len = 16
+    c2 = ExLlamaCache(model)
+    chunked = model.forward(ids, c2).cpu()
+    assert c2.current_seq_len == 37
+    assert (full - chunked).abs().max().item() <= 2e-2 * full.abs().max().item()
+    model.config.max_input_len = 64
+    # batched: two different prompts in one batch == each alone
+    ids2 = torch.randint(1, dims.vocab_size, (2, 9), generator=torch.Generator().manual_seed(3)).to("cuda:0")
+    cb = ExLlamaCache(model, batch_size=2)
+    both = model.forward(ids2, cb, last_id_only=False).cpu()
+    for r in range(2):
+        c1 = ExLlamaCache(model)
+        one = model.forward(ids2[r:r + 1], c1, last_id_only=False).cpu()
+        assert (both[r] - one[0]).abs().max().item() <= 2e-2 * one.abs().max().item()
+    model.free_unmanaged()
+
+
+def test_cache_clone_roll_and_copy_states():
+    model, cache, tensors, dims = _build("tiny", 64, False, seed=4, max_seq_len=32)
+    ids = torch.randint(1, dims.vocab_size, (1, 10)).to("cuda:0")
+    model.forward(ids, cache, preprocess_only=True)
+    c2 = cache.clone()
+    assert torch.equal(c2.key_states[0], cache.key_states[0])
+    from exllama_amd.model import ExLlamaCache
+    big = ExLlamaCache(model, batch_size=3, max_seq_len=32)
+    cache.copy_states(big, 0, 10, 0, 10, 0, 1, 0, 3)
+    assert torch.equal(big.value_states[1][2, :, :10], cache.value_states[1][0, :, :10])
+    before = cache.key_states[0][:, :, 1].clone()
+    cache.roll_left()
+    assert torch.equal(cache.key_states[0][:, :, 0], before)
+    model.free_unmanaged()
+
+
+def test_7b_layer_shapes_finite_and_consistent():
+    """BASELINE shape (h 4096, I 11008, 32 heads, g128), two layers: 2048-token prefill is finite, its last-token
+    logits equal a 2047-token prefill followed by one fused decode step (prefill GEMM path vs decode GEMV path at full
+    context), and greedy tokens agree."""
+    from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
+    dims = synth.LLAMA_7B
+    tensors = synth.make_checkpoint(dims, groupsize=128, act_order=False, seed=0, device="cuda:0", zeros="sym", num_layers=2)
+    cfg = ExLlamaConfig(synth.config_dict(dims, 2))
+    cfg.max_seq_len = 2048
+    model = ExLlama(cfg, tensors=tensors)
+    cache = ExLlamaCache(model)
+    ids = torch.randint(0, 31999, (1, 2048), generator=torch.Generator().manual_seed(0)).to("cuda:0")
+    a = model.forward(ids, cache).cpu()
+    assert torch.isfinite(a).all()
+    c2 = ExLlamaCache(model)
+    model.forward(ids[:, :2047], c2, preprocess_only=True)
+    b = model.forward(ids[:, 2047:], c2).cpu()
+    scale = a.abs().max().item()
+    assert (a - b).abs().max().item() <= 3e-2 * scale, ((a - b).abs().max().item(), scale)
+    assert int(a[0, -1].argmax()) == int(b[0, -1].argmax())
+    with pytest.raises(RuntimeError, match="exceeds the cache length"):
+        model.forward(ids[:, :1], cache)
+    model.free_unmanaged()

@@ -1,0 +1,460 @@
+"""GPU parity tests: every HIP kernel, called through the C ABI (exllama_amd.cuda_ext -> ctypes -> libexl_amd.so),
+against the CPU oracle on the same seeded inputs.
+
+Tolerances (stated per test): integer / bit-copy work is bit-exact; fp16 results of fp32-accumulated kernels are
+compared with `|got - ref| <= atol` where atol is a small multiple of one fp16 ulp at the output's scale.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from exllama_amd import synth
+from oracle import exl_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ce():
+    assert torch.cuda.is_available(), "GPU tests selected but no HIP device is visible"
+    from exllama_amd import cuda_ext
+    return cuda_ext
+
+
+def _lin(K, N, gs, act, seed, zeros="rand", std=0.05):
+    gen = torch.Generator().manual_seed(seed)
+    lin = synth.make_q4_linear(K, N, gs, act, gen, "cpu", zeros=zeros, std=std)
+    return lin, gen
+
+
+def _to_dev(lin):
+    return {k: v.to(DEV).contiguous() for k, v in lin.items() if k != "g_idx"}
+
+
+def _handle(ce, lin):
+    d = _to_dev(lin)
+    h = ce.ext_make_q4(d["qweight"], d["qzeros"], d["scales"], lin.get("g_idx"), 0)
+    return h, d
+
+
+def _oracle_w(lin):
+    qw = lin["qweight"].numpy().view(np.uint32)
+    qz = lin["qzeros"].numpy().view(np.uint32)
+    sc = lin["scales"].numpy()
+    x_map = None
+    if "g_idx" in lin:
+        x_map, qw = O.make_sequential(qw, lin["g_idx"].numpy(), qz.shape[0])
+    return dict(qweight=qw, qzeros=qz, scales=sc, x_map=x_map)
+
+
+def _close(got, ref, ulps=2.0):
+    """fp16 comparison: atol = ulps * (fp16 ulp at the largest |ref|) ; also reports the worst element."""
+    got = np.asarray(got).astype(np.float64)
+    ref = np.asarray(ref).astype(np.float64)
+    assert got.shape == ref.shape
+    assert np.isfinite(got).all()
+    scale = max(np.abs(ref).max(), 1e-3)
+    atol = ulps * scale * 2.0 ** -10
+    err = np.abs(got - ref).max()
+    assert err <= atol, f"max |diff| {err:.3e} > atol {atol:.3e} (scale {scale:.3e})"
+
+
+# ---------------------------------------------------------------------------------------------------------
+# make_q4 / act-order / reconstruct / column_remap: integer + bit-exact fp16
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K,N,gs,act", [(256, 128, 64, True), (512, 96, 128, False), (256, 64, 32, True),
+                                        (4096, 4096, 128, True), (11008, 4096, 128, False), (704, 256, 64, True)])
+def test_make_q4_and_reconstruct_bit_exact(ce, K, N, gs, act):
+    lin, _ = _lin(K, N, gs, act, seed=K + N)
+    h, d = _handle(ce, lin)
+    ow = _oracle_w(lin)
+    info = ce.exllama_ext.q4_info(h)
+    assert (info["height"], info["width"], info["groups"], info["groupsize"]) == (K, N, K // gs, gs)
+    if act:
+        assert info["x_map"], "act-order weight must own a device x_map"
+        # in-place repack of the caller's qweight tensor (reference: q4_matrix.cu:159)
+        assert np.array_equal(d["qweight"].cpu().numpy().view(np.uint32), ow["qweight"])
+    else:
+        assert not info["x_map"]
+        assert np.array_equal(d["qweight"].cpu().numpy().view(np.uint32), lin["qweight"].numpy().view(np.uint32))
+    w16 = torch.empty((K, N), dtype=torch.float16, device=DEV)
+    ce.exllama_ext.q4_reconstruct(h, w16)
+    ref = O.dequant_w16(ow["qweight"], ow["qzeros"], ow["scales"])
+    assert np.array_equal(w16.cpu().numpy().view(np.uint16), ref.view(np.uint16))      # bit-exact fp16 weights
+
+
+def test_make_q4_golden_fixture(ce, golden_dir):
+    g = np.load(os.path.join(golden_dir, "ops_small.npz"))
+    for tag in ("a", "c"):
+        qw = torch.from_numpy(g[f"q4{tag}_qweight"].view(np.int32).copy()).to(DEV)
+        qz = torch.from_numpy(g[f"q4{tag}_qzeros"].view(np.int32).copy()).to(DEV)
+        sc = torch.from_numpy(g[f"q4{tag}_scales"].copy()).to(DEV)
+        gi = torch.from_numpy(g[f"q4{tag}_g_idx"].copy())
+        h = ce.ext_make_q4(qw, qz, sc, gi, 0)
+        assert np.array_equal(qw.cpu().numpy().view(np.uint32), g[f"q4{tag}_qweight_seq"])
+        x = torch.from_numpy(g[f"q4{tag}_x"].copy()).to(DEV)
+        out = ce.ext_q4_matmul(x[:3], h, qw.shape[1])
+        _close(out.cpu().numpy(), g[f"q4{tag}_out_gemv"])
+
+
+def test_empty_g_idx_is_rejected_by_caller_contract(ce):
+    """All-zero g_idx never reaches make_q4 (model.py:147-149 drops it); a g_idx with an out-of-range group raises."""
+    lin, _ = _lin(256, 64, 64, False, seed=3)
+    d = _to_dev(lin)
+    bad = torch.full((256,), 99, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="out of range"):
+        ce.ext_make_q4(d["qweight"], d["qzeros"], d["scales"], bad, 0)
+
+
+def test_column_remap_bit_exact(ce):
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(37, 512, generator=gen).half()
+    perm = torch.randperm(512, generator=gen).to(torch.int32)
+    out = torch.empty_like(x, device=DEV)
+    ce.exllama_ext.column_remap(x.to(DEV), out, perm.to(DEV))
+    assert np.array_equal(out.cpu().numpy().view(np.uint16), O.column_remap(x.numpy(), perm.numpy()).view(np.uint16))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# q4 matmul: decode GEMV and prefill MFMA GEMM
+# ---------------------------------------------------------------------------------------------------------
+GEMV_SHAPES = [(256, 128, 64, True), (512, 96, 128, False), (256, 64, 32, True), (704, 256, 64, False),
+               (4096, 4096, 128, False), (4096, 11008, 128, False), (11008, 4096, 128, False),
+               (5120, 5120, 128, True), (6656, 6656, 32, True), (4096, 32000 // 32 * 32, 4096, False)]
+
+
+@pytest.mark.parametrize("K,N,gs,act", GEMV_SHAPES)
+@pytest.mark.parametrize("rows", [1, 3, 8])
+def test_q4_gemv_vs_oracle(ce, K, N, gs, act, rows):
+    if rows != 1 and K * N > 4096 * 4096:
+        pytest.skip("large shapes are covered at rows = 1")
+    lin, gen = _lin(K, N, gs, act, seed=K * 7 + N + rows, std=0.02 * (4096 / K) ** 0.5)
+    h, d = _handle(ce, lin)
+    ow = _oracle_w(lin)
+    x = torch.randn(rows, K, generator=gen).half()
+    out = torch.empty((rows, N), dtype=torch.float16, device=DEV)
+    ce.exllama_ext.q4_matmul_gemv(x.to(DEV), h, out)
+    ref = O.q4_matmul_gemv_f32(x.numpy(), **ow)
+    _close(out.cpu().numpy(), ref, ulps=1.5)          # fp32 accumulation, one final rounding: <= ~1 ulp at scale
+    # residual-fusing epilogue (no_zero): out += x @ W
+    res = (torch.randn(rows, N, generator=gen) * 0.5).half()
+    out2 = res.to(DEV).clone()
+    ce.exllama_ext.q4_matmul_gemv(x.to(DEV), h, out2, no_zero=True)
+    _close(out2.cpu().numpy(), O.q4_matmul_gemv_f32(x.numpy(), out=res.numpy(), **ow), ulps=1.5)
+
+
+def test_q4_gemv_is_deterministic(ce):
+    """No atomics: bit-identical across runs (the reference's fp16 atomicAdd split-K is not)."""
+    lin, gen = _lin(4096, 4096, 128, False, seed=1)
+    h, d = _handle(ce, lin)
+    x = torch.randn(1, 4096, generator=gen).half().to(DEV)
+    outs = []
+    for _ in range(5):
+        o = torch.empty((1, 4096), dtype=torch.float16, device=DEV)
+        ce.exllama_ext.q4_matmul_gemv(x, h, o)
+        outs.append(o.cpu().numpy().view(np.uint16).copy())
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])
+
+
+GEMM_SHAPES = [(256, 128, 64, True, 16), (512, 96, 128, False, 33), (704, 256, 64, True, 130), (256, 64, 32, True, 8),
+               (4096, 4096, 128, False, 128), (4096, 11008, 128, False, 96), (11008, 4096, 128, True, 200),
+               (6656, 6656, 32, True, 64)]
+
+
+@pytest.mark.parametrize("K,N,gs,act,rows", GEMM_SHAPES)
+def test_q4_gemm_vs_oracle(ce, K, N, gs, act, rows):
+    lin, gen = _lin(K, N, gs, act, seed=K + 3 * N + rows, std=0.02 * (4096 / K) ** 0.5)
+    h, d = _handle(ce, lin)
+    ow = _oracle_w(lin)
+    x = torch.randn(rows, K, generator=gen).half()
+    tmp = torch.empty((rows * 2, K), dtype=torch.float16, device=DEV)      # act-order gather scratch = "temp_state"
+    z = torch.zeros(64, dtype=torch.float16, device=DEV)
+    ce.exllama_ext.prepare_buffers(torch.device(DEV), tmp, z, torch.zeros((1, 64), dtype=torch.float32, device=DEV), z)
+    out = torch.empty((rows, N), dtype=torch.float16, device=DEV)
+    ce.exllama_ext.q4_matmul_gemm(x.to(DEV), h, out)
+    ref = O.q4_matmul_recons(x.numpy(), **ow)
+    _close(out.cpu().numpy(), ref, ulps=1.5)          # same W16 bits, fp32 accumulate in a different order
+    res = (torch.randn(rows, N, generator=gen) * 0.5).half()
+    out2 = res.to(DEV).clone()
+    ce.exllama_ext.q4_matmul_gemm(x.to(DEV), h, out2, no_zero=True)
+    _close(out2.cpu().numpy(), O.q4_matmul_recons(x.numpy(), out=res.numpy(), **ow), ulps=1.5)
+
+
+def test_q4_matmul_threshold_dispatch(ce):
+    """rows < matmul_recons_thd -> GEMV, else GEMM (reference: exllama_ext.cpp:217); both agree within tolerance."""
+    lin, gen = _lin(512, 256, 128, False, seed=9)
+    h, d = _handle(ce, lin)
+    ow = _oracle_w(lin)
+    for rows in (1, 7, 8, 40):
+        x = torch.randn(rows, 512, generator=gen).half()
+        out = ce.ext_q4_matmul(x.to(DEV), h, 256)
+        ref = O.q4_matmul_recons(x.numpy(), **ow)
+        _close(out.cpu().numpy(), ref, ulps=3.0)
+    x3 = torch.randn(2, 5, 512, generator=gen).half()                       # leading dims are flattened (cuda_ext.py:100)
+    assert ce.ext_q4_matmul(x3.to(DEV), h, 256).shape == (2, 5, 256)
+
+
+def test_full_size_prefill_property_gemm_equals_reconstruct_times_blas(ce):
+    """BASELINE size (7B gate_proj, M = 2048): the fused-dequant MFMA GEMM must equal torch's fp16 GEMM on the
+    reconstructed W16 (an independent implementation of the same product) -- size-independent equivalence."""
+    K, N, M = 4096, 11008, 2048
+    lin, gen = _lin(K, N, 128, False, seed=77, zeros="sym", std=0.02)
+    h, d = _handle(ce, lin)
+    x = torch.randn(M, K, generator=gen).half().to(DEV)
+    out = torch.empty((M, N), dtype=torch.float16, device=DEV)
+    ce.exllama_ext.q4_matmul_gemm(x, h, out)
+    w16 = torch.empty((K, N), dtype=torch.float16, device=DEV)
+    ce.exllama_ext.q4_reconstruct(h, w16)
+    ref = (x.float() @ w16.float())
+    err = (out.float() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 2.0 * scale * 2.0 ** -10, (err, scale)
+    # linearity: (2x) @ W == 2 (x @ W) exactly in fp16 (power-of-two scaling commutes with rounding)
+    out2 = torch.empty_like(out)
+    ce.exllama_ext.q4_matmul_gemm((x * 2).contiguous(), h, out2)
+    assert torch.equal(out2, out * 2)
+
+
+def test_q4_matmul_lora(ce):
+    lin, gen = _lin(512, 256, 128, False, seed=21)
+    h, d = _handle(ce, lin)
+    ow = _oracle_w(lin)
+    x = torch.randn(5, 512, generator=gen).half()
+    a = (torch.randn(512, 16, generator=gen) * 0.05).half()
+    b = (torch.randn(16, 256, generator=gen) * 0.05).half()
+    out = ce.ext_q4_matmul(x.to(DEV), h, 256, a.to(DEV), b.to(DEV))
+    t = O.half_matmul(x.numpy(), a.numpy())
+    ref = O.q4_matmul_gemv_f32(x.numpy(), out=O.half_matmul(t, b.numpy()), **ow)
+    _close(out.cpu().numpy(), ref, ulps=3.0)
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 512, 16), (3, 64, 200), (70, 130 // 2 * 2, 96), (130, 256, 64)])
+def test_half_matmul(ce, M, K, N):
+    gen = torch.Generator().manual_seed(M * K + N)
+    x = torch.randn(M, K, generator=gen).half()
+    w = (torch.randn(K, N, generator=gen) * 0.1).half()
+    ref = O.half_matmul(x.numpy(), w.numpy())
+    _close(ce.ext_half_matmul(x.to(DEV), w.to(DEV), cublas=True).cpu().numpy(), ref, ulps=1.5)
+    _close(ce.ext_half_matmul(x.to(DEV), w.to(DEV), cublas=False).cpu().numpy(), ref, ulps=1.5)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# glue kernels
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,dim", [(1, 4096), (6, 320), (2048, 4096), (3, 8192), (5, 22016 // 8 * 8)])
+def test_rms_norm(ce, rows, dim, golden_dir):
+    gen = torch.Generator().manual_seed(rows + dim)
+    x = (torch.randn(rows, dim, generator=gen) * 2).half()
+    w = (1 + 0.1 * torch.randn(dim, generator=gen)).half()
+    out = ce.ext_rms_norm(x.to(DEV), w.to(DEV), 1e-6)
+    ref = O.rms_norm(x.numpy(), w.numpy(), 1e-6)
+    got = out.cpu().numpy()
+    # two fp16 multiplies after an fp32 reduction: identical up to 1 ulp where the fp16 rounding of rsqrt flips
+    diff = np.abs(got.view(np.int16).astype(np.int32) - ref.view(np.int16).astype(np.int32))
+    assert diff.max() <= 2, diff.max()
+    assert (diff > 0).mean() < 0.02
+    xin = x.to(DEV).clone()
+    ce.ext_rms_norm_(xin, w.to(DEV), 1e-6)                                   # in-place variant
+    assert torch.equal(xin, out)
+
+
+def test_rms_norm_golden(ce, golden_dir):
+    g = np.load(os.path.join(golden_dir, "ops_small.npz"))
+    out = ce.ext_rms_norm(torch.from_numpy(g["rms_x"].copy()).to(DEV), torch.from_numpy(g["rms_w"].copy()).to(DEV), 1e-6)
+    diff = np.abs(out.cpu().numpy().view(np.int16).astype(np.int32) - g["rms_out"].view(np.int16).astype(np.int32))
+    assert diff.max() <= 1
+
+
+@pytest.mark.parametrize("bsz,q_len,heads,hd,past", [(1, 1, 32, 128, 0), (1, 1, 32, 128, 1919), (2, 3, 4, 32, 5),
+                                                     (1, 2048, 32, 128, 0), (1, 7, 8, 64, 100)])
+def test_rope_bit_exact(ce, bsz, q_len, heads, hd, past):
+    gen = torch.Generator().manual_seed(q_len + heads)
+    sin, cos = O.rope_tables(max(2048, past + q_len), hd)
+    x = torch.randn(bsz, q_len, heads * hd, generator=gen).half()
+    xd = x.to(DEV).clone()
+    ce.ext_rope_(xd, torch.from_numpy(sin).to(DEV)[None, None], torch.from_numpy(cos).to(DEV)[None, None], past, heads, hd)
+    ref = O.rope(x.numpy().reshape(bsz, -1), sin, cos, past, heads, hd).reshape(x.shape)
+    assert np.array_equal(xd.cpu().numpy().view(np.uint16), ref.view(np.uint16))       # fp16 mul + fma: exact contract
+    # device-side position (graph replay path) gives the same bits
+    xd2 = x.to(DEV).clone()
+    pos = torch.tensor([past], dtype=torch.int32, device=DEV)
+    ce.exllama_ext.rope_(xd2, torch.from_numpy(sin).to(DEV), torch.from_numpy(cos).to(DEV), 0, heads, hd, past_len_dev=pos)
+    assert torch.equal(xd2, xd)
+
+
+def test_silu_mul(ce):
+    gen = torch.Generator().manual_seed(4)
+    x = (torch.randn(4, 11008, generator=gen) * 3).half()
+    y = torch.randn(4, 11008, generator=gen).half()
+    xd = x.to(DEV).clone()
+    ce.exllama_ext.silu_mul(xd, y.to(DEV))
+    with np.errstate(over="ignore"):
+        ref = O.silu_mul(x.numpy(), y.numpy())
+    got = xd.cpu().numpy()
+    diff = np.abs(got.view(np.int16).astype(np.int32) - ref.view(np.int16).astype(np.int32))
+    assert diff.max() <= 2          # hardware exp / rcp approximations: <= 2 fp16 ulp (oracle docstring)
+    np.testing.assert_allclose(got.astype(np.float32), ref.astype(np.float32), rtol=3e-3, atol=1e-4)
+
+
+def test_update_cache_bit_exact(ce):
+    gen = torch.Generator().manual_seed(5)
+    bsz, q_len, kvh, hd, max_seq, past = 2, 3, 4, 32, 16, 7
+    k = torch.randn(bsz, q_len, kvh * hd, generator=gen).half()
+    v = torch.randn(bsz, q_len, kvh * hd, generator=gen).half()
+    kc = torch.zeros(bsz, kvh, max_seq, hd, dtype=torch.float16, device=DEV)
+    vc = torch.zeros_like(kc)
+    ce.exllama_ext.update_cache(k.to(DEV), v.to(DEV), kc, vc, past)
+    rk = np.zeros((bsz, kvh, max_seq, hd), dtype=np.float16)
+    rv = np.zeros_like(rk)
+    O.update_cache(k.numpy(), v.numpy(), rk, rv, past)
+    assert np.array_equal(kc.cpu().numpy().view(np.uint16), rk.view(np.uint16))
+    assert np.array_equal(vc.cpu().numpy().view(np.uint16), rv.view(np.uint16))
+    with pytest.raises(RuntimeError, match="exceeds max_seq_len"):
+        ce.exllama_ext.update_cache(k.to(DEV), v.to(DEV), kc, vc, max_seq - 1)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------------------
+def _attn_case(ce, bsz, q_len, heads, kvh, hd, past, max_seq, seed, with_mask=False, dev_pos=False):
+    gen = torch.Generator().manual_seed(seed)
+    kv_len = past + q_len
+    q = torch.randn(bsz, q_len, heads * hd, generator=gen).half()
+    kc = torch.zeros(bsz, kvh, max_seq, hd, dtype=torch.float16)
+    vc = torch.zeros_like(kc)
+    kc[:, :, :kv_len] = torch.randn(bsz, kvh, kv_len, hd, generator=gen).half()
+    vc[:, :, :kv_len] = torch.randn(bsz, kvh, kv_len, hd, generator=gen).half()
+    mask = None
+    if with_mask:
+        mask = torch.zeros(bsz, 1, q_len, kv_len, dtype=torch.float16)
+        mask[:, :, :, :2] = -65504.0                                          # left padding
+    out = torch.empty_like(q, device=DEV)
+    pos = torch.tensor([past], dtype=torch.int32, device=DEV) if dev_pos else None
+    ce.exllama_ext.attention(q.to(DEV), kc.to(DEV), vc.to(DEV), out, past, heads,
+                             mask=None if mask is None else mask.to(DEV), past_len_dev=pos)
+    qn = q.numpy().reshape(bsz, q_len, heads, hd).transpose(0, 2, 1, 3)
+    ref = O.attention(qn, kc.numpy()[:, :, :kv_len], vc.numpy()[:, :, :kv_len], causal_past_len=past,
+                      mask=None if mask is None else mask.numpy())
+    ref = ref.transpose(0, 2, 1, 3).reshape(bsz, q_len, heads * hd)
+    _close(out.cpu().numpy(), ref, ulps=4.0)        # fp16 probabilities inside the MFMA path: a few ulp at |o| ~ 1
+
+
+@pytest.mark.parametrize("past", [0, 1, 63, 64, 300, 1919, 2047])
+def test_attention_decode(ce, past):
+    _attn_case(ce, 1, 1, 32, 32, 128, past, 2048, seed=past)
+
+
+def test_attention_decode_variants(ce):
+    _attn_case(ce, 2, 1, 8, 4, 64, 37, 64, seed=1)                 # GQA, bsz 2, hd 64
+    _attn_case(ce, 1, 3, 8, 8, 128, 10, 64, seed=2)                # short q_len: causal inside the new tokens
+    _attn_case(ce, 1, 1, 4, 4, 128, 500, 2048, seed=3, dev_pos=True)
+    _attn_case(ce, 2, 5, 4, 2, 32, 6, 32, seed=4, with_mask=True)  # additive padding mask (model.py:1016-1026)
+
+
+@pytest.mark.parametrize("q_len,past,heads,kvh", [(16, 0, 4, 4), (128, 0, 4, 4), (200, 0, 8, 2), (333, 45, 4, 4), (64, 1000, 2, 2)])
+def test_attention_prefill_flash(ce, q_len, past, heads, kvh):
+    _attn_case(ce, 1, q_len, heads, kvh, 128, past, 2048, seed=q_len + past)
+
+
+def test_attention_prefill_full_size_row_checks(ce):
+    """S = 2048, 32 heads (BASELINE config 2): spot-check rows of a few heads against the oracle, and the causal
+    property: the first row equals v[0], and output rows are independent of later keys."""
+    gen = torch.Generator().manual_seed(8)
+    heads, hd, S = 32, 128, 2048
+    q = torch.randn(1, S, heads * hd, generator=gen).half().to(DEV)
+    kc = torch.randn(1, heads, S, hd, generator=gen).half().to(DEV)
+    vc = torch.randn(1, heads, S, hd, generator=gen).half().to(DEV)
+    out = torch.empty_like(q)
+    ce.exllama_ext.attention(q, kc, vc, out, 0, heads)
+    o = out.view(S, heads, hd)
+    assert torch.equal(o[0], vc[0, :, 0, :])                        # softmax over one key
+    for hsel in (0, 17, 31):
+        qn = q.view(S, heads, hd)[:, hsel].cpu().numpy()[None, None]
+        ref = O.attention(qn, kc[:, hsel:hsel + 1].cpu().numpy(), vc[:, hsel:hsel + 1].cpu().numpy(), causal_past_len=0)
+        _close(o[:, hsel].cpu().numpy(), ref[0, 0], ulps=4.0)
+    kc2 = kc.clone()
+    kc2[:, :, 1024:] = 0                                             # perturb the future: rows < 1024 must not move
+    out2 = torch.empty_like(q)
+    ce.exllama_ext.attention(q, kc2, vc, out2, 0, heads)
+    assert torch.equal(out2[:, :1024], out[:, :1024])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fused decode ops (compositions exactly as the reference launches them)
+# ---------------------------------------------------------------------------------------------------------
+def _prep_buffers(ce, max_rows, dim, inter):
+    ts = torch.zeros((max(2 * max_rows, 16), max(dim, inter)), dtype=torch.float16, device=DEV)
+    tm = torch.zeros((2 * max_rows, inter), dtype=torch.float16, device=DEV)
+    tz = torch.zeros((1, 65536), dtype=torch.float32, device=DEV)
+    td = torch.zeros((1, 64), dtype=torch.float16, device=DEV)
+    ce.exllama_ext.prepare_buffers(torch.device(DEV), ts, tm, tz, td)
+    return ts, tm, tz, td
+
+
+@pytest.mark.parametrize("dim,heads,kvh,act,gs", [(256, 4, 4, False, 64), (512, 8, 4, True, 128), (4096, 32, 32, False, 128)])
+def test_q4_attn_fused(ce, dim, heads, kvh, act, gs):
+    hd = dim // heads
+    keep = _prep_buffers(ce, 2, dim, dim)
+    gen = torch.Generator().manual_seed(dim)
+    lq, _ = _lin(dim, heads * hd, gs, act, seed=dim + 1, std=0.03)
+    lk, _ = _lin(dim, kvh * hd, gs, act, seed=dim + 2, std=0.03)
+    lv, _ = _lin(dim, kvh * hd, gs, act, seed=dim + 3, std=0.03)
+    hq, dq = _handle(ce, lq)
+    hk, dk = _handle(ce, lk)
+    hv, dv = _handle(ce, lv)
+    max_seq, past = 64, 9
+    sin, cos = O.rope_tables(max_seq, hd)
+    x = torch.randn(1, 1, dim, generator=gen).half()
+    w = (1 + 0.1 * torch.randn(dim, generator=gen)).half()
+    q = torch.empty((1, 1, heads * hd), dtype=torch.float16, device=DEV)
+    k = torch.empty((1, 1, kvh * hd), dtype=torch.float16, device=DEV)
+    v = torch.empty_like(k)
+    kc = torch.zeros(1, kvh, max_seq, hd, dtype=torch.float16, device=DEV)
+    vc = torch.zeros_like(kc)
+    nt = ce.none_tensor
+    ce.exllama_ext.q4_attn(x.to(DEV), w.to(DEV), 1e-6, q, k, v, hq, hk, hv, torch.from_numpy(sin).to(DEV)[None, None],
+                           torch.from_numpy(cos).to(DEV)[None, None], 1, past, heads, kvh, hd, kc, vc, max_seq,
+                           nt, nt, nt, nt, nt, nt, nt)
+    rkc = np.zeros((1, kvh, max_seq, hd), dtype=np.float16)
+    rvc = np.zeros_like(rkc)
+    rq, rk, rv = O.q4_attn(x.numpy(), w.numpy(), 1e-6, _oracle_w(lq), _oracle_w(lk), _oracle_w(lv), sin, cos, past, heads,
+                           kvh, hd, rkc, rvc)
+    _close(q.cpu().numpy(), rq, ulps=3.0)
+    _close(k.cpu().numpy(), rk, ulps=3.0)
+    _close(v.cpu().numpy(), rv, ulps=3.0)
+    # the scatter is a bit copy of the states the kernel itself produced
+    assert torch.equal(kc[0, :, past, :].reshape(-1), k.view(-1))
+    assert torch.equal(vc[0, :, past, :].reshape(-1), v.view(-1))
+    assert not kc[:, :, :past].any() and not kc[:, :, past + 1:].any()
+
+
+def test_q4_attn_2_and_mlp_fused(ce):
+    dim, inter, gs = 512, 1408, 128
+    keep = _prep_buffers(ce, 2, dim, inter)
+    gen = torch.Generator().manual_seed(2)
+    lo, _ = _lin(dim, dim, gs, True, seed=31, std=0.03)
+    lg, _ = _lin(dim, inter, gs, True, seed=32, std=0.03)
+    lu, _ = _lin(dim, inter, gs, False, seed=33, std=0.03)
+    ld, _ = _lin(inter, dim, gs, True, seed=34, std=0.02)
+    ho, _d0 = _handle(ce, lo)
+    hg, _d1 = _handle(ce, lg)
+    hu, _d2 = _handle(ce, lu)
+    hdn, _d3 = _handle(ce, ld)
+    nt = ce.none_tensor
+    for rows in (1, 2):
+        x = torch.randn(rows, 1, dim, generator=gen).half()
+        attn = torch.randn(rows, 1, dim, generator=gen).half()
+        xd = x.to(DEV).clone()
+        ce.exllama_ext.q4_attn_2(xd, attn.to(DEV), ho, nt, nt, nt)
+        ref = O.q4_attn_2(x.numpy(), attn.numpy(), _oracle_w(lo))
+        _close(xd.cpu().numpy(), ref, ulps=2.0)
+        w = (1 + 0.1 * torch.randn(dim, generator=gen)).half()
+        xm = x.to(DEV).clone().view(-1, dim)
+        ce.exllama_ext.q4_mlp(xm, w.to(DEV), 1e-6, hg, hu, hdn, nt, nt, nt, nt, nt, nt, nt)
+        with np.errstate(over="ignore"):
+            refm = O.q4_mlp(x.numpy().reshape(-1, dim), w.numpy(), 1e-6, _oracle_w(lg), _oracle_w(lu), _oracle_w(ld))
+        _close(xm.cpu().numpy(), refm, ulps=4.0)

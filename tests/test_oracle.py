@@ -1,0 +1,142 @@
+"""CPU tests of the oracle itself: golden fixtures (regression pins), the reference's own rep_penalty.cpp,
+and algebraic self-consistency of the restated kernels."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from exllama_amd import synth
+from oracle import exl_oracle as O
+from oracle.model_oracle import OracleLlama
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ops(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops_small.npz"))
+
+
+@pytest.mark.parametrize("tag,act", [("a", True), ("b", False), ("c", True)])
+def test_q4_golden(ops, tag, act):
+    qw, qz, sc, x = (ops[f"q4{tag}_{k}"] for k in ("qweight", "qzeros", "scales", "x"))
+    x_map, qws = None, qw
+    if act:
+        x_map, qws = O.make_sequential(qw, ops[f"q4{tag}_g_idx"], qz.shape[0])
+        assert np.array_equal(x_map, ops[f"q4{tag}_x_map"])                      # integer work: bit-exact
+        assert np.array_equal(qws, ops[f"q4{tag}_qweight_seq"])
+    assert np.array_equal(O.dequant_w16(qws, qz, sc).view(np.uint16), ops[f"q4{tag}_w16"].view(np.uint16))
+    assert np.array_equal(O.q4_matmul_recons(x, qws, qz, sc, x_map).view(np.uint16), ops[f"q4{tag}_out_recons"].view(np.uint16))
+    assert np.array_equal(O.q4_matmul_gemv_f32(x[:3], qws, qz, sc, x_map).view(np.uint16), ops[f"q4{tag}_out_gemv"].view(np.uint16))
+
+
+def test_pack_unpack_roundtrip():
+    rs = np.random.RandomState(0)
+    q = rs.randint(0, 16, size=(64, 24)).astype(np.uint8)
+    assert np.array_equal(O.unpack_qweight(O.pack_qweight(q)), q)
+    z = rs.randint(0, 16, size=(4, 24))
+    assert np.array_equal(O.unpack_qzeros(O.pack_qzeros(z)), z + 1)              # the +1 of GPTQ v1 storage
+
+
+def test_act_order_is_a_pure_permutation():
+    """x' @ W_seq == x @ W for the dequantised weights (make_sequential + column_remap)."""
+    gen = torch.Generator().manual_seed(5)
+    K, N, gs = 384, 64, 128
+    lin = synth.make_q4_linear(K, N, gs, True, gen, "cpu", zeros="rand", std=0.05)
+    qw, qz, sc, gi = (lin[k].numpy() for k in ("qweight", "qzeros", "scales", "g_idx"))
+    x = torch.randn(4, K, generator=gen).half().numpy()
+    x_map, qws = O.make_sequential(qw, gi, qz.shape[0])
+    assert sorted(x_map.tolist()) == list(range(K))
+    assert np.array_equal(gi[x_map.astype(np.int64)], np.repeat(np.arange(K // gs), gs))     # groups now contiguous
+    # direct evaluation with per-row group index on the ORIGINAL row order
+    q = O.unpack_qweight(qw).astype(np.int32)
+    z = O.unpack_qzeros(qz)
+    W = ((q - z[gi]).astype(np.float16).astype(np.float32) * sc.astype(np.float32)[gi]).astype(np.float16)
+    ref = x.astype(np.float64) @ W.astype(np.float64)
+    got = O.column_remap(x, x_map).astype(np.float64) @ O.dequant_w16(qws, qz, sc).astype(np.float64)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-9)
+
+
+def test_gemv_forms_agree_within_fp16_tolerance(ops):
+    """fp32-accumulated target vs dequant-then-GEMM vs the reference's fp16-accumulating arithmetic."""
+    for tag in "abc":
+        a = ops[f"q4{tag}_out_gemv"][:1].astype(np.float32)
+        b = ops[f"q4{tag}_out_recons"][:1].astype(np.float32)
+        e = ops[f"q4{tag}_out_f16emu"].astype(np.float32)
+        scale = np.abs(b).max()
+        assert np.abs(a - b).max() <= 4e-3 * scale
+        assert np.abs(e - b).max() <= 2e-2 * scale      # the reference's own fp16 accumulation is this far off
+
+
+def test_elementwise_golden(ops):
+    assert np.array_equal(O.rms_norm(ops["rms_x"], ops["rms_w"], 1e-6).view(np.uint16), ops["rms_out"].view(np.uint16))
+    assert np.array_equal(O.rope(ops["rope_x"], ops["rope_sin"], ops["rope_cos"], 5, 4, 32).view(np.uint16), ops["rope_out"].view(np.uint16))
+    with np.errstate(over="ignore"):
+        assert np.array_equal(O.silu_mul(ops["silu_x"], ops["silu_y"]).view(np.uint16), ops["silu_out"].view(np.uint16))
+    got = O.attention(ops["att_q"], ops["att_k"], ops["att_v"], causal_past_len=8)
+    assert np.array_equal(got.view(np.uint16), ops["att_out"].view(np.uint16))
+
+
+def test_rms_norm_matches_plain_formula():
+    rs = np.random.RandomState(1)
+    x = rs.randn(3, 256).astype(np.float16)
+    w = (1 + 0.1 * rs.randn(256)).astype(np.float16)
+    ref = x.astype(np.float64) / np.sqrt((x.astype(np.float64) ** 2).mean(-1, keepdims=True) + 1e-6) * w.astype(np.float64)
+    np.testing.assert_allclose(O.rms_norm(x, w, 1e-6).astype(np.float64), ref, rtol=3e-3, atol=3e-3)
+
+
+def test_rope_is_a_rotation():
+    sin, cos = O.rope_tables(32, 16)
+    x = np.random.RandomState(2).randn(1, 2 * 16).astype(np.float16)          # 1 token, 2 heads
+    y = O.rope(x, sin, cos, 7, 2, 16).astype(np.float64).reshape(2, 16)
+    xx = x.astype(np.float64).reshape(2, 16)
+    np.testing.assert_allclose((y ** 2).sum(-1), (xx ** 2).sum(-1), rtol=5e-3)     # norm preserved
+    assert np.array_equal(O.rope(x, sin, cos, 0, 2, 16).view(np.uint16), x.view(np.uint16))   # position 0 = identity
+
+
+def test_update_cache_scatter():
+    k = np.arange(1, 25, dtype=np.float16).reshape(1, 2, 12)          # bsz 1, q_len 2, kv_heads 3 * hd 4
+    v = -k
+    kc = np.zeros((1, 3, 10, 4), dtype=np.float16)
+    vc = np.zeros_like(kc)
+    O.update_cache(k, v, kc, vc, past_len=5)
+    assert np.array_equal(kc[0, :, 5, :].reshape(-1), k[0, 0])
+    assert np.array_equal(vc[0, :, 6, :].reshape(-1), v[0, 1])
+    assert not kc[0, :, :5].any() and not kc[0, :, 7:].any()
+
+
+def test_rep_penalty_against_reference_binary(golden_dir):
+    """Golden vectors were produced by the reference's rep_penalty.cpp (oracle/_ref); the numpy restatement and, when
+    present, the freshly built reference binary must reproduce them bit for bit."""
+    g = np.load(os.path.join(golden_dir, "rep_penalty.npz"))
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "librep_penalty_ref.so")
+    ref = C.CDLL(ref_path) if os.path.exists(ref_path) else None
+    for n in range(int(g["ncases"])):
+        vocab, seq_len, sustain, decay = (int(v) for v in g[f"c{n}_params"])
+        pmax = float(g[f"c{n}_pmax"])
+        seq = g[f"c{n}_seq"]
+        assert np.array_equal(O.rep_penalty_mask(vocab, seq, pmax, sustain, decay).view(np.uint32), g[f"c{n}_mask"].view(np.uint32))
+        lg = g[f"c{n}_logits"].copy()[None]
+        O.apply_rep_penalty(seq[None], pmax, sustain, decay, lg)
+        assert np.array_equal(lg[0].view(np.uint32), g[f"c{n}_applied"].view(np.uint32))
+        if ref is not None:
+            s = np.ascontiguousarray(seq.astype(np.uint64) if seq_len else np.zeros(1, dtype=np.uint64))
+            m = np.zeros(vocab, dtype=np.float32)
+            ref._Z15rep_penalty_cpuiPKmPffiii(vocab, s.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p), C.c_float(pmax), sustain, decay, seq_len)
+            assert np.array_equal(m.view(np.uint32), g[f"c{n}_mask"].view(np.uint32))
+
+
+def test_tiny_model_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tiny_model.npz"))
+    dims = synth.PRESETS["tiny"]
+    tensors = synth.make_checkpoint(dims, groupsize=64, act_order=False, seed=11, device="cpu", zeros="rand")
+    m = OracleLlama(synth.config_dict(dims), tensors, max_seq_len=64)
+    logits = m.forward(g["tiny_ids"], last_id_only=False)
+    assert np.isfinite(logits).all()
+    np.testing.assert_array_equal(logits.astype(np.float16).view(np.uint16), g["tiny_logits"].view(np.uint16))
+    # prefill-all vs token-by-token must agree within fp16 tolerance (same algebra, different matmul shapes)
+    m2 = OracleLlama(synth.config_dict(dims), tensors, max_seq_len=64)
+    step = np.concatenate([m2.forward(g["tiny_ids"][:, i:i + 1]) for i in range(g["tiny_ids"].shape[1])], axis=1)
+    np.testing.assert_allclose(step, logits, rtol=0, atol=2e-2 * np.abs(logits).max())
