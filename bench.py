@@ -130,7 +130,7 @@ def main():
         e[3].record()
         logits = decode(G, logits)                                # best case: context 4 .. 4+G
         e[4].record()
-        if record:
+        if record is not None:
             record.append(e)
         return logits
 

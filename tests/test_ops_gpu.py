@@ -204,9 +204,13 @@ def test_full_size_prefill_property_gemm_equals_reconstruct_times_blas(ce):
     K, N, M = 4096, 11008, 2048
     lin, gen = _lin(K, N, 128, False, seed=77, zeros="sym", std=0.02)
     h, d = _handle(ce, lin)
-    x = torch.randn(M, K, generator=gen).half().to(DEV)
+    x = torch.randn(M, K, generator=gen).half()
+    x = torch.where(x.abs() < 2.0 ** -10, torch.full_like(x, 2.0 ** -10), x).to(DEV)     # keep fp16 subnormals out of the exactness check
     out = torch.empty((M, N), dtype=torch.float16, device=DEV)
     ce.exllama_ext.q4_matmul_gemm(x, h, out)
+    again = torch.empty_like(out)
+    ce.exllama_ext.q4_matmul_gemm(x, h, again)
+    assert torch.equal(out, again)                                  # deterministic: no atomics, fixed tile order
     w16 = torch.empty((K, N), dtype=torch.float16, device=DEV)
     ce.exllama_ext.q4_reconstruct(h, w16)
     ref = (x.float() @ w16.float())
@@ -216,7 +220,8 @@ def test_full_size_prefill_property_gemm_equals_reconstruct_times_blas(ce):
     # linearity: (2x) @ W == 2 (x @ W) exactly in fp16 (power-of-two scaling commutes with rounding)
     out2 = torch.empty_like(out)
     ce.exllama_ext.q4_matmul_gemm((x * 2).contiguous(), h, out2)
-    assert torch.equal(out2, out * 2)
+    nbad = int((out2 != out * 2).sum())
+    assert nbad == 0, f"{nbad} of {out.numel()} elements break exact linearity"
 
 
 def test_q4_matmul_lora(ce):
