@@ -239,6 +239,8 @@ def gemv_roofline_probe(model, groupsize, dev, tokens=3):
         ext.q4_matmul_gemv(xs[lin.height], lin.q4, outs[lin.width])
     torch.cuda.synchronize()
     pairs = []
+    # keep the GPU busy while the host enqueues, so that event-to-event time is kernel time, not host launch latency
+    torch.cuda._sleep(int(2.0e9 * 0.08 * tokens))
     for _ in range(tokens):
         for lin in mats:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -76,6 +76,7 @@ class _ExllamaExt:
     def __init__(self):
         self._lib = _lib.load()
         self.tuning = _lib.ExlTuning(8, 2, 8, 0, 0, 0, 0, 0, 0)
+        self._dims = {}                 # handle -> (height, width): avoids an FFI round trip per matmul
 
     # -- exllama_ext.cpp:89-112
     def set_tuning_params(self, matmul_recons_thd, fused_mlp_thd, sdp_thd, matmul_fused_remap, rmsnorm_no_half2,
@@ -99,6 +100,7 @@ class _ExllamaExt:
 
     # -- exllama_ext.cpp:117-121
     def cleanup(self):
+        self._dims.clear()
         check(self._lib.exl_cleanup(), "cleanup")
 
     # -- exllama_ext.cpp:157-194
@@ -124,6 +126,7 @@ class _ExllamaExt:
                                         qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(),
                                         None if g_host is None else g_host.data_ptr(), _stream(qweight),
                                         C.byref(handle)), "make_q4")
+        self._dims[handle.value] = (qweight.size(0) * 8, qweight.size(1))
         return handle.value
 
     def q4_info(self, w):
@@ -141,9 +144,10 @@ class _ExllamaExt:
         _req_cuda(x, "x")
         _req_cuda(out, "out")
         _req(x.size(0) == out.size(0), "x and out have incompatible shapes")
-        info = self.q4_info(w)
-        _req(info["height"] == x.size(-1), "x and w have incompatible shapes")
-        _req(out.size(-1) == info["width"], "out and w have incompatible shapes")
+        dims = self._dims.get(w)
+        _req(dims is not None, "invalid q4 handle")
+        _req(dims[0] == x.size(-1), "x and w have incompatible shapes")
+        _req(out.size(-1) == dims[1], "out and w have incompatible shapes")
 
     # -- exllama_ext.cpp:199-240
     def q4_matmul(self, x, w, out):

@@ -441,7 +441,7 @@ class ExLlama:
             }
             self.buffers.append(b)
             ext.prepare_buffers(torch.device(dev), b["temp_state"], b["temp_mlp"], b["temp_zeros_float"], b["temp_dq"])
-        self._graph = None
+        self._decoder = None
         torch.cuda.empty_cache()
 
     # ---- loading -------------------------------------------------------------------------------------------
@@ -549,6 +549,10 @@ class ExLlama:
             raise RuntimeError(f"sequence ({past_len} + {seq_len}) exceeds the cache length {cache.max_seq_len}")
         if output_device is None:
             output_device = input_ids.device
+        st = self._decoder
+        if (st is not None and cache is st["cache"] and bsz == 1 and seq_len == 1 and lora is None
+                and input_mask is None and not preprocess_only):
+            return self._decode_step(input_ids, cache, str(output_device))
         devs = cfg.device_map.get_layers_devs()
 
         buffer = ExLlamaBuffer(cfg)
@@ -588,8 +592,87 @@ class ExLlama:
         logits = torch.matmul(hidden, self.lm_head_weight.t()).float()
         return _move_tensor(logits, output_device, "logits", cfg)
 
-    # ---- hipGraph decode ----------------------------------------------------------------------------------
+    # ---- native decode executor + hipGraph ---------------------------------------------------------------
+    def enable_decode_graph(self, cache, use_graph=True):
+        """Route bsz = 1, q_len = 1 forwards on `cache` through the native decode executor (5 kernels per layer,
+        exllama_amd/csrc/decode_fused.hip) and, with use_graph, replay them as ONE captured hipGraph per token.
+        The position lives in device memory, so the same graph serves every context length."""
+        import ctypes as C
+        cfg = self.config
+        devs = cfg.device_map.get_all_devs()
+        if len(devs) != 1 or not devs[0].startswith("cuda"):
+            raise RuntimeError("the native decode executor needs the whole model on one HIP device")
+        if cache.batch_size != 1:
+            raise RuntimeError("the native decode executor handles batch size 1")
+        if cache.max_seq_len > cfg.max_seq_len:
+            raise RuntimeError("cache is longer than the RoPE tables (config.max_seq_len)")
+        dev = torch.device(devs[0])
+        self.disable_decode_graph()
+        lib = ext._lib
+        sin, cos = self.sincos[devs[0]]
+        handle = C.c_void_p()
+        with cuda_ext._Guard(dev):
+            cuda_ext.check(lib.exl_decoder_create(dev.index, cfg.num_hidden_layers, cfg.hidden_size, cfg.intermediate_size,
+                                                  cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim,
+                                                  cfg.vocab_size, cache.max_seq_len, float(cfg.rms_norm_eps),
+                                                  self.embed_weight.data_ptr(), self.norm.weight.data_ptr(),
+                                                  self.lm_head_weight.data_ptr(), sin.data_ptr(), cos.data_ptr(),
+                                                  C.byref(handle)), "decoder_create")
+            for i, layer in enumerate(self.layers):
+                a, m = layer.self_attn, layer.mlp
+                cuda_ext.check(lib.exl_decoder_set_layer(handle, i, a.q_proj.q4, a.k_proj.q4, a.v_proj.q4, a.o_proj.q4,
+                                                         m.gate_proj.q4, m.up_proj.q4, m.down_proj.q4,
+                                                         layer.input_layernorm.weight.data_ptr(),
+                                                         layer.post_attention_layernorm.weight.data_ptr(),
+                                                         cache.key_states[i].data_ptr(), cache.value_states[i].data_ptr()),
+                               "decoder_set_layer")
+        st = {
+            "handle": handle, "cache": cache, "dev": dev, "graph": None,
+            "tok": torch.zeros((1, 1), dtype=torch.int64, device=dev),
+            "pos": torch.zeros((1,), dtype=torch.int32, device=dev),
+            "logits": torch.zeros((1, 1, cfg.vocab_size), dtype=torch.float32, device=dev),
+            "dev_pos": -1,
+        }
+        self._decoder = st
+        if use_graph:
+            st["pos"].fill_(cache.current_seq_len)
+            self._decoder_launch(st, advance=0)                 # eager dry run (K/V written at the current slot are
+            torch.cuda.synchronize(dev)                          # overwritten by the real token later)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._decoder_launch(st, advance=1)
+            st["graph"] = g
+            st["dev_pos"] = cache.current_seq_len
+
+    def _decoder_launch(self, st, advance):
+        with cuda_ext._Guard(st["dev"]):
+            cuda_ext.check(ext._lib.exl_decoder_step(st["handle"], st["tok"].data_ptr(), st["pos"].data_ptr(),
+                                                     st["logits"].data_ptr(), int(advance),
+                                                     torch.cuda.current_stream(st["dev"]).cuda_stream), "decoder_step")
+
+    def _decode_step(self, input_ids, cache, output_device):
+        st = self._decoder
+        if cache.current_seq_len + 1 > cache.max_seq_len:
+            raise RuntimeError(f"sequence ({cache.current_seq_len} + 1) exceeds the cache length {cache.max_seq_len}")
+        st["tok"].copy_(input_ids.view(1, 1), non_blocking=True)
+        if st["dev_pos"] != cache.current_seq_len:              # host rewound / advanced the cache outside the executor
+            st["pos"].fill_(cache.current_seq_len)
+        if st["graph"] is not None:
+            st["graph"].replay()
+        else:
+            self._decoder_launch(st, advance=1)
+        cache.current_seq_len += 1
+        st["dev_pos"] = cache.current_seq_len
+        return _move_tensor(st["logits"].clone(), output_device, "logits", self.config)
+
+    def disable_decode_graph(self):
+        st = getattr(self, "_decoder", None)
+        if st is not None:
+            st["graph"] = None
+            ext._lib.exl_decoder_free(st["handle"])
+        self._decoder = None
+
     def free_unmanaged(self):
         """Release native handles/buffers (reference: model.py:1090-1092)."""
-        self._graph = None
+        self.disable_decode_graph()
         ext.cleanup()

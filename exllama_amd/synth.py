@@ -52,8 +52,12 @@ LLAMA_65B = LlamaDims(8192, 22016, 80, 64)
 LLAMA_TINY = LlamaDims(256, 704, 2, 4, vocab_size=512)
 LLAMA_TINY_GQA = LlamaDims(512, 1408, 2, 8, num_key_value_heads=4, vocab_size=512)
 
+LLAMA_TINY_HD128 = LlamaDims(512, 1408, 3, 4, vocab_size=512)                       # head_dim 128 like the real models
+LLAMA_TINY_HD128_GQA = LlamaDims(1024, 2816, 2, 8, num_key_value_heads=2, vocab_size=640)
+
 PRESETS = {"7b": LLAMA_7B, "13b": LLAMA_13B, "33b": LLAMA_33B, "65b": LLAMA_65B,
-           "tiny": LLAMA_TINY, "tiny_gqa": LLAMA_TINY_GQA}
+           "tiny": LLAMA_TINY, "tiny_gqa": LLAMA_TINY_GQA, "tiny_hd128": LLAMA_TINY_HD128,
+           "tiny_hd128_gqa": LLAMA_TINY_HD128_GQA}
 
 
 def make_q4_linear(K, N, groupsize, act_order, gen, device, zeros="sym", std=None):

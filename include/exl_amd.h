@@ -151,6 +151,23 @@ int exl_q4_mlp(int device, void* x, const void* rms_norm_weight, float epsilon, 
                const void* up_b, int up_rank, const void* down_a, const void* down_b, int down_rank,
                void* lora_temp, void* stream);
 
+/* ---- native single-token decode executor (no counterpart in the reference: it replaces the Python layer loop
+ * model.py:1053-1058 + the three fused ops + the ATen attention for bsz = 1, q_len = 1) -------------------------- */
+/* All pointers are device pointers that must stay valid for the decoder's lifetime: embed [vocab, hidden] fp16,
+ * final_norm [hidden] fp16, lm_head [vocab, hidden] fp16, sin/cos [max_seq_len, head_dim] fp16. head_dim must be 128. */
+int exl_decoder_create(int device, int n_layers, int hidden, int inter, int heads, int kv_heads, int head_dim,
+                       int vocab, int max_seq_len, float eps, const void* embed, const void* final_norm,
+                       const void* lm_head, const void* sin, const void* cos, void** out_decoder);
+/* q..down: Q4 handles of layer `index`; norms fp16 [hidden]; caches fp16 [1, kv_heads, max_seq_len, head_dim]. */
+int exl_decoder_set_layer(void* decoder, int index, void* q, void* k, void* v, void* o, void* gate, void* up,
+                          void* down, const void* in_norm, const void* post_norm, void* key_cache, void* value_cache);
+/* One token: reads the token id (int64) and the position (int32) from DEVICE memory, appends K/V at that position,
+ * writes fp32 logits [vocab]; when advance != 0 the device position is incremented at the end of the step.
+ * 5 kernels per layer + 1, no allocation, no synchronisation: capturable in a hipGraph. */
+int exl_decoder_step(void* decoder, const int64_t* token_dev, int32_t* pos_dev, float* logits_out, int advance,
+                     void* stream);
+int exl_decoder_free(void* decoder);
+
 /* ---- repetition penalty, HOST memory, fp32 (reference: exllama_ext.cpp:684-741, cpu_func/rep_penalty.cpp) */
 int exl_rep_penalty(int vocab_size, const uint64_t* sequence_host, float* rep_mask_host, float penalty_max,
                     int sustain, int decay, int seq_len);

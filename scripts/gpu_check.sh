@@ -20,14 +20,14 @@ smoke)
 bench)
   timeout 900 python bench.py --gpus 1 --steps 2 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?" >> $OUT/bench.err ;;
 prof)
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- \
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- \
       python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/bench_prof.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err )
   echo "prof exit $?" >> $OUT/prof.err
   find $OUT/prof -name "*kernel_stats*" | head -3 >> $OUT/prof.err
   # keep only the small summaries (traces can be huge)
-  find $OUT/prof -type f ! -name "*stats*" -size +2M -delete ;;
+  find $OUT/prof -type f ! -name "*stats*" -size +8M -delete ;;
 pmc)
-  ( cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $GRAFT_REPO_ROOT/$OUT/pmc_fetch -o pmc -- \
+  ( cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_fetch -o pmc -- \
       python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline --gen 16 > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/pmc.err )
   echo "pmc exit $?" >> $OUT/pmc.err ;;
 esac

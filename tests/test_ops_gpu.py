@@ -220,7 +220,8 @@ def test_full_size_prefill_property_gemm_equals_reconstruct_times_blas(ce):
     # linearity: (2x) @ W == 2 (x @ W) exactly in fp16 (power-of-two scaling commutes with rounding)
     out2 = torch.empty_like(out)
     ce.exllama_ext.q4_matmul_gemm((x * 2).contiguous(), h, out2)
-    nbad = int((out2 != out * 2).sum())
+    normal = out.abs() >= 2.0 ** -13                               # fp16-subnormal outputs round on a coarser grid
+    nbad = int(((out2 != out * 2) & normal).sum())
     assert nbad == 0, f"{nbad} of {out.numel()} elements break exact linearity"
 
 
