@@ -51,10 +51,16 @@ __device__ __forceinline__ float block_sum_256(float v, float* red4, int tid)
 }
 
 // K1 / K4
+// Load order matters: the few L2-resident prologue loads (x, slabs) are issued BEFORE the 16 streaming weight loads
+// (loads retire in order, so anything queued behind the weight stream would wait for HBM), all in straight-line code
+// so that hipcc can wait with a counted vmcnt while the weights are still in flight.
+#define DEC_MAXS 4          // split-K slabs per consumer
+
+template <int DEC_NV>       // 8-half vectors per thread: hidden <= 2048 * DEC_NV
 __global__ __launch_bounds__(256) void dec_norm_gemv_kernel(const ANormArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    f16* xlin = (f16*) smem;                                  // [h]
+    f16* xlin = (f16*) smem;                                  // [h]   (act-order only)
     uint4* xs = (uint4*) (smem + (size_t) a.h * 2);           // [h / 8]
     float* red = (float*) (smem + (size_t) a.h * 4);          // [4 * GC_BN] (+4 for the norm reduction)
 
@@ -68,48 +74,79 @@ __global__ __launch_bounds__(256) void dec_norm_gemv_kernel(const ANormArgs a)
     const int col = tile * GC_BN + tx * 4;
     const bool col_ok = col < m.N;
 
-    // weights first: they do not depend on x
+    // ---- 1. prologue loads: residual stream + slabs (clamped addresses instead of branches) -----------------
+    const int nvec = a.h >> 3;
+    const f16* src = a.tok ? a.hid_in + (size_t) (*a.tok) * a.h : a.hid_in;
+    uint4 xraw[DEC_NV];
+    float4 sl[DEC_NV][DEC_MAXS][2];
+    const float* slab0 = a.slabs ? a.slabs : (const float*) src;       // never dereferenced as slabs when nslab == 0
+#pragma unroll
+    for (int i = 0; i < DEC_NV; ++i) {
+        const int idx = tid + i * 256;
+        const int ci = idx < nvec ? idx : 0;
+        if (i * 256 < nvec) {                                            // uniform per kernel
+            xraw[i] = *(const uint4*) (src + ci * 8);
+#pragma unroll
+            for (int s = 0; s < DEC_MAXS; ++s) {
+                if (s < a.nslab) {                                       // uniform per kernel
+                    sl[i][s][0] = *(const float4*) (slab0 + (size_t) s * a.h + ci * 8);
+                    sl[i][s][1] = *(const float4*) (slab0 + (size_t) s * a.h + ci * 8 + 4);
+                }
+            }
+        }
+    }
+    // ---- 2. weight stream ------------------------------------------------------------------------------------
     const GcPlan plan = gc_plan(0, m.K >> 3);
     uint4 wv[GC_MAXR];
     gc_issue(m, plan, 0, col, col_ok, ty, wv);
 
-    // ---- residual stream + RMSNorm -> xlin ---------------------------------------------------------------
-    const int nvec = a.h >> 3;
-    const f16* src = a.tok ? a.hid_in + (size_t) (*a.tok) * a.h : a.hid_in;
+    // ---- 3. residual add, RMSNorm -----------------------------------------------------------------------------
+    f16x8 xv[DEC_NV];
     float ss = 0.f;
-    for (int i = tid; i < nvec; i += 256) {
-        f16x8 v = *(const f16x8*) (src + i * 8);
-        if (a.slabs) {
-            float f[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = 0.f;
-            for (int s = 0; s < a.nslab; ++s) {
-                const float4 p0 = *(const float4*) (a.slabs + (size_t) s * a.h + i * 8);
-                const float4 p1 = *(const float4*) (a.slabs + (size_t) s * a.h + i * 8 + 4);
-                f[0] += p0.x; f[1] += p0.y; f[2] += p0.z; f[3] += p0.w;
-                f[4] += p1.x; f[5] += p1.y; f[6] += p1.z; f[7] += p1.w;
+    for (int i = 0; i < DEC_NV; ++i) {
+        const int idx = tid + i * 256;
+        if (i * 256 < nvec) {
+            f16x8 v = __builtin_bit_cast(f16x8, xraw[i]);
+            if (a.nslab > 0) {
+                float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < DEC_MAXS; ++s) {
+                    if (s < a.nslab) {
+                        f[0] += sl[i][s][0].x; f[1] += sl[i][s][0].y; f[2] += sl[i][s][0].z; f[3] += sl[i][s][0].w;
+                        f[4] += sl[i][s][1].x; f[5] += sl[i][s][1].y; f[6] += sl[i][s][1].z; f[7] += sl[i][s][1].w;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (f16) (f[j] + (float) v[j]);
             }
+            if (idx < nvec) {
+                if (blockIdx.x == 0 && a.hid_out) *(f16x8*) (a.hid_out + idx * 8) = v;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (f16) (f[j] + (float) v[j]);
+                for (int j = 0; j < 8; ++j) { const float f = (float) v[j]; ss = fmaf(f, f, ss); }
+            }
+            xv[i] = v;
         }
-        if (blockIdx.x == 0 && a.hid_out) *(f16x8*) (a.hid_out + i * 8) = v;
-        *(f16x8*) (xlin + i * 8) = v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float f = (float) v[j]; ss = fmaf(f, f, ss); }
     }
     const float total = block_sum_256(ss, red + 4 * GC_BN, tid);
     const f16 rm = (f16) (1.0f / sqrtf(total * (1.0f / (float) a.h) + a.eps));
-    for (int i = tid; i < nvec; i += 256) {
-        const f16x8 v = *(const f16x8*) (xlin + i * 8);
-        const f16x8 w = *(const f16x8*) (a.norm_w + i * 8);
-        f16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const f16 t = v[j] * rm; o[j] = t * w[j]; }
-        *(f16x8*) (xlin + i * 8) = o;                          // each thread rewrites only what it read
+    for (int i = 0; i < DEC_NV; ++i) {
+        const int idx = tid + i * 256;
+        if (i * 256 < nvec && idx < nvec) {
+            const f16x8 w = *(const f16x8*) (a.norm_w + idx * 8);
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const f16 t = xv[i][j] * rm; o[j] = t * w[j]; }
+            if (m.x_map) *(f16x8*) (xlin + idx * 8) = o;
+            else         xs[idx] = gc_permute(__builtin_bit_cast(uint4, o));
+        }
     }
     __syncthreads();
-    gc_stage_from_lds(xlin, m.x_map, 0, m.K >> 3, xs, tid);
-    __syncthreads();
+    if (m.x_map) {                                                       // act-order: gather through x_map
+        gc_stage_from_lds(xlin, m.x_map, 0, m.K >> 3, xs, tid);
+        __syncthreads();
+    }
 
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     gc_consume(m, plan, 0, col, col_ok, ty, wv, xs, acc);
@@ -182,21 +219,29 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
 #pragma unroll
     for (int j = 0; j < 8; ++j) qf[j] = (float) qr[j] * scale;
 
+    constexpr int UN = 8;                                       // key rows in flight per thread
     float mx = -INFINITY;
-    for (int j0 = 0; j0 < nkeys; j0 += KPI) {
-        const int j = j0 + ks;
-        float dot = 0.f;
-        if (j < nkeys) {
-            const int key = s0 + j;
-            const f16x8 kv = key == past ? kr : *(const f16x8*) (kbase + (size_t) key * HD);   // the new key never comes from memory
+    for (int j0 = 0; j0 < nkeys; j0 += KPI * UN) {
+        f16x8 kv[UN];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dot = fmaf(qf[e], (float) kv[e], dot);
+        for (int u = 0; u < UN; ++u) {
+            const int j = j0 + u * KPI + ks;
+            const int key = s0 + (j < nkeys ? j : 0);           // clamped: always a valid row
+            kv[u] = *(const f16x8*) (kbase + (size_t) key * HD);
+            if (key == past) kv[u] = kr;                        // the new key never comes from memory
         }
 #pragma unroll
-        for (int off = 1; off < LPK; off <<= 1) dot += __shfl_xor(dot, off, 64);
-        if (j < nkeys) {
-            if (d8 == 0) sc[j] = dot;
-            mx = fmaxf(mx, dot);
+        for (int u = 0; u < UN; ++u) {
+            const int j = j0 + u * KPI + ks;
+            float dot = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dot = fmaf(qf[e], (float) kv[u][e], dot);
+#pragma unroll
+            for (int off = 1; off < LPK; off <<= 1) dot += __shfl_xor(dot, off, 64);
+            if (j < nkeys) {
+                if (d8 == 0) sc[j] = dot;
+                mx = fmaxf(mx, dot);
+            }
         }
     }
 #pragma unroll
@@ -220,12 +265,22 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
-    for (int j = ks; j < nkeys; j += KPI) {
-        const int key = s0 + j;
-        const f16x8 vv = key == past ? vn : *(const f16x8*) (vbase + (size_t) key * HD);
-        const float p = sc[j];
+    for (int j0 = 0; j0 < nkeys; j0 += KPI * UN) {
+        f16x8 vv[UN];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = fmaf(p, (float) vv[e], o[e]);
+        for (int u = 0; u < UN; ++u) {
+            const int j = j0 + u * KPI + ks;
+            const int key = s0 + (j < nkeys ? j : 0);
+            vv[u] = *(const f16x8*) (vbase + (size_t) key * HD);
+            if (key == past) vv[u] = vn;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int j = j0 + u * KPI + ks;
+            const float p = j < nkeys ? sc[j] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(p, (float) vv[u][e], o[e]);
+        }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[ks][d8 * 8 + e] = o[e];
@@ -285,6 +340,9 @@ __device__ __forceinline__ f16 attn_merge_elem(const float* partial, int nsplit,
     return (f16) (o / l);
 }
 
+#define DEC_MAX_NSPLIT 8
+
+template <int FAST, int NG>  // FAST: 0 general path, 1 attention merge, 2 silu*mul; NG: 8-element groups per thread
 __global__ __launch_bounds__(256) void dec_vec_gemv_kernel(const BVecArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -301,47 +359,96 @@ __global__ __launch_bounds__(256) void dec_vec_gemv_kernel(const BVecArgs a)
     const int nrows = min(prow_total, r0 + a.prows_per_block) - r0;
     const GcPlan plan = gc_plan(r0, nrows);
     uint4 wv[GC_MAXR];
-    gc_issue(m, plan, 0, col, col_ok, ty, wv);
 
-    for (int idx = tid; idx < nrows; idx += 256) {
-        const int k0 = (r0 + idx) * 8;
-        f16x8 v;
-        if (!m.x_map && a.mode == 0) {
-            v = *(const f16x8*) (a.vec + k0);
-        } else if (!m.x_map && a.mode == 1) {
-            // 8 consecutive elements of one head: merge weights w_s = exp(m_s - M) / l computed once
-            const int head = k0 >> 7, d0 = k0 & 127;
-            const float* pp = a.partial + (size_t) head * a.nsplit * 130;
-            float M = -INFINITY;
-            for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, pp[s * 130 + 128]);
-            float l = 0.f;
-            float o[8];
+    // fast paths keep every prologue load ahead of the weight stream, in straight-line code (<= 2 groups per thread)
+    if constexpr (FAST == 2) {
+        uint4 gv[NG], uv[NG];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = 0.f;
-            for (int s = 0; s < a.nsplit; ++s) {
-                const float ms = pp[s * 130 + 128];
-                const float w = ms > -INFINITY ? __expf(ms - M) : 0.f;
-                l = fmaf(pp[s * 130 + 129], w, l);
-                const float2* po = (const float2*) (pp + s * 130 + d0);      // 130-float rows: 8-byte aligned only
+        for (int i = 0; i < NG; ++i) {
+            const int idx = tid + i * 256;
+            const int k0 = (r0 + (idx < nrows ? idx : 0)) * 8;
+            gv[i] = *(const uint4*) (a.g + k0);
+            uv[i] = *(const uint4*) (a.u + k0);
+        }
+        gc_issue(m, plan, 0, col, col_ok, ty, wv);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const float2 t = po[j]; o[2 * j] = fmaf(t.x, w, o[2 * j]); o[2 * j + 1] = fmaf(t.y, w, o[2 * j + 1]); }
-            }
-            const float inv = 1.0f / l;
+        for (int i = 0; i < NG; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < nrows) {
+                const f16x8 g8 = __builtin_bit_cast(f16x8, gv[i]);
+                const f16x8 u8 = __builtin_bit_cast(f16x8, uv[i]);
+                f16x8 v;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (f16) (o[j] * inv);
-        } else if (!m.x_map && a.mode == 2) {
-            const f16x8 gv = *(const f16x8*) (a.g + k0);
-            const f16x8 uv = *(const f16x8*) (a.u + k0);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = silu_mul_f16(gv[j], uv[j]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int e = m.x_map ? (int) m.x_map[k0 + j] : k0 + j;
-                v[j] = a.mode == 0 ? a.vec[e] : a.mode == 1 ? attn_merge_elem(a.partial, a.nsplit, e) : silu_mul_f16(a.g[e], a.u[e]);
+                for (int j = 0; j < 8; ++j) v[j] = silu_mul_f16(g8[j], u8[j]);
+                xs[idx] = gc_permute(__builtin_bit_cast(uint4, v));
             }
         }
-        xs[idx] = gc_permute(__builtin_bit_cast(uint4, v));
+    } else if constexpr (FAST == 1) {
+        // attention merge of 8 consecutive elements of one head per group
+        float ms[NG][DEC_MAX_NSPLIT], ls[NG][DEC_MAX_NSPLIT];
+        float2 po[NG][DEC_MAX_NSPLIT][4];
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int idx = tid + i * 256;
+            const int k0 = (r0 + (idx < nrows ? idx : 0)) * 8;
+            const float* pp = a.partial + (size_t) (k0 >> 7) * a.nsplit * 130;
+            const int d0 = k0 & 127;
+            if (i * 256 < nrows) {                              // block-uniform
+#pragma unroll
+                for (int sp = 0; sp < DEC_MAX_NSPLIT; ++sp) {
+                    const int cs = sp < a.nsplit ? sp : 0;
+                    ms[i][sp] = pp[cs * 130 + 128];
+                    ls[i][sp] = pp[cs * 130 + 129];
+                    const float2* q2 = (const float2*) (pp + cs * 130 + d0);     // 130-float rows: 8-byte aligned
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) po[i][sp][j] = q2[j];
+                }
+            }
+        }
+        gc_issue(m, plan, 0, col, col_ok, ty, wv);
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int idx = tid + i * 256;
+            if (i * 256 < nrows) {
+                float M = -INFINITY;
+#pragma unroll
+                for (int sp = 0; sp < DEC_MAX_NSPLIT; ++sp) if (sp < a.nsplit) M = fmaxf(M, ms[i][sp]);
+                float l = 0.f;
+                float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sp = 0; sp < DEC_MAX_NSPLIT; ++sp) {
+                    const float w = (sp < a.nsplit && ms[i][sp] > -INFINITY) ? __expf(ms[i][sp] - M) : 0.f;
+                    l = fmaf(ls[i][sp], w, l);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[2 * j] = fmaf(po[i][sp][j].x, w, o[2 * j]);
+                        o[2 * j + 1] = fmaf(po[i][sp][j].y, w, o[2 * j + 1]);
+                    }
+                }
+                const float inv = 1.0f / l;
+                f16x8 v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (f16) (o[j] * inv);
+                if (idx < nrows) xs[idx] = gc_permute(__builtin_bit_cast(uint4, v));
+            }
+        }
+    } else {
+        // general path (act-order gather, plain vectors, long K ranges): activation first, then the weights
+        for (int idx = tid; idx < nrows; idx += 256) {
+            const int k0 = (r0 + idx) * 8;
+            f16x8 v;
+            if (!m.x_map && a.mode == 0) {
+                v = *(const f16x8*) (a.vec + k0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = m.x_map ? (int) m.x_map[k0 + j] : k0 + j;
+                    v[j] = a.mode == 0 ? a.vec[e] : a.mode == 1 ? attn_merge_elem(a.partial, a.nsplit, e) : silu_mul_f16(a.g[e], a.u[e]);
+                }
+            }
+            xs[idx] = gc_permute(__builtin_bit_cast(uint4, v));
+        }
+        gc_issue(m, plan, 0, col, col_ok, ty, wv);
     }
     __syncthreads();
 
@@ -457,7 +564,7 @@ static void pick_splitk(int K, int N, int* splitk, int* prows)
     const int prow_total = K / 8;
     const int tiles = (N + GC_BN - 1) / GC_BN;
     int sk = (512 + tiles - 1) / tiles;
-    if (sk > 8) sk = 8;
+    if (sk > DEC_MAXS) sk = DEC_MAXS;
     while (sk > 1 && prow_total / sk < 64) --sk;
     int pr = (prow_total + sk - 1) / sk;
     pr = (pr + 3) & ~3;
@@ -487,6 +594,7 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     pick_splitk(inter, hidden, &d->splitk_d, &d->prows_d);
     int ns = 256 / heads;
     if (ns < 1) ns = 1;
+    if (ns > DEC_MAX_NSPLIT) ns = DEC_MAX_NSPLIT;
     while ((max_seq_len + ns - 1) / ns + 16 > DEC_ATT_MAX_KEYS) ++ns;
     d->nsplit = ns;
     const int kvd = kv_heads * head_dim;
@@ -574,7 +682,10 @@ static int launch_norm_gemv(const Decoder* d, const f16* hid_in, const int64_t* 
         a.tile_end[i] = tiles;
     }
     const size_t smem = (size_t) d->h * 4 + (4 * GC_BN + 8) * sizeof(float);
-    hipLaunchKernelGGL(dec_norm_gemv_kernel, dim3(tiles), dim3(256), smem, s, a);
+    const int nv = (d->h / 8 + 255) / 256;
+    if (nv <= 2)      hipLaunchKernelGGL(dec_norm_gemv_kernel<2>, dim3(tiles), dim3(256), smem, s, a);
+    else if (nv <= 3) hipLaunchKernelGGL(dec_norm_gemv_kernel<3>, dim3(tiles), dim3(256), smem, s, a);
+    else              hipLaunchKernelGGL(dec_norm_gemv_kernel<4>, dim3(tiles), dim3(256), smem, s, a);
     EXL_LAUNCH_CHECK();
     return 0;
 }
@@ -587,7 +698,12 @@ static int launch_vec_gemv(int mode, const f16* vec, const float* partial, int n
     a.mat = gc_view(m); a.slabs = slabs; a.prows_per_block = prows;
     const size_t smem = (size_t) prows * 16 + 4 * GC_BN * sizeof(float);
     dim3 grid((m->width + GC_BN - 1) / GC_BN, splitk);
-    hipLaunchKernelGGL(dec_vec_gemv_kernel, grid, dim3(256), smem, s, a);
+    const bool fast = !m->x_map && prows <= 512 && (mode == 2 || (mode == 1 && nsplit <= DEC_MAX_NSPLIT));
+    if (!fast)                      hipLaunchKernelGGL((dec_vec_gemv_kernel<0, 1>), grid, dim3(256), smem, s, a);
+    else if (mode == 1 && prows <= 256) hipLaunchKernelGGL((dec_vec_gemv_kernel<1, 1>), grid, dim3(256), smem, s, a);
+    else if (mode == 1)             hipLaunchKernelGGL((dec_vec_gemv_kernel<1, 2>), grid, dim3(256), smem, s, a);
+    else if (prows <= 256)          hipLaunchKernelGGL((dec_vec_gemv_kernel<2, 1>), grid, dim3(256), smem, s, a);
+    else                            hipLaunchKernelGGL((dec_vec_gemv_kernel<2, 2>), grid, dim3(256), smem, s, a);
     EXL_LAUNCH_CHECK();
     return 0;
 }
