@@ -55,32 +55,34 @@ struct GcMatrix {                   // device-visible view of a Q4Matrix
 // [pass * GC_TY * rpt + ty * rpt, +rpt) of the block range.
 struct GcPlan { int r0, nrows, rpt, npass; };
 
-__device__ __forceinline__ GcPlan gc_plan(int r0, int nrows)
+__device__ __forceinline__ GcPlan gc_plan(int r0, int nrows, int maxr = GC_MAXR)
 {
     GcPlan p;
     p.r0 = r0;
     p.nrows = nrows;
-    p.npass = (nrows + GC_TY * GC_MAXR - 1) / (GC_TY * GC_MAXR);
+    p.npass = (nrows + GC_TY * maxr - 1) / (GC_TY * maxr);
     p.rpt = (nrows + GC_TY * p.npass - 1) / (GC_TY * p.npass);
     return p;
 }
 
+template <int MAXR>
 __device__ __forceinline__ void gc_issue(const GcMatrix& m, const GcPlan& p, int pass, int col, bool col_ok, int ty,
-                                         uint4 (&wv)[GC_MAXR])
+                                         uint4 (&wv)[MAXR])
 {
     const uint4* wcol = (const uint4*) m.qweight + (col >> 2);
     const int n4 = m.N >> 2;
     const int c0 = (pass * GC_TY + ty) * p.rpt;
 #pragma unroll
-    for (int i = 0; i < GC_MAXR; ++i) {
+    for (int i = 0; i < MAXR; ++i) {
         const int rr = c0 + i;
         wv[i] = (col_ok && i < p.rpt && rr < p.nrows) ? nt_load16(wcol + (size_t) (p.r0 + rr) * n4) : make_uint4(0, 0, 0, 0);
     }
 }
 
 // xs: LDS, permuted 8-half groups, index = packed row relative to the block's r0
+template <int MAXR>
 __device__ __forceinline__ void gc_consume(const GcMatrix& m, const GcPlan& p, int pass, int col, bool col_ok, int ty,
-                                           const uint4 (&wv)[GC_MAXR], const uint4* xs, float (&acc)[4])
+                                           const uint4 (&wv)[MAXR], const uint4* xs, float (&acc)[4])
 {
     const int c0 = (pass * GC_TY + ty) * p.rpt;
     if (c0 >= p.nrows) return;
@@ -115,7 +117,7 @@ __device__ __forceinline__ void gc_consume(const GcMatrix& m, const GcPlan& p, i
     };
     load_group(g);
 #pragma unroll
-    for (int i = 0; i < GC_MAXR; ++i) {
+    for (int i = 0; i < MAXR; ++i) {
         const int rr = c0 + i;
         if (i < p.rpt && rr < p.nrows) {
             if (until == 0) { flush_group(); ++g; load_group(g); until = gprows; }
