@@ -31,6 +31,7 @@ SIGNATURES = {
     "exl_make_q4": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(c_void_p)]),
     "exl_free_q4": (c_int, [c_void_p]),
     "exl_q4_info": (c_int, [c_void_p] + [C.POINTER(c_int)] * 5 + [C.POINTER(c_void_p)]),
+    "exl_q4_layout": (c_int, [c_void_p, C.POINTER(c_int)]),
     "exl_q4_matmul": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "exl_q4_matmul_gemv": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "exl_q4_matmul_gemm": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),

@@ -85,6 +85,14 @@ extern "C" int exl_prepare_buffers(int device, void* temp_state, size_t temp_sta
     return ensure_workspace(device);
 }
 
+struct DeviceGuard {
+    int prev; bool ok;
+    explicit DeviceGuard(int d) : prev(0), ok(false) {
+        if (hipGetDevice(&prev) == hipSuccess && (prev == d || hipSetDevice(d) == hipSuccess)) ok = true;
+    }
+    ~DeviceGuard() { int cur = 0; if (ok && hipGetDevice(&cur) == hipSuccess && cur != prev) (void) hipSetDevice(prev); }
+};
+
 // ---- Q4 handles -----------------------------------------------------------------------------------------
 static std::vector<Q4Matrix*> g_matrices;
 static std::unordered_set<void*> g_live;
@@ -155,6 +163,7 @@ extern "C" int exl_make_q4(int device, int height, int width, int groups, uint32
     m->qzeros = qzeros;
     m->scales = (f16*) scales;
     m->x_map = nullptr;
+    m->layout = EXL_LAYOUT_GPTQ;
 
     if (g_idx_host) {
         // stable counting sort of rows by group -> x_map (new row -> old row); integer-exact restatement of
@@ -173,6 +182,14 @@ extern "C" int exl_make_q4(int device, int height, int width, int groups, uint32
         const int r = launch_make_sequential(m, x_map.data(), (hipStream_t) stream);
         (void) hipSetDevice(prev);
         if (r) { delete m; return r; }
+    }
+    // Re-tile the packed weights in place into the streaming layout of the decode / prefill kernels (gemv_t16.h).
+    // Needs whole 16-row blocks and 16-column tiles and groups that are whole 4-row pieces; every Llama shape qualifies.
+    if (height % 128 == 0 && width % 16 == 0 && groupsize % 32 == 0) {
+        DeviceGuard guard(device);
+        if (!guard.ok) { free_matrix(m); EXL_FAIL(EXL_E_INVALID, "make_q4: cannot select device %d", device); }
+        const int r = launch_retile_t16(m, (hipStream_t) stream);
+        if (r) { free_matrix(m); return r; }
     }
     g_matrices.push_back(m);
     g_live.insert(m);
@@ -205,14 +222,15 @@ extern "C" int exl_q4_info(void* handle, int* device, int* height, int* width, i
     return 0;
 }
 
+extern "C" int exl_q4_layout(void* handle, int* layout)
+{
+    Q4Matrix* m = q4_from_handle(handle);
+    EXL_REQUIRE(m && layout, EXL_E_INVALID, "q4_layout: invalid handle");
+    *layout = m->layout;
+    return 0;
+}
+
 // ---- q4 matmul ------------------------------------------------------------------------------------------
-struct DeviceGuard {
-    int prev; bool ok;
-    explicit DeviceGuard(int d) : prev(0), ok(false) {
-        if (hipGetDevice(&prev) == hipSuccess && (prev == d || hipSetDevice(d) == hipSuccess)) ok = true;
-    }
-    ~DeviceGuard() { int cur = 0; if (ok && hipGetDevice(&cur) == hipSuccess && cur != prev) (void) hipSetDevice(prev); }
-};
 
 static int q4_gemv(Q4Matrix* m, const void* x, int rows, void* out, int no_zero, hipStream_t s)
 {

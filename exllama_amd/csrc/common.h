@@ -46,11 +46,14 @@ struct Q4Matrix {
     int width;         // N
     int groups;
     int groupsize;
-    uint32_t* qweight; // borrowed [K/8, N]
+    uint32_t* qweight; // borrowed; layout 0: GPTQ [K/8, N]; layout 1: T16 pieces (gemv_t16.h), re-tiled IN PLACE by make_q4
     uint32_t* qzeros;  // borrowed [G, N/8]
     f16* scales;       // borrowed [G, N]
     uint32_t* x_map;   // owned   [K] or NULL (act-order)
+    int layout;        // EXL_LAYOUT_GPTQ or EXL_LAYOUT_T16
 };
+#define EXL_LAYOUT_GPTQ 0   // as loaded; kept only for shapes the T16 tiling cannot express (K % 128 or N % 16 != 0)
+#define EXL_LAYOUT_T16  1   // the product layout
 #define EXL_Q4_MAGIC 0x51344d58u
 
 // Looks the pointer up in the registry of live handles (never dereferences an unknown pointer).
@@ -71,6 +74,7 @@ extern ExlTuning g_tuning;
 
 // ---- launchers implemented in the .hip files -----------------------------------------------------------
 int launch_make_sequential(Q4Matrix* m, const uint32_t* x_map_host, hipStream_t s);
+int launch_retile_t16(Q4Matrix* m, hipStream_t s);            // GPTQ -> T16 in place (through a temporary copy); sets m->layout
 int launch_reconstruct(const Q4Matrix* m, f16* out, hipStream_t s);
 int launch_column_remap(const f16* x, f16* x_new, int height, int width, const uint32_t* x_map, hipStream_t s);
 

@@ -1,163 +1,175 @@
 // Native single-token decode executor: one C call (capturable into one hipGraph) runs a whole Llama token step
-// as 5 kernels per layer + 1 head kernel, instead of the ~20 launches per layer of the op-by-op path.
+// as 6 kernels per layer + 1 head kernel, instead of the ~20 launches per layer of the op-by-op path.
 //
 // It is the MI355X answer to the reference's decode loop (/root/reference/model.py:1053-1058 driving
 // q4_attn -> ATen attention -> q4_attn_2 -> q4_mlp, i.e. q4_attn.cu:74-228 + q4_mlp.cu:100-199 + model.py:376-409):
 // same arithmetic contract per op (fp16 values at the same points: normed x, q/k/v,
 // attention output, gate/up, activation, residual stream), different decomposition:
 //
-//   K1 norm_gemv   x = h(hid + sum(down slabs of the previous layer)) [layer 0: the embedding row];
-//                  RMSNorm in LDS; q, k, v projections as ONE launch over the three matrices (fp16 out)
-//   K2 attn        RoPE(q), RoPE(k_new) in registers, k_new/v_new appended to the cache, split-KV attention
-//                  over the cache -> fp32 partials (o, m, l) per (head, split)
-//   K3 vec_gemv    merges the attention partials while staging its activation slice, o_proj split-K -> fp32 slabs
-//   K4 norm_gemv   x = h(hid + sum(o slabs)); RMSNorm; gate and up projections as one launch (fp16 out)
-//   K5 vec_gemv    silu(g) * u computed while staging, down_proj split-K -> fp32 slabs
-//   K6 head        x = h(hid + sum(down slabs)); final RMSNorm; fp16 lm_head GEMV -> fp32 logits; advances the position
+//   K1 qkv      RMSNorm(hid) [layer 0: the embedding row] staged in LDS; q, k, v projections as ONE launch over the
+//               three matrices -> fp16 q/k/v
+//   K2 attn     RoPE(q), RoPE(k_new) in registers, k_new/v_new appended to the cache, split-KV attention over the
+//               cache -> fp32 partials (o, m, l) per (head, split)
+//   K2b merge   log-sum-exp merge of the partials -> fp16 attention output
+//   K3 o_proj   hid += attn_out @ Wo      (residual added in the epilogue, fp16 residual stream updated in place)
+//   K4 gate_up  RMSNorm(hid); one block computes the SAME 16 columns of gate and up -> act = silu(gate) * up (fp16)
+//   K5 down     hid += act @ Wdown
+//   K6 head     final RMSNorm; fp16 lm_head GEMV -> fp32 logits; advances the device-side position
 //
-// Split-K partial sums are never combined with atomics: each consumer adds the slabs in a fixed order in its
-// prologue ("launch-boundary reduce"), so the result is bit-reproducible.  The position is read from device
-// memory, so one captured graph serves every context length.
-#include "gemv_core.h"
+// Every GEMV block streams one contiguous 16-column weight tile over the FULL K range (T16 layout, gemv_t16.h), so
+// there is no split-K, no partial-sum slab, no atomics: results are bit-reproducible run to run.  The position is
+// read from device memory, so one captured graph serves every context length.
+#include "gemv_t16.h"
 
 #include <vector>
 
 #define DEC_MAX_MATS 3
 #define DEC_ATT_MAX_KEYS 1024
+#define DEC_WAVES 8
+#define DEC_THREADS (DEC_WAVES * 64)
 
-struct ANormArgs {
-    // source of the residual stream
-    const f16* hid_in;            // [h] or the embedding table when tok != NULL
-    const int64_t* tok;           // token id (layer 0) or NULL
-    const float* slabs;           // [nslab][h] fp32 partial sums to add, or NULL
-    int nslab;
-    f16* hid_out;                 // written by block 0 (may alias nothing that is read in this launch)
-    const f16* norm_w;
+T16Matrix t16_view(const Q4Matrix* m);          // q4_gemv.hip
+
+struct DecGemvArgs {
+    // ---- prologue: the activation vector of length K staged in LDS ----
+    const f16* vec;               // PNORM 0: plain fp16 [K];  PNORM 1: residual stream [h] (or the embedding table when tok)
+    const int64_t* tok;           // PNORM 1, layer 0: token id (device)
+    const f16* norm_w;            // PNORM 1
     float eps;
-    int h;
+    f16* hid_copy;                // PNORM 1 with tok: block 0 stores the embedding row here (start of the residual stream)
+    // ---- matrices; 16-column tiles are numbered across them in order ----
     int nmat;
-    GcMatrix mat[DEC_MAX_MATS];
-    f16* out[DEC_MAX_MATS];
-    int tile_end[DEC_MAX_MATS];   // cumulative 32-column tile counts
+    T16Matrix mat[DEC_MAX_MATS];
+    int tile_end[DEC_MAX_MATS];   // cumulative tile counts (EMODE 2: tiles of mat[0]; mat[1] is walked in lock-step)
+    // ---- epilogue ----
+    f16* out[DEC_MAX_MATS];       // EMODE 0: out[mi][n] = h(y);  EMODE 2: out[0][n] = silu(h(y_gate)) * h(y_up)
+    f16* hid_io;                  // EMODE 1: hid_io[n] = h(hid_io[n] + y)
+    int rb_per_wave;
+    int xs_images;                // 1, or 2 when gate and up carry different act-order maps (EMODE 2)
 };
 
-__device__ __forceinline__ float block_sum_256(float v, float* red4, int tid)
+__device__ __forceinline__ f16 silu_mul_f16(f16 x, f16 y)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if ((tid & 63) == 0) red4[tid >> 6] = v;
-    __syncthreads();
-    return red4[0] + red4[1] + red4[2] + red4[3];
+    const f16 e = (f16) __expf((float) (f16) (-x));
+    const f16 sm = (f16) 1.0f + e;
+    const f16 rc = (f16) (1.0f / (float) sm);
+    const f16 v = x * rc;
+    return v * y;
 }
 
-// K1 / K4
-// Load order matters: the few L2-resident prologue loads (x, slabs) are issued BEFORE the 16 streaming weight loads
-// (loads retire in order, so anything queued behind the weight stream would wait for HBM), all in straight-line code
-// so that hipcc can wait with a counted vmcnt while the weights are still in flight.
-#define DEC_MAXS 4          // split-K slabs per consumer
-
-template <int DEC_NV>       // 8-half vectors per thread: hidden <= 2048 * DEC_NV
-__global__ __launch_bounds__(256) void dec_norm_gemv_kernel(const ANormArgs a)
+// PNORM: 0 plain vector, 1 RMSNorm(residual stream).  EMODE: 0 store fp16, 1 residual add, 2 silu(gate) * up pair.
+// NV = 8-half vectors of the activation per thread (K <= 4096 * NV).
+// Load order matters: the small L2-resident prologue loads (x, norm weight, scale/zero entries) are issued BEFORE the
+// streaming weight loads (loads return in order), and the weight loads are in flight while the block builds its
+// activation image in LDS.
+template <int U, int NP, bool G16, int PNORM, int EMODE, int NV>
+__global__ __launch_bounds__(DEC_THREADS) void dec_gemv_kernel(const DecGemvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    f16* xlin = (f16*) smem;                                  // [h]   (act-order only)
-    uint4* xs = (uint4*) (smem + (size_t) a.h * 2);           // [h / 8]
-    float* red = (float*) (smem + (size_t) a.h * 4);          // [4 * GC_BN] (+4 for the norm reduction)
+    const int K = a.mat[0].K, R = a.mat[0].R;
+    uint4* xs = (uint4*) smem;                                       // [xs_images][R]
+    float* red = (float*) (smem + (size_t) a.xs_images * R * 16);    // [DEC_WAVES][16] + [DEC_WAVES]
+    f16* xlin = (f16*) (smem + (size_t) a.xs_images * R * 16 + (DEC_WAVES * 16 + DEC_WAVES) * sizeof(float));   // [K], act-order only
 
-    const int tid = threadIdx.x;
-    const int tx = tid % GC_TX, ty = tid / GC_TX;
-    int mi = 0, tile = blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int b = blockIdx.x;
+    if ((gridDim.x & 7) == 0) { const int per = gridDim.x >> 3; b = (b & 7) * per + (b >> 3); }   // neighbours share an XCD L2
+    int mi = 0, tile = b;
+    constexpr int WPT = EMODE == 2 ? DEC_WAVES / 2 : DEC_WAVES;      // waves per tile
+    if constexpr (EMODE == 2) {
+        mi = wave / WPT;                                             // waves 0-3: gate tile b, waves 4-7: up tile b
+    } else {
 #pragma unroll
-    for (int i = 0; i < DEC_MAX_MATS - 1; ++i)
-        if (mi == i && i + 1 < a.nmat && (int) blockIdx.x >= a.tile_end[i]) { mi = i + 1; tile = blockIdx.x - a.tile_end[i]; }
-    const GcMatrix& m = a.mat[mi];
-    const int col = tile * GC_BN + tx * 4;
-    const bool col_ok = col < m.N;
+        for (int i = 0; i < DEC_MAX_MATS - 1; ++i)
+            if (mi == i && i + 1 < a.nmat && b >= a.tile_end[i]) { mi = i + 1; tile = b - a.tile_end[i]; }
+    }
+    const T16Matrix& m = a.mat[mi];
 
-    // ---- 1. prologue loads: residual stream + slabs (clamped addresses instead of branches) -----------------
-    const int nvec = a.h >> 3;
-    const f16* src = a.tok ? a.hid_in + (size_t) (*a.tok) * a.h : a.hid_in;
-    uint4 xraw[DEC_NV];
-    float4 sl[DEC_NV][DEC_MAXS][2];
-    const float* slab0 = a.slabs ? a.slabs : (const float*) src;       // never dereferenced as slabs when nslab == 0
+    // ---- 1. prologue loads ------------------------------------------------------------------------------------
+    const int nvec = K >> 3;
+    const f16* src = a.vec;
+    if constexpr (PNORM == 1) { if (a.tok) src = a.vec + (size_t) (*a.tok) * K; }
+    uint4 xraw[NV], wraw[NV];
 #pragma unroll
-    for (int i = 0; i < DEC_NV; ++i) {
-        const int idx = tid + i * 256;
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * DEC_THREADS;
         const int ci = idx < nvec ? idx : 0;
-        if (i * 256 < nvec) {                                            // uniform per kernel
-            xraw[i] = *(const uint4*) (src + ci * 8);
-#pragma unroll
-            for (int s = 0; s < DEC_MAXS; ++s) {
-                if (s < a.nslab) {                                       // uniform per kernel
-                    sl[i][s][0] = *(const float4*) (slab0 + (size_t) s * a.h + ci * 8);
-                    sl[i][s][1] = *(const float4*) (slab0 + (size_t) s * a.h + ci * 8 + 4);
-                }
-            }
-        }
+        xraw[i] = *(const uint4*) (src + ci * 8);
+        if constexpr (PNORM == 1) wraw[i] = *(const uint4*) (a.norm_w + ci * 8);
     }
-    // ---- 2. weight stream ------------------------------------------------------------------------------------
-    const GcPlan plan = gc_plan(0, m.K >> 3);
-    uint4 wv[GC_MAXR];
-    gc_issue(m, plan, 0, col, col_ok, ty, wv);
+    // ---- 2. weight stream -------------------------------------------------------------------------------------
+    T16Wave<U, NP, G16> w;
+    const int rb0 = (wave % WPT) * a.rb_per_wave;
+    w.init(m, tile, lane, rb0, min(m.RB, rb0 + a.rb_per_wave));
+    w.load_entries(m);
+    w.issue(m, 0);
 
-    // ---- 3. residual add, RMSNorm -----------------------------------------------------------------------------
-    f16x8 xv[DEC_NV];
-    float ss = 0.f;
+    // ---- 3. activation image --------------------------------------------------------------------------------
+    f16x8 xv[NV];
+    if constexpr (PNORM == 1) {
+        float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < DEC_NV; ++i) {
-        const int idx = tid + i * 256;
-        if (i * 256 < nvec) {
-            f16x8 v = __builtin_bit_cast(f16x8, xraw[i]);
-            if (a.nslab > 0) {
-                float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < DEC_MAXS; ++s) {
-                    if (s < a.nslab) {
-                        f[0] += sl[i][s][0].x; f[1] += sl[i][s][0].y; f[2] += sl[i][s][0].z; f[3] += sl[i][s][0].w;
-                        f[4] += sl[i][s][1].x; f[5] += sl[i][s][1].y; f[6] += sl[i][s][1].z; f[7] += sl[i][s][1].w;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (f16) (f[j] + (float) v[j]);
-            }
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * DEC_THREADS;
+            xv[i] = __builtin_bit_cast(f16x8, xraw[i]);
             if (idx < nvec) {
-                if (blockIdx.x == 0 && a.hid_out) *(f16x8*) (a.hid_out + idx * 8) = v;
+                if (a.tok && a.hid_copy && blockIdx.x == 0) *(f16x8*) (a.hid_copy + idx * 8) = xv[i];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float f = (float) v[j]; ss = fmaf(f, f, ss); }
+                for (int j = 0; j < 8; ++j) { const float f = (float) xv[i][j]; ss = fmaf(f, f, ss); }
             }
-            xv[i] = v;
         }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+        if (lane == 0) red[DEC_WAVES * 16 + wave] = ss;
+        __syncthreads();
+        float total = 0.f;
+#pragma unroll
+        for (int i = 0; i < DEC_WAVES; ++i) total += red[DEC_WAVES * 16 + i];
+        const f16 rm = (f16) (1.0f / sqrtf(total * (1.0f / (float) K) + a.eps));
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const f16x8 nw = __builtin_bit_cast(f16x8, wraw[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const f16 t = xv[i][j] * rm; xv[i][j] = t * nw[j]; }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) xv[i] = __builtin_bit_cast(f16x8, xraw[i]);
     }
-    const float total = block_sum_256(ss, red + 4 * GC_BN, tid);
-    const f16 rm = (f16) (1.0f / sqrtf(total * (1.0f / (float) a.h) + a.eps));
 #pragma unroll
-    for (int i = 0; i < DEC_NV; ++i) {
-        const int idx = tid + i * 256;
-        if (i * 256 < nvec && idx < nvec) {
-            const f16x8 w = *(const f16x8*) (a.norm_w + idx * 8);
-            f16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const f16 t = xv[i][j] * rm; o[j] = t * w[j]; }
-            if (m.x_map) *(f16x8*) (xlin + idx * 8) = o;
-            else         xs[idx] = gc_permute(__builtin_bit_cast(uint4, o));
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * DEC_THREADS;
+        if (idx < nvec) {
+            if (m.x_map) *(f16x8*) (xlin + idx * 8) = xv[i];
+            else         xs[idx] = t16_permute(__builtin_bit_cast(uint4, xv[i]));
         }
     }
     __syncthreads();
-    if (m.x_map) {                                                       // act-order: gather through x_map
-        gc_stage_from_lds(xlin, m.x_map, 0, m.K >> 3, xs, tid);
+    if (m.x_map) {                                                   // act-order: gather through this matrix' x_map
+        if (a.xs_images > 1) xs += (size_t) mi * R;                  // gate and up permute k differently: one image each
+        t16_stage_from_lds(xlin, m.x_map, R, xs, tid % (WPT * 64), WPT * 64);
         __syncthreads();
     }
 
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    gc_consume(m, plan, 0, col, col_ok, ty, wv, xs, acc);
-    for (int pass = 1; pass < plan.npass; ++pass) {
-        gc_issue(m, plan, pass, col, col_ok, ty, wv);
-        gc_consume(m, plan, pass, col, col_ok, ty, wv, xs, acc);
-    }
-    const float v = gc_block_reduce(acc, red, tid);
-    if (tid < GC_BN) {
-        const int n = tile * GC_BN + tid;
-        if (n < m.N) a.out[mi][n] = (f16) v;
+    // ---- 4. stream, dot, reduce -----------------------------------------------------------------------------
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    w.run(m, xs, c);
+    if (lane < 16) red[wave * 16 + lane] = c[0];
+    __syncthreads();
+    if (tid < 16) {
+        const int n = tile * 16 + tid;
+        if constexpr (EMODE == 2) {
+            float g = 0.f, u = 0.f;
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) { g += red[i * 16 + tid]; u += red[(WPT + i) * 16 + tid]; }
+            a.out[0][n] = silu_mul_f16((f16) g, (f16) u);
+        } else {
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < DEC_WAVES; ++i) v += red[i * 16 + tid];
+            if constexpr (EMODE == 0) a.out[mi][n] = (f16) v;
+            else a.hid_io[n] = (f16) (v + (float) a.hid_io[n]);
+        }
     }
 }
 
@@ -299,33 +311,13 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// K3 / K5: activation built on the fly (attention merge | silu*mul | plain vector) -> split-K GEMV -> fp32 slabs
+// K2b: merge the split-KV partials of one head -> fp16 attention output (the value the reference's ATen attention
+// rounds to fp16 before o_proj, model.py:407-409)
 // ---------------------------------------------------------------------------------------------------------------
-struct BVecArgs {
-    int mode;                     // 0: plain fp16 vector, 1: attention partial merge, 2: silu(g) * u
-    const f16* vec;               // mode 0
-    const float* partial;         // mode 1: [heads][nsplit][130]
-    int nsplit;
-    const f16* g;                 // mode 2
-    const f16* u;
-    GcMatrix mat;
-    float* slabs;                 // [splitk][N]
-    int prows_per_block;
-};
-
-__device__ __forceinline__ f16 silu_mul_f16(f16 x, f16 y)
+__global__ __launch_bounds__(128) void dec_attn_merge_kernel(const float* __restrict__ partial, f16* __restrict__ out, int nsplit)
 {
-    const f16 e = (f16) __expf((float) (f16) (-x));
-    const f16 sm = (f16) 1.0f + e;
-    const f16 rc = (f16) (1.0f / (float) sm);
-    const f16 v = x * rc;
-    return v * y;
-}
-
-__device__ __forceinline__ f16 attn_merge_elem(const float* partial, int nsplit, int e)
-{
-    const int head = e >> 7, d = e & 127;
-    const float* pp = partial + (size_t) head * nsplit * 130;
+    const int h = blockIdx.x, d = threadIdx.x;
+    const float* pp = partial + (size_t) h * nsplit * 130;
     float M = -INFINITY;
     for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pp[s * 130 + 128]);
     float l = 0.f, o = 0.f;
@@ -337,139 +329,13 @@ __device__ __forceinline__ f16 attn_merge_elem(const float* partial, int nsplit,
             o = fmaf(pp[s * 130 + d], w, o);
         }
     }
-    return (f16) (o / l);
-}
-
-#define DEC_MAX_NSPLIT 8
-
-template <int FAST, int NG>  // FAST: 0 general path, 1 attention merge, 2 silu*mul; NG: 8-element groups per thread
-__global__ __launch_bounds__(256) void dec_vec_gemv_kernel(const BVecArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint4* xs = (uint4*) smem;                                // [prows_per_block]
-    float* red = (float*) (smem + (size_t) a.prows_per_block * 16);
-
-    const int tid = threadIdx.x;
-    const int tx = tid % GC_TX, ty = tid / GC_TX;
-    const GcMatrix& m = a.mat;
-    const int col = blockIdx.x * GC_BN + tx * 4;
-    const bool col_ok = col < m.N;
-    const int prow_total = m.K >> 3;
-    const int r0 = blockIdx.y * a.prows_per_block;
-    const int nrows = min(prow_total, r0 + a.prows_per_block) - r0;
-    const GcPlan plan = gc_plan(r0, nrows);
-    uint4 wv[GC_MAXR];
-
-    // fast paths keep every prologue load ahead of the weight stream, in straight-line code (<= 2 groups per thread)
-    if constexpr (FAST == 2) {
-        uint4 gv[NG], uv[NG];
-#pragma unroll
-        for (int i = 0; i < NG; ++i) {
-            const int idx = tid + i * 256;
-            const int k0 = (r0 + (idx < nrows ? idx : 0)) * 8;
-            gv[i] = *(const uint4*) (a.g + k0);
-            uv[i] = *(const uint4*) (a.u + k0);
-        }
-        gc_issue(m, plan, 0, col, col_ok, ty, wv);
-#pragma unroll
-        for (int i = 0; i < NG; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < nrows) {
-                const f16x8 g8 = __builtin_bit_cast(f16x8, gv[i]);
-                const f16x8 u8 = __builtin_bit_cast(f16x8, uv[i]);
-                f16x8 v;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = silu_mul_f16(g8[j], u8[j]);
-                xs[idx] = gc_permute(__builtin_bit_cast(uint4, v));
-            }
-        }
-    } else if constexpr (FAST == 1) {
-        // attention merge of 8 consecutive elements of one head per group
-        float ms[NG][DEC_MAX_NSPLIT], ls[NG][DEC_MAX_NSPLIT];
-        float2 po[NG][DEC_MAX_NSPLIT][4];
-#pragma unroll
-        for (int i = 0; i < NG; ++i) {
-            const int idx = tid + i * 256;
-            const int k0 = (r0 + (idx < nrows ? idx : 0)) * 8;
-            const float* pp = a.partial + (size_t) (k0 >> 7) * a.nsplit * 130;
-            const int d0 = k0 & 127;
-            if (i * 256 < nrows) {                              // block-uniform
-#pragma unroll
-                for (int sp = 0; sp < DEC_MAX_NSPLIT; ++sp) {
-                    const int cs = sp < a.nsplit ? sp : 0;
-                    ms[i][sp] = pp[cs * 130 + 128];
-                    ls[i][sp] = pp[cs * 130 + 129];
-                    const float2* q2 = (const float2*) (pp + cs * 130 + d0);     // 130-float rows: 8-byte aligned
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) po[i][sp][j] = q2[j];
-                }
-            }
-        }
-        gc_issue(m, plan, 0, col, col_ok, ty, wv);
-#pragma unroll
-        for (int i = 0; i < NG; ++i) {
-            const int idx = tid + i * 256;
-            if (i * 256 < nrows) {
-                float M = -INFINITY;
-#pragma unroll
-                for (int sp = 0; sp < DEC_MAX_NSPLIT; ++sp) if (sp < a.nsplit) M = fmaxf(M, ms[i][sp]);
-                float l = 0.f;
-                float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int sp = 0; sp < DEC_MAX_NSPLIT; ++sp) {
-                    const float w = (sp < a.nsplit && ms[i][sp] > -INFINITY) ? __expf(ms[i][sp] - M) : 0.f;
-                    l = fmaf(ls[i][sp], w, l);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        o[2 * j] = fmaf(po[i][sp][j].x, w, o[2 * j]);
-                        o[2 * j + 1] = fmaf(po[i][sp][j].y, w, o[2 * j + 1]);
-                    }
-                }
-                const float inv = 1.0f / l;
-                f16x8 v;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (f16) (o[j] * inv);
-                if (idx < nrows) xs[idx] = gc_permute(__builtin_bit_cast(uint4, v));
-            }
-        }
-    } else {
-        // general path (act-order gather, plain vectors, long K ranges): activation first, then the weights
-        for (int idx = tid; idx < nrows; idx += 256) {
-            const int k0 = (r0 + idx) * 8;
-            f16x8 v;
-            if (!m.x_map && a.mode == 0) {
-                v = *(const f16x8*) (a.vec + k0);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int e = m.x_map ? (int) m.x_map[k0 + j] : k0 + j;
-                    v[j] = a.mode == 0 ? a.vec[e] : a.mode == 1 ? attn_merge_elem(a.partial, a.nsplit, e) : silu_mul_f16(a.g[e], a.u[e]);
-                }
-            }
-            xs[idx] = gc_permute(__builtin_bit_cast(uint4, v));
-        }
-        gc_issue(m, plan, 0, col, col_ok, ty, wv);
-    }
-    __syncthreads();
-
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    gc_consume(m, plan, 0, col, col_ok, ty, wv, xs, acc);
-    for (int pass = 1; pass < plan.npass; ++pass) {
-        gc_issue(m, plan, pass, col, col_ok, ty, wv);
-        gc_consume(m, plan, pass, col, col_ok, ty, wv, xs, acc);
-    }
-    const float v = gc_block_reduce(acc, red, tid);
-    if (tid < GC_BN) {
-        const int n = blockIdx.x * GC_BN + tid;
-        if (n < m.N) a.slabs[(size_t) blockIdx.y * m.N + n] = v;
-    }
+    out[h * 128 + d] = (f16) (o / l);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// K6: final residual + RMSNorm + fp16 lm_head GEMV (one wave per vocabulary row, 128-bit loads) -> fp32 logits
+// K6: final RMSNorm + fp16 lm_head GEMV (one wave per vocabulary row, 128-bit loads) -> fp32 logits
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dec_head_kernel(const f16* __restrict__ hid, const float* __restrict__ slabs,
-                                                       int nslab, const f16* __restrict__ norm_w, float eps, int h,
+__global__ __launch_bounds__(256) void dec_head_kernel(const f16* __restrict__ hid, const f16* __restrict__ norm_w, float eps, int h,
                                                        const f16* __restrict__ lm_head, int vocab,
                                                        float* __restrict__ logits, int rows_per_block,
                                                        int32_t* __restrict__ pos_dev, int advance)
@@ -481,21 +347,16 @@ __global__ __launch_bounds__(256) void dec_head_kernel(const f16* __restrict__ h
     const int nvec = h >> 3;
     float ss = 0.f;
     for (int i = tid; i < nvec; i += 256) {
-        f16x8 v = *(const f16x8*) (hid + i * 8);
-        float f[8];
+        const f16x8 v = *(const f16x8*) (hid + i * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = 0.f;
-        for (int s = 0; s < nslab; ++s) {
-            const float4 p0 = *(const float4*) (slabs + (size_t) s * h + i * 8);
-            const float4 p1 = *(const float4*) (slabs + (size_t) s * h + i * 8 + 4);
-            f[0] += p0.x; f[1] += p0.y; f[2] += p0.z; f[3] += p0.w;
-            f[4] += p1.x; f[5] += p1.y; f[6] += p1.z; f[7] += p1.w;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { v[j] = (f16) (f[j] + (float) v[j]); const float t = (float) v[j]; ss = fmaf(t, t, ss); }
+        for (int j = 0; j < 8; ++j) { const float t = (float) v[j]; ss = fmaf(t, t, ss); }
         *(f16x8*) (xlin + i * 8) = v;
     }
-    const float total = block_sum_256(ss, red4, tid);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if ((tid & 63) == 0) red4[tid >> 6] = ss;
+    __syncthreads();
+    const float total = red4[0] + red4[1] + red4[2] + red4[3];
     const f16 rm = (f16) (1.0f / sqrtf(total * (1.0f / (float) h) + eps));
     for (int i = tid; i < nvec; i += 256) {
         const f16x8 v = *(const f16x8*) (xlin + i * 8);
@@ -516,10 +377,10 @@ __global__ __launch_bounds__(256) void dec_head_kernel(const f16* __restrict__ h
         for (int i = lane; i < nvec; i += 64) {
             const uint4 wv = nt_load16(wr + i * 8);
             const uint4 xv = *(const uint4*) (xlin + i * 8);
-            acc = __builtin_amdgcn_fdot2(gc_h2(wv.x), gc_h2(xv.x), acc, false);
-            acc = __builtin_amdgcn_fdot2(gc_h2(wv.y), gc_h2(xv.y), acc, false);
-            acc = __builtin_amdgcn_fdot2(gc_h2(wv.z), gc_h2(xv.z), acc, false);
-            acc = __builtin_amdgcn_fdot2(gc_h2(wv.w), gc_h2(xv.w), acc, false);
+            acc = __builtin_amdgcn_fdot2(t16_h2(wv.x), t16_h2(xv.x), acc, false);
+            acc = __builtin_amdgcn_fdot2(t16_h2(wv.y), t16_h2(xv.y), acc, false);
+            acc = __builtin_amdgcn_fdot2(t16_h2(wv.z), t16_h2(xv.z), acc, false);
+            acc = __builtin_amdgcn_fdot2(t16_h2(wv.w), t16_h2(xv.w), acc, false);
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
@@ -544,33 +405,12 @@ struct Decoder {
     float eps;
     const f16 *embed, *final_norm, *lm_head, *sin, *cos;
     std::vector<DecLayer> layers;
-    f16 *hidA, *hidB, *qbuf, *kbuf, *vbuf, *gbuf, *ubuf;
-    float *slab_o, *slab_d, *partial;
-    int splitk_o, splitk_d, prows_o, prows_d, nsplit;
+    f16 *hid, *qbuf, *kbuf, *vbuf, *attn_out, *act;
+    float* partial;
+    int nsplit;
     void* block;                  // one hipMalloc
 };
-#define DEC_MAGIC 0x44454331u
-
-static GcMatrix gc_view(const Q4Matrix* m)
-{
-    GcMatrix g;
-    g.qweight = m->qweight; g.qzeros = m->qzeros; g.scales = m->scales; g.x_map = m->x_map;
-    g.K = m->height; g.N = m->width; g.groupsize = m->groupsize;
-    return g;
-}
-
-static void pick_splitk(int K, int N, int* splitk, int* prows)
-{
-    const int prow_total = K / 8;
-    const int tiles = (N + GC_BN - 1) / GC_BN;
-    int sk = (512 + tiles - 1) / tiles;
-    if (sk > DEC_MAXS) sk = DEC_MAXS;
-    while (sk > 1 && prow_total / sk < 64) --sk;
-    int pr = (prow_total + sk - 1) / sk;
-    pr = (pr + 3) & ~3;
-    *prows = pr;
-    *splitk = (prow_total + pr - 1) / pr;
-}
+#define DEC_MAGIC 0x44454332u
 
 extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inter, int heads, int kv_heads, int head_dim,
                                   int vocab, int max_seq_len, float eps, const void* embed, const void* final_norm,
@@ -580,7 +420,9 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     *out = nullptr;
     EXL_REQUIRE(device >= 0 && device < EXL_MAX_DEVICES, EXL_E_INVALID, "decoder_create: invalid device %d", device);
     EXL_REQUIRE(head_dim == 128, EXL_E_UNSUPPORTED, "decoder: head_dim must be 128 (got %d)", head_dim);
-    EXL_REQUIRE(hidden % 8 == 0 && hidden == heads * head_dim && heads % kv_heads == 0, EXL_E_UNSUPPORTED, "decoder: bad head geometry");
+    EXL_REQUIRE(hidden % 128 == 0 && hidden == heads * head_dim && heads % kv_heads == 0, EXL_E_UNSUPPORTED, "decoder: bad head geometry");
+    EXL_REQUIRE(inter % 128 == 0, EXL_E_UNSUPPORTED, "decoder: intermediate size must be a multiple of 128 (got %d)", inter);
+    EXL_REQUIRE(hidden <= 8192 && inter <= 24576, EXL_E_UNSUPPORTED, "decoder: hidden (%d) / intermediate (%d) size too large", hidden, inter);
     EXL_REQUIRE(embed && final_norm && lm_head && sin && cos, EXL_E_INVALID, "decoder_create: null pointer");
     Decoder* d = new Decoder();
     d->magic = DEC_MAGIC;
@@ -590,20 +432,17 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     d->sin = (const f16*) sin; d->cos = (const f16*) cos;
     d->layers.resize(n_layers);
     for (auto& l : d->layers) l.set = false;
-    pick_splitk(hidden, hidden, &d->splitk_o, &d->prows_o);
-    pick_splitk(inter, hidden, &d->splitk_d, &d->prows_d);
     int ns = 256 / heads;
     if (ns < 1) ns = 1;
-    if (ns > DEC_MAX_NSPLIT) ns = DEC_MAX_NSPLIT;
+    if (ns > 8) ns = 8;
     while ((max_seq_len + ns - 1) / ns + 16 > DEC_ATT_MAX_KEYS) ++ns;
     d->nsplit = ns;
     const int kvd = kv_heads * head_dim;
     size_t bytes = 0;
     auto carve = [&](size_t n) { const size_t off = bytes; bytes += (n + 255) & ~(size_t) 255; return off; };
-    const size_t o_hidA = carve((size_t) hidden * 2), o_hidB = carve((size_t) hidden * 2), o_q = carve((size_t) hidden * 2);
+    const size_t o_hid = carve((size_t) hidden * 2), o_q = carve((size_t) hidden * 2);
     const size_t o_k = carve((size_t) kvd * 2), o_v = carve((size_t) kvd * 2);
-    const size_t o_g = carve((size_t) inter * 2), o_u = carve((size_t) inter * 2);
-    const size_t o_so = carve((size_t) d->splitk_o * hidden * 4), o_sd = carve((size_t) d->splitk_d * hidden * 4);
+    const size_t o_ao = carve((size_t) hidden * 2), o_act = carve((size_t) inter * 2);
     const size_t o_p = carve((size_t) heads * ns * 130 * 4);
     int prev = 0;
     hipError_t e = hipGetDevice(&prev);
@@ -612,9 +451,9 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     (void) hipSetDevice(prev);
     if (e != hipSuccess) { delete d; EXL_FAIL((int) e, "decoder_create: %s", hipGetErrorString(e)); }
     unsigned char* b = (unsigned char*) d->block;
-    d->hidA = (f16*) (b + o_hidA); d->hidB = (f16*) (b + o_hidB); d->qbuf = (f16*) (b + o_q);
-    d->kbuf = (f16*) (b + o_k); d->vbuf = (f16*) (b + o_v); d->gbuf = (f16*) (b + o_g); d->ubuf = (f16*) (b + o_u);
-    d->slab_o = (float*) (b + o_so); d->slab_d = (float*) (b + o_sd); d->partial = (float*) (b + o_p);
+    d->hid = (f16*) (b + o_hid); d->qbuf = (f16*) (b + o_q);
+    d->kbuf = (f16*) (b + o_k); d->vbuf = (f16*) (b + o_v); d->attn_out = (f16*) (b + o_ao); d->act = (f16*) (b + o_act);
+    d->partial = (float*) (b + o_p);
     *out = d;
     return 0;
 }
@@ -643,8 +482,10 @@ extern "C" int exl_decoder_set_layer(void* dec, int index, void* q, void* k, voi
                 l.down->height == d->inter && l.down->width == d->h, EXL_E_INVALID, "decoder_set_layer: matrix shapes do not match the model");
     for (Q4Matrix* m : {l.q, l.k, l.v, l.o, l.gate, l.up, l.down}) {
         EXL_REQUIRE(m->device == d->device, EXL_E_INVALID, "decoder_set_layer: matrix lives on another device");
-        EXL_REQUIRE(m->width % 4 == 0 && m->groupsize % 8 == 0, EXL_E_UNSUPPORTED, "decoder_set_layer: unsupported matrix geometry");
+        EXL_REQUIRE(m->layout == EXL_LAYOUT_T16, EXL_E_UNSUPPORTED, "decoder_set_layer: matrix is not in the T16 layout");
     }
+    EXL_REQUIRE(l.gate->groupsize == l.up->groupsize && (l.gate->x_map == nullptr) == (l.up->x_map == nullptr), EXL_E_UNSUPPORTED,
+                "decoder_set_layer: gate and up projections must share group size and act-order mode");
     EXL_REQUIRE(in_norm && post_norm && key_cache && value_cache, EXL_E_INVALID, "decoder_set_layer: null pointer");
     l.in_norm = (const f16*) in_norm; l.post_norm = (const f16*) post_norm;
     l.kc = (f16*) key_cache; l.vc = (f16*) value_cache;
@@ -663,49 +504,61 @@ extern "C" int exl_decoder_free(void* dec)
     return 0;
 }
 
-static int launch_norm_gemv(const Decoder* d, const f16* hid_in, const int64_t* tok, const float* slabs, int nslab,
-                            f16* hid_out, const f16* norm_w, int nmat, Q4Matrix* const* mats, f16* const* outs, hipStream_t s)
+// (U, NP) by row-blocks per wave; G16 by group size; NV by K
+template <int PNORM, int EMODE, int NV>
+static int launch_dec_gemv_cfg(bool g16, int rbw, dim3 grid, size_t smem, hipStream_t s, const DecGemvArgs& a)
 {
-    ANormArgs a;
-    a.hid_in = hid_in; a.tok = tok; a.slabs = slabs; a.nslab = nslab; a.hid_out = hid_out; a.norm_w = norm_w;
-    a.eps = d->eps; a.h = d->h; a.nmat = nmat;
+#define DEC_LAUNCH(U, NP) do { if (g16) hipLaunchKernelGGL((dec_gemv_kernel<U, NP, true, PNORM, EMODE, NV>), grid, dim3(DEC_THREADS), smem, s, a); \
+                               else     hipLaunchKernelGGL((dec_gemv_kernel<U, NP, false, PNORM, EMODE, NV>), grid, dim3(DEC_THREADS), smem, s, a); } while (0)
+    if (rbw <= 4)       DEC_LAUNCH(4, 1);
+    else if (rbw <= 8)  DEC_LAUNCH(4, 2);
+    else if (rbw <= 12) DEC_LAUNCH(6, 2);
+    else                DEC_LAUNCH(6, 4);
+#undef DEC_LAUNCH
+    EXL_LAUNCH_CHECK();
+    return 0;
+}
+
+// pnorm / emode as in dec_gemv_kernel.  mats: nmat matrices sharing K (emode 2: gate, up).
+static int launch_dec_gemv(int pnorm, int emode, const f16* vec, const int64_t* tok, const f16* norm_w, float eps, f16* hid_copy,
+                           int nmat, Q4Matrix* const* mats, f16* const* outs, f16* hid_io, hipStream_t s)
+{
+    DecGemvArgs a;
+    a.vec = vec; a.tok = tok; a.norm_w = norm_w; a.eps = eps; a.hid_copy = hid_copy; a.nmat = nmat; a.hid_io = hid_io;
     int tiles = 0;
+    bool any_map = false;
     for (int i = 0; i < DEC_MAX_MATS; ++i) {
         if (i < nmat) {
-            a.mat[i] = gc_view(mats[i]);
-            a.out[i] = outs[i];
-            tiles += (mats[i]->width + GC_BN - 1) / GC_BN;
+            a.mat[i] = t16_view(mats[i]);
+            a.out[i] = outs ? outs[i] : nullptr;
+            if (emode != 2 || i == 0) tiles += mats[i]->width / 16;
+            any_map = any_map || mats[i]->x_map != nullptr;
         } else {
             a.mat[i] = a.mat[0];
             a.out[i] = nullptr;
         }
         a.tile_end[i] = tiles;
     }
-    const size_t smem = (size_t) d->h * 4 + (4 * GC_BN + 8) * sizeof(float);
-    const int nv = (d->h / 8 + 255) / 256;
-    if (nv <= 2)      hipLaunchKernelGGL(dec_norm_gemv_kernel<2>, dim3(tiles), dim3(256), smem, s, a);
-    else if (nv <= 3) hipLaunchKernelGGL(dec_norm_gemv_kernel<3>, dim3(tiles), dim3(256), smem, s, a);
-    else              hipLaunchKernelGGL(dec_norm_gemv_kernel<4>, dim3(tiles), dim3(256), smem, s, a);
-    EXL_LAUNCH_CHECK();
-    return 0;
-}
-
-static int launch_vec_gemv(int mode, const f16* vec, const float* partial, int nsplit, const f16* g, const f16* u,
-                           const Q4Matrix* m, float* slabs, int splitk, int prows, hipStream_t s)
-{
-    BVecArgs a;
-    a.mode = mode; a.vec = vec; a.partial = partial; a.nsplit = nsplit; a.g = g; a.u = u;
-    a.mat = gc_view(m); a.slabs = slabs; a.prows_per_block = prows;
-    const size_t smem = (size_t) prows * 16 + 4 * GC_BN * sizeof(float);
-    dim3 grid((m->width + GC_BN - 1) / GC_BN, splitk);
-    const bool fast = !m->x_map && prows <= 512 && (mode == 2 || (mode == 1 && nsplit <= DEC_MAX_NSPLIT));
-    if (!fast)                      hipLaunchKernelGGL((dec_vec_gemv_kernel<0, 1>), grid, dim3(256), smem, s, a);
-    else if (mode == 1 && prows <= 256) hipLaunchKernelGGL((dec_vec_gemv_kernel<1, 1>), grid, dim3(256), smem, s, a);
-    else if (mode == 1)             hipLaunchKernelGGL((dec_vec_gemv_kernel<1, 2>), grid, dim3(256), smem, s, a);
-    else if (prows <= 256)          hipLaunchKernelGGL((dec_vec_gemv_kernel<2, 1>), grid, dim3(256), smem, s, a);
-    else                            hipLaunchKernelGGL((dec_vec_gemv_kernel<2, 2>), grid, dim3(256), smem, s, a);
-    EXL_LAUNCH_CHECK();
-    return 0;
+    const int K = mats[0]->height, RB = K / 128;
+    const int wpt = emode == 2 ? DEC_WAVES / 2 : DEC_WAVES;
+    const int rbw = (RB + wpt - 1) / wpt;
+    EXL_REQUIRE(rbw <= 24, EXL_E_UNSUPPORTED, "decoder: in_features %d too large", K);
+    a.rb_per_wave = rbw;
+    const bool g16 = mats[0]->groupsize % 128 == 0;
+    for (int i = 1; i < nmat; ++i)
+        EXL_REQUIRE((mats[i]->groupsize % 128 == 0) == g16 && mats[i]->height == K, EXL_E_UNSUPPORTED, "decoder: fused matrices must share K and group-size class");
+    a.xs_images = (emode == 2 && any_map) ? 2 : 1;
+    const size_t smem = (size_t) a.xs_images * (K / 8) * 16 + (DEC_WAVES * 16 + DEC_WAVES) * sizeof(float) + (any_map ? (size_t) K * 2 : 0);
+    EXL_REQUIRE(smem <= 64 * 1024, EXL_E_UNSUPPORTED, "decoder: activation stage (%zu bytes of LDS) exceeds 64 KiB", smem);
+    const int nv = (K / 8 + DEC_THREADS - 1) / DEC_THREADS;
+    dim3 grid(tiles);
+#define DEC_NV(P, E) (nv <= 1 ? launch_dec_gemv_cfg<P, E, 1>(g16, rbw, grid, smem, s, a) : nv <= 2 ? launch_dec_gemv_cfg<P, E, 2>(g16, rbw, grid, smem, s, a) \
+                      : nv <= 3 ? launch_dec_gemv_cfg<P, E, 3>(g16, rbw, grid, smem, s, a) : launch_dec_gemv_cfg<P, E, 6>(g16, rbw, grid, smem, s, a))
+    if (pnorm == 1 && emode == 0) return DEC_NV(1, 0);
+    if (pnorm == 1 && emode == 2) return DEC_NV(1, 2);
+    if (pnorm == 0 && emode == 1) return DEC_NV(0, 1);
+#undef DEC_NV
+    EXL_FAIL(EXL_E_INVALID, "decoder: unsupported kernel combination");
 }
 
 extern "C" int exl_decoder_step(void* dec, const int64_t* token_dev, int32_t* pos_dev, float* logits_out, int advance,
@@ -725,26 +578,29 @@ extern "C" int exl_decoder_step(void* dec, const int64_t* token_dev, int32_t* po
         const DecLayer& l = d->layers[i];
         Q4Matrix* qkv[3] = {l.q, l.k, l.v};
         f16* qkv_out[3] = {d->qbuf, d->kbuf, d->vbuf};
-        if (i == 0) rc = launch_norm_gemv(d, d->embed, token_dev, nullptr, 0, d->hidA, l.in_norm, 3, qkv, qkv_out, s);
-        else        rc = launch_norm_gemv(d, d->hidB, nullptr, d->slab_d, d->splitk_d, d->hidA, l.in_norm, 3, qkv, qkv_out, s);
+        if (i == 0) rc = launch_dec_gemv(1, 0, d->embed, token_dev, l.in_norm, d->eps, d->hid, 3, qkv, qkv_out, nullptr, s);
+        else        rc = launch_dec_gemv(1, 0, d->hid, nullptr, l.in_norm, d->eps, nullptr, 3, qkv, qkv_out, nullptr, s);
         if (rc) break;
         hipLaunchKernelGGL(dec_attn_kernel, dim3(d->nsplit, d->heads), dim3(256), 0, s, d->qbuf, d->kbuf, d->vbuf, l.kc, l.vc,
                            d->sin, d->cos, d->partial, pos_dev, d->heads, d->kv_heads, d->max_seq, d->nsplit, scale);
+        hipLaunchKernelGGL(dec_attn_merge_kernel, dim3(d->heads), dim3(128), 0, s, d->partial, d->attn_out, d->nsplit);
         { hipError_t e = hipGetLastError(); if (e != hipSuccess) { exl_set_error("decoder attn launch: %s", hipGetErrorString(e)); rc = (int) e; break; } }
-        rc = launch_vec_gemv(1, nullptr, d->partial, d->nsplit, nullptr, nullptr, l.o, d->slab_o, d->splitk_o, d->prows_o, s);
+        Q4Matrix* om[1] = {l.o};
+        rc = launch_dec_gemv(0, 1, d->attn_out, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s);
         if (rc) break;
         Q4Matrix* gu[2] = {l.gate, l.up};
-        f16* gu_out[2] = {d->gbuf, d->ubuf};
-        rc = launch_norm_gemv(d, d->hidA, nullptr, d->slab_o, d->splitk_o, d->hidB, l.post_norm, 2, gu, gu_out, s);
+        f16* gu_out[2] = {d->act, nullptr};
+        rc = launch_dec_gemv(1, 2, d->hid, nullptr, l.post_norm, d->eps, nullptr, 2, gu, gu_out, nullptr, s);
         if (rc) break;
-        rc = launch_vec_gemv(2, nullptr, nullptr, 0, d->gbuf, d->ubuf, l.down, d->slab_d, d->splitk_d, d->prows_d, s);
+        Q4Matrix* dm[1] = {l.down};
+        rc = launch_dec_gemv(0, 1, d->act, nullptr, nullptr, 0.f, nullptr, 1, dm, nullptr, d->hid, s);
     }
     if (rc == 0) {
         const int rows_per_block = 32;
         const int blocks = (d->vocab + rows_per_block - 1) / rows_per_block;
         const size_t smem = (size_t) d->h * 2 + 8 * sizeof(float);
-        hipLaunchKernelGGL(dec_head_kernel, dim3(blocks), dim3(256), smem, s, d->hidB, d->slab_d, d->splitk_d, d->final_norm,
-                           d->eps, d->h, d->lm_head, d->vocab, logits_out, rows_per_block, pos_dev, advance);
+        hipLaunchKernelGGL(dec_head_kernel, dim3(blocks), dim3(256), smem, s, d->hid, d->final_norm, d->eps, d->h, d->lm_head,
+                           d->vocab, logits_out, rows_per_block, pos_dev, advance);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { exl_set_error("decoder head launch: %s", hipGetErrorString(e)); rc = (int) e; }
     }

@@ -1,0 +1,177 @@
+// Device-side core of the int4 decode GEMV on the T16 weight layout (q4_matrix.hip: retile_t16_kernel).
+//
+// T16 layout ("16-column tiles, 4-row pieces").  With R = K/8 packed rows and RB = R/16 row-blocks, the GPTQ word
+// (packed row r, column n) lives in the 16-byte piece
+//     piece(n, r) = (t * RB + rb) * 64 + rsub * 16 + col        t = n / 16, col = n % 16, rb = r / 16, rsub = (r % 16) / 4
+// as dword j = r % 4.  So one piece = 4 consecutive packed rows (32 k) of ONE column, one wave64 load instruction
+// (lane = rsub * 16 + col) = 16 packed rows x 16 columns = 1 KiB of contiguous memory, and a 16-column tile is one
+// contiguous run of K * 8 bytes that a block streams front to back with full K: no split-K, no partial-sum slabs, no
+// cross-block reduction on the decode path.
+//
+// The lane layout of a piece is exactly the B operand of v_mfma_f32_16x16x32_f16 (lane = (k-group, column), 8 k per
+// lane): the matrix core is used as the wave-wide dot-product AND reduction engine.  Per 1 KiB instruction a lane
+// expands its 4 words to fp16 (magic-number nibble expansion, exact zero-point subtraction, ONE fp16 multiply by the
+// group scale = bit-identical to the reference's reconstruct, q4_matrix.cu:207) and issues 4 MFMAs against the
+// activation k-groups read from LDS; D accumulates in fp32 across the whole K range.  No shuffles, no atomics.
+//
+// A operand: lane (m = l & 15, kg = l >> 4) supplies activation row m, k-group kg.  With one activation row every m
+// reads the same LDS address (broadcast) and every D row is the same dot product; with up to 16 rows (op-level
+// q4_matmul for M < 8) each m reads its own row and D rows 4*rsub + j land in acc[j].
+#pragma once
+#include "common.h"
+
+#define T16_MAGIC 0x64006400u
+#define T16_EH 6                    // entry slots per lane: up to 24 row-blocks per wave
+
+__device__ __forceinline__ f16x2 t16_h2(uint32_t v) { return __builtin_bit_cast(f16x2, v); }
+
+// (h0..h7) -> (h0,h4),(h1,h5),(h2,h6),(h3,h7): the order in which nibble pairs fall out of a GPTQ word
+__device__ __forceinline__ uint4 t16_permute(uint4 d)
+{
+    uint4 o;
+    o.x = (d.x & 0xFFFFu) | (d.z << 16);
+    o.y = (d.x >> 16) | (d.z & 0xFFFF0000u);
+    o.z = (d.y & 0xFFFFu) | (d.w << 16);
+    o.w = (d.y >> 16) | (d.w & 0xFFFF0000u);
+    return o;
+}
+
+// 8 weights of one word as fp16, order (q0,q4,q1,q5,q2,q6,q3,q7), each h( h(q - z) * s )
+__device__ __forceinline__ f16x8 t16_dequant(uint32_t w, f16x2 zc0, f16x2 zc1, f16x2 s2)
+{
+    const f16x2 sixteenth = {(f16) 0.0625f, (f16) 0.0625f};
+    const uint32_t w8 = w >> 8;
+    const f16x2 d0 = (t16_h2((w & 0x000F000Fu) | T16_MAGIC) + zc0) * s2;
+    const f16x2 d1 = (t16_h2((w & 0x00F000F0u) | T16_MAGIC) * sixteenth + zc1) * s2;
+    const f16x2 d2 = (t16_h2((w8 & 0x000F000Fu) | T16_MAGIC) + zc0) * s2;
+    const f16x2 d3 = (t16_h2((w8 & 0x00F000F0u) | T16_MAGIC) * sixteenth + zc1) * s2;
+    const uint4 u = make_uint4(__builtin_bit_cast(uint32_t, d0), __builtin_bit_cast(uint32_t, d1),
+                               __builtin_bit_cast(uint32_t, d2), __builtin_bit_cast(uint32_t, d3));
+    return __builtin_bit_cast(f16x8, u);
+}
+
+struct T16Matrix {                  // device-visible view of a Q4Matrix in T16 layout
+    const uint4* qw;                // [N/16][RB][64] pieces
+    const uint32_t* qzeros;         // [G][N/8]           (GPTQ layout)
+    const f16* scales;              // [G][N]             (GPTQ layout)
+    const uint32_t* x_map;          // [K] or NULL (act-order)
+    int K, N, R, RB;
+    int gprows;                     // packed rows per group = groupsize / 8 (a multiple of 4)
+    int gshift;                     // log2(gprows) or -1
+    int G;
+};
+
+__device__ __forceinline__ int t16_group_of_row(const T16Matrix& m, int r) { return m.gshift >= 0 ? (r >> m.gshift) : (r / m.gprows); }
+
+// (scale bits) | (z + 1) << 16 for (group g, column n)
+__device__ __forceinline__ uint32_t t16_load_entry(const T16Matrix& m, int g, int n)
+{
+    const uint32_t zw = m.qzeros[(size_t) g * (m.N >> 3) + (n >> 3)];
+    const uint16_t sb = ((const uint16_t*) m.scales)[(size_t) g * m.N + n];
+    return (uint32_t) sb | ((((zw >> ((n & 7) * 4)) & 0xFu) + 1) << 16);
+}
+
+// Per-wave streaming state.  U = 16-byte loads in flight per lane (one pass = U row-blocks), NP = max passes.
+// G16 = true : groupsize is a multiple of 128 (every row-block lies in one group): entries are loaded once per
+//              4 row-blocks per lane and handed around with ds_bpermute;
+// G16 = false: groupsize 32 / 64: each lane loads the entry of its own 4 rows with every piece.
+template <int U, int NP, bool G16>
+struct T16Wave {
+    static_assert(U * NP <= 4 * T16_EH, "too many row-blocks per wave");
+    const uint4* base;
+    int rb0, rb1, rbsafe, col, rsub, n;
+    uint32_t ent[G16 ? T16_EH : U];
+    uint4 wv[U];
+
+    __device__ __forceinline__ void init(const T16Matrix& m, int t, int lane, int rb_begin, int rb_end)
+    {
+        col = lane & 15; rsub = lane >> 4;
+        rb0 = rb_begin; rb1 = rb_end;
+        rbsafe = min(rb_begin, m.RB - 1);                             // waves past the end of K still form valid addresses
+        n = t * 16 + col;
+        base = m.qw + (size_t) t * m.RB * 64 + lane;
+    }
+    // issue the small loads of the wave's scale/zero entries (G16) -- call BEFORE the first issue()
+    __device__ __forceinline__ void load_entries(const T16Matrix& m)
+    {
+        if constexpr (G16) {
+#pragma unroll
+            for (int h = 0; h < T16_EH; ++h) {
+                if (h * 4 < U * NP) {
+                    const int rb = min(rb0 + 4 * h + rsub, m.RB - 1);
+                    ent[h] = (rb0 + 4 * h < rb1) ? t16_load_entry(m, t16_group_of_row(m, rb * 16), n) : 0u;
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void issue(const T16Matrix& m, int pass)
+    {
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int rb = rb0 + pass * U + i;
+            const int rbc = rb < rb1 ? rb : rbsafe;                    // clamped: always a valid address
+            if constexpr (!G16) ent[i] = t16_load_entry(m, t16_group_of_row(m, rbc * 16 + rsub * 4), n);
+            wv[i] = nt_load16(base + (size_t) rbc * 64);
+        }
+    }
+    // xrow: LDS activation image (permuted 8-half groups per packed row) of the activation row this lane feeds to the
+    // A operand (row m = lane & 15; with a single activation row every lane passes the same pointer).
+    __device__ __forceinline__ void consume(int pass, const uint4* xrow, f32x4& c)
+    {
+        const f16x2 c960 = {(f16) 960.f, (f16) 960.f};
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int li = pass * U + i;
+            const int rb = rb0 + li;
+            if (rb < rb1) {                                             // wave-uniform
+                uint32_t e;
+                if constexpr (G16) e = (uint32_t) __shfl((int) ent[li >> 2], ((li & 3) << 4) | col, 64);
+                else e = ent[i];
+                const f16 sc = __builtin_bit_cast(f16, (uint16_t) (e & 0xFFFFu));
+                const f16 za = (f16) (float) (-(1024 + (int) (e >> 16)));
+                const f16x2 s2 = {sc, sc};
+                const f16x2 zc0 = {za, za};
+                const f16x2 zc1 = zc0 + c960;
+                const int r = rb * 16 + rsub * 4;
+                const uint4 x0 = xrow[r], x1 = xrow[r + 1], x2 = xrow[r + 2], x3 = xrow[r + 3];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x0), t16_dequant(wv[i].x, zc0, zc1, s2), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x1), t16_dequant(wv[i].y, zc0, zc1, s2), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x2), t16_dequant(wv[i].z, zc0, zc1, s2), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x3), t16_dequant(wv[i].w, zc0, zc1, s2), c, 0, 0, 0);
+            }
+        }
+    }
+    // all passes; the loads of pass 0 must already be in flight (issued ahead of the block's prologue)
+    __device__ __forceinline__ void run(const T16Matrix& m, const uint4* xrow, f32x4& c)
+    {
+        consume(0, xrow, c);
+#pragma unroll
+        for (int p = 1; p < NP; ++p) {
+            if (rb0 + p * U < rb1) {                                    // wave-uniform
+                issue(m, p);
+                consume(p, xrow, c);
+            }
+        }
+    }
+};
+
+// Build the permuted (and x_map-gathered) LDS image of an activation row from a linear fp16 copy in LDS.
+__device__ __forceinline__ void t16_stage_from_lds(const f16* xlin, const uint32_t* x_map, int R, uint4* xs, int tid,
+                                                   int nthreads)
+{
+    for (int idx = tid; idx < R; idx += nthreads) {
+        const int k = idx * 8;
+        uint4 v;
+        if (x_map) {
+            const uint4 m0 = *(const uint4*) (x_map + k);
+            const uint4 m1 = *(const uint4*) (x_map + k + 4);
+            f16x8 g;
+            g[0] = xlin[m0.x]; g[1] = xlin[m0.y]; g[2] = xlin[m0.z]; g[3] = xlin[m0.w];
+            g[4] = xlin[m1.x]; g[5] = xlin[m1.y]; g[6] = xlin[m1.z]; g[7] = xlin[m1.w];
+            v = __builtin_bit_cast(uint4, g);
+        } else {
+            v = *(const uint4*) (xlin + k);
+        }
+        xs[idx] = t16_permute(v);
+    }
+}

@@ -54,6 +54,7 @@ __device__ __forceinline__ f16x8 dequant_word(uint32_t w, f16x2 zc0, f16x2 zc1, 
     return r;
 }
 
+template <bool T16>      // weight layout: GPTQ [K/8][N] words, or T16 pieces (gemv_t16.h)
 __global__ __launch_bounds__(256) void q4_gemm_kernel(const f16* __restrict__ x, const uint32_t* __restrict__ qweight,
                                                       const uint32_t* __restrict__ qzeros,
                                                       const f16* __restrict__ scales, f16* __restrict__ out, int M,
@@ -119,11 +120,23 @@ __global__ __launch_bounds__(256) void q4_gemm_kernel(const f16* __restrict__ x,
         for (int i = 0; i < 4; ++i)
             *(uint4*) (lds + buf * (BM * BK * 2) + a_lds_off(a_row[i], a_c8[i])) = permute_x8(ar[i]);
     };
+    // B operand of MFMA step kk, lane half g = the 8 k of ONE packed row.  GPTQ layout: row 2*kk + g of the K tile (one
+    // uint2 = columns n, n+1).  T16 layout: the lane's two pieces hold rows 4*g .. 4*g+3 of the K tile for columns n and
+    // n+1 (32 contiguous bytes), step kk uses dword kk -- the A fragment is read with the matching k-order below.
+    const uint4* t16p = (const uint4*) qweight + ((size_t) (n >> 4) * (K >> 7)) * 64 + (n & 15);
     auto load_b = [&](int k0, uint2 (&br)[4]) {
+        if constexpr (T16) {
+            const int rb = k0 >> 7, rsub = ((k0 >> 6) & 1) * 2 + g;
+            uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0;
+            if (n_ok) { const uint4* p = t16p + (size_t) rb * 64 + rsub * 16; p0 = p[0]; p1 = p[1]; }
+            br[0] = make_uint2(p0.x, p1.x); br[1] = make_uint2(p0.y, p1.y);
+            br[2] = make_uint2(p0.z, p1.z); br[3] = make_uint2(p0.w, p1.w);
+        } else {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int prow = (k0 >> 3) + 2 * kk + g;
-            br[kk] = (n_ok && prow * 8 < K) ? *(const uint2*) (wptr + (size_t) prow * N) : make_uint2(0, 0);
+            for (int kk = 0; kk < 4; ++kk) {
+                const int prow = (k0 >> 3) + 2 * kk + g;
+                br[kk] = (n_ok && prow * 8 < K) ? *(const uint2*) (wptr + (size_t) prow * N) : make_uint2(0, 0);
+            }
         }
     };
 
@@ -147,10 +160,10 @@ __global__ __launch_bounds__(256) void q4_gemm_kernel(const f16* __restrict__ x,
         const unsigned char* abuf = lds + (it & 1) * (BM * BK * 2);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const int k = k0 + kk * 16;
-            if (k < K) {                                       // block-uniform
+            const int k = T16 ? k0 + 32 * g + 8 * kk : k0 + kk * 16;    // first k this lane multiplies in this step
+            if (k0 + kk * 16 < K) {                            // block-uniform
                 const int grp = gshift >= 0 ? (k >> gshift) : (k / groupsize);
-                if (grp != cur_group) {                        // block-uniform
+                if (grp != cur_group) {                        // uniform unless groupsize == 32 in the T16 layout
                     cur_group = grp;
                     uint32_t zw = 0;
                     f16x2 sv = {(f16) 0.f, (f16) 0.f};
@@ -175,7 +188,7 @@ __global__ __launch_bounds__(256) void q4_gemm_kernel(const f16* __restrict__ x,
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int row = wm * 64 + t * 32 + c;
-                    af[t] = *(const f16x8*) (abuf + a_lds_off(row, kk * 2 + g));
+                    af[t] = *(const f16x8*) (abuf + a_lds_off(row, T16 ? 4 * g + kk : kk * 2 + g));
                 }
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
@@ -233,8 +246,12 @@ int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
     const int mtiles = (rows + BM - 1) / BM;
     const int ntiles = (N + BN - 1) / BN;
     const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
-    hipLaunchKernelGGL(q4_gemm_kernel, dim3(grid), dim3(256), 0, s, xin, w->qweight, w->qzeros, w->scales, out, rows, K,
-                       N, gshift, w->groupsize, no_zero, mtiles, ntiles);
+    if (w->layout == EXL_LAYOUT_T16)
+        hipLaunchKernelGGL(q4_gemm_kernel<true>, dim3(grid), dim3(256), 0, s, xin, w->qweight, w->qzeros, w->scales, out, rows, K,
+                           N, gshift, w->groupsize, no_zero, mtiles, ntiles);
+    else
+        hipLaunchKernelGGL(q4_gemm_kernel<false>, dim3(grid), dim3(256), 0, s, xin, w->qweight, w->qzeros, w->scales, out, rows, K,
+                           N, gshift, w->groupsize, no_zero, mtiles, ntiles);
     EXL_LAUNCH_CHECK();
     return 0;
 }

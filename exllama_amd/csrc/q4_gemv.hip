@@ -16,7 +16,7 @@
 //   * k-slices are combined with wave shuffles + LDS; split-K across blocks writes fp32 slabs that a
 //     tiny second kernel sums in a FIXED order.  No atomics anywhere -> bit-reproducible run to run
 //     (the reference uses fp16 atomicAdd, q4_matmul.cu:206).
-#include "common.h"
+#include "gemv_t16.h"
 
 #define MAGIC_1024 0x64006400u
 
@@ -236,10 +236,130 @@ static int launch_cfg(int ch, dim3 grid, size_t smem, hipStream_t s, const f16* 
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// T16 layout (the product path): one block = one 16-column tile, 8 waves split the K range, MFMA dot products
+// (gemv_t16.h).  Up to 16 activation rows ride along in the M dimension of the MFMA for free.
+// ---------------------------------------------------------------------------------------------------------------
+T16Matrix t16_view(const Q4Matrix* m)
+{
+    T16Matrix v;
+    v.qw = (const uint4*) m->qweight; v.qzeros = m->qzeros; v.scales = m->scales; v.x_map = m->x_map;
+    v.K = m->height; v.N = m->width; v.R = m->height / 8; v.RB = m->height / 128;
+    v.gprows = m->groupsize / 8;
+    v.gshift = -1;
+    if ((v.gprows & (v.gprows - 1)) == 0) { v.gshift = 0; while ((1 << v.gshift) < v.gprows) ++v.gshift; }
+    v.G = m->groups;
+    return v;
+}
+
+#define T16_WAVES 8
+
+template <int U, int NP, bool G16, int MR>
+__global__ __launch_bounds__(T16_WAVES * 64) void q4_gemv_t16_kernel(const T16Matrix m, const f16* __restrict__ x,
+                                                                      f16* __restrict__ out, int rows, int no_zero,
+                                                                      int rb_per_wave, int xstride)
+{
+    constexpr int NTH = T16_WAVES * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4* xs = (uint4*) smem;                                           // [rows][xstride]
+    float* red = (float*) (smem + (size_t) rows * xstride * 16);         // [WAVES][MR][16]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int t = blockIdx.x;
+    if ((gridDim.x & 7) == 0) { const int per = gridDim.x >> 3; t = (t & 7) * per + (t >> 3); }   // neighbours share an XCD L2
+    T16Wave<U, NP, G16> w;
+    const int rb0 = wave * rb_per_wave;
+    w.init(m, t, lane, rb0, min(m.RB, rb0 + rb_per_wave));
+    w.load_entries(m);
+    w.issue(m, 0);
+    // activation rows -> LDS (permuted; gathered through x_map for act-order weights)
+    for (int idx = tid; idx < rows * m.R; idx += NTH) {
+        const int mm = idx / m.R, r = idx - mm * m.R;
+        const f16* xr = x + (size_t) mm * m.K;
+        uint4 v;
+        if (m.x_map) {
+            const uint4 m0 = *(const uint4*) (m.x_map + r * 8);
+            const uint4 m1 = *(const uint4*) (m.x_map + r * 8 + 4);
+            f16x8 g;
+            g[0] = xr[m0.x]; g[1] = xr[m0.y]; g[2] = xr[m0.z]; g[3] = xr[m0.w];
+            g[4] = xr[m1.x]; g[5] = xr[m1.y]; g[6] = xr[m1.z]; g[7] = xr[m1.w];
+            v = __builtin_bit_cast(uint4, g);
+        } else {
+            v = *(const uint4*) (xr + r * 8);
+        }
+        xs[(size_t) mm * xstride + r] = t16_permute(v);
+    }
+    __syncthreads();
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    const int arow = MR == 1 ? 0 : min(lane & 15, rows - 1);
+    w.run(m, xs + (size_t) arow * xstride, c);
+    if (MR == 1) {
+        if (lane < 16) red[wave * 16 + lane] = c[0];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[(wave * 16 + (lane >> 4) * 4 + j) * 16 + (lane & 15)] = c[j];
+    }
+    __syncthreads();
+    if (tid < rows * 16) {
+        const int mm = tid >> 4, cc = tid & 15;
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < T16_WAVES; ++wv) v += MR == 1 ? red[wv * 16 + cc] : red[(wv * 16 + mm) * 16 + cc];
+        f16* o = out + (size_t) mm * m.N + t * 16 + cc;
+        if (no_zero) v += (float) *o;
+        *o = (f16) v;
+    }
+}
+
+template <bool G16, int MR>
+static int launch_t16_cfg(int rbw, dim3 grid, size_t smem, hipStream_t s, const T16Matrix& m, const f16* x, f16* out, int rows,
+                          int no_zero, int xstride)
+{
+#define T16_LAUNCH(U, NP) hipLaunchKernelGGL((q4_gemv_t16_kernel<U, NP, G16, MR>), grid, dim3(T16_WAVES * 64), smem, s, m, x, out, rows, no_zero, rbw, xstride)
+    if (rbw <= 4)       T16_LAUNCH(4, 1);
+    else if (rbw <= 8)  T16_LAUNCH(4, 2);
+    else if (rbw <= 12) T16_LAUNCH(6, 2);
+    else                T16_LAUNCH(6, 4);
+#undef T16_LAUNCH
+    EXL_LAUNCH_CHECK();
+    return 0;
+}
+
+static int launch_q4_gemv_t16(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_zero, hipStream_t s)
+{
+    const T16Matrix m = t16_view(w);
+    const int rbw = (m.RB + T16_WAVES - 1) / T16_WAVES;
+    EXL_REQUIRE(rbw <= 24, EXL_E_UNSUPPORTED, "q4 gemv: in_features %d too large for the decode kernel (max %d)", m.K, 24 * T16_WAVES * 128);
+    const bool g16 = m.gprows % 16 == 0;
+    const int ntiles = m.N / 16;
+    // LDS budget: rows * xstride * 16 + reduction buffer <= 64 KiB (the default dynamic-LDS limit); more rows go in
+    // several launches (this is the op-level path for 2..7 rows; single-token decode runs through decode_fused.hip)
+    const int xstride = rows == 1 ? m.R : m.R + 1;
+    const int max_rows = (int) ((64 * 1024 - 8 * 1024) / ((size_t) (m.R + 1) * 16));
+    EXL_REQUIRE(max_rows >= 1, EXL_E_UNSUPPORTED, "q4 gemv: in_features %d does not fit the activation stage", m.K);
+    for (int r0 = 0; r0 < rows; r0 += max_rows) {
+        const int nr = rows - r0 < max_rows ? rows - r0 : max_rows;
+        const f16* xp = x + (size_t) r0 * m.K;
+        f16* op = out + (size_t) r0 * m.N;
+        const int xs = nr == 1 ? m.R : xstride;
+        const size_t smem = (size_t) nr * xs * 16 + (size_t) T16_WAVES * (nr == 1 ? 16 : 256) * sizeof(float);
+        int rc;
+        if (nr == 1) rc = g16 ? launch_t16_cfg<true, 1>(rbw, dim3(ntiles), smem, s, m, xp, op, nr, no_zero, xs)
+                              : launch_t16_cfg<false, 1>(rbw, dim3(ntiles), smem, s, m, xp, op, nr, no_zero, xs);
+        else         rc = g16 ? launch_t16_cfg<true, 16>(rbw, dim3(ntiles), smem, s, m, xp, op, nr, no_zero, xs)
+                              : launch_t16_cfg<false, 16>(rbw, dim3(ntiles), smem, s, m, xp, op, nr, no_zero, xs);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 int launch_q4_gemv(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_zero, float* ws, size_t ws_floats,
                    hipStream_t s)
 {
     if (rows <= 0) return 0;
+    if (w->layout == EXL_LAYOUT_T16) {
+        EXL_REQUIRE(rows <= 16, EXL_E_UNSUPPORTED, "q4 gemv: rows (%d) > 16", rows);
+        return launch_q4_gemv_t16(w, x, rows, out, no_zero, s);
+    }
     const int K = w->height, N = w->width;
     EXL_REQUIRE(rows <= 8, EXL_E_UNSUPPORTED, "q4 gemv: rows (%d) > 8", rows);
     EXL_REQUIRE(N % 4 == 0 && K % 8 == 0, EXL_E_UNSUPPORTED, "q4 gemv: need N %% 4 == 0 and K %% 8 == 0");

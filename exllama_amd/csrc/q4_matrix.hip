@@ -76,8 +76,79 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(const uint4* __restric
     }
 }
 
+// T16 layout: one thread = one 16-byte piece = 4 packed rows x 1 column -> 32 fp16 values of that column.
+__global__ __launch_bounds__(256) void reconstruct_t16_kernel(const uint4* __restrict__ w, f16* __restrict__ out,
+                                                              const f16* __restrict__ scales,
+                                                              const uint32_t* __restrict__ qzeros, int RB, int width,
+                                                              int groupsize, size_t npieces)
+{
+    const size_t p = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (p >= npieces) return;
+    const int lane = (int) (p & 63);
+    const size_t trb = p >> 6;
+    const int rb = (int) (trb % RB), t = (int) (trb / RB);
+    const int col = lane & 15, rsub = lane >> 4;
+    const int n = t * 16 + col;
+    const int r0 = rb * 16 + rsub * 4;
+    const int group = (r0 * 8) / groupsize;                  // 4 packed rows never straddle a group (groupsize % 32 == 0)
+    const int z = (int) ((qzeros[(size_t) group * (width / 8) + (n >> 3)] >> (4 * (n & 7))) & 0xFu) + 1;
+    const f16 sc = scales[(size_t) group * width + n];
+    const uint4 v = w[p];
+    const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = (int) ((words[j] >> (4 * i)) & 0xFu);
+            out[(size_t) ((r0 + j) * 8 + i) * width + n] = (f16) (q - z) * sc;
+        }
+}
+
+// GPTQ [R][N] words -> T16 pieces.  One thread = one destination piece.
+__global__ __launch_bounds__(256) void retile_t16_kernel(const uint32_t* __restrict__ src, uint4* __restrict__ dst, int RB,
+                                                         int width, size_t npieces)
+{
+    const size_t p = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (p >= npieces) return;
+    const int lane = (int) (p & 63);
+    const size_t trb = p >> 6;
+    const int rb = (int) (trb % RB), t = (int) (trb / RB);
+    const int n = t * 16 + (lane & 15);
+    const int r0 = rb * 16 + (lane >> 4) * 4;
+    uint4 v;
+    v.x = src[(size_t) (r0 + 0) * width + n];
+    v.y = src[(size_t) (r0 + 1) * width + n];
+    v.z = src[(size_t) (r0 + 2) * width + n];
+    v.w = src[(size_t) (r0 + 3) * width + n];
+    dst[p] = v;
+}
+
+int launch_retile_t16(Q4Matrix* m, hipStream_t s)
+{
+    const int R = m->height / 8;
+    const size_t wbytes = (size_t) R * m->width * sizeof(uint32_t);
+    uint32_t* tmp = nullptr;
+    EXL_HIP(hipMalloc((void**) &tmp, wbytes));
+    EXL_HIP(hipMemcpyAsync(tmp, m->qweight, wbytes, hipMemcpyDeviceToDevice, s));
+    const size_t npieces = wbytes / 16;
+    hipLaunchKernelGGL(retile_t16_kernel, dim3((unsigned) ((npieces + 255) / 256)), dim3(256), 0, s, tmp, (uint4*) m->qweight,
+                       R / 16, m->width, npieces);
+    EXL_LAUNCH_CHECK();
+    EXL_HIP(hipStreamSynchronize(s));
+    EXL_HIP(hipFree(tmp));
+    m->layout = EXL_LAYOUT_T16;
+    return 0;
+}
+
 int launch_reconstruct(const Q4Matrix* m, f16* out, hipStream_t s)
 {
+    if (m->layout == EXL_LAYOUT_T16) {
+        const size_t npieces = (size_t) (m->height / 8) * m->width / 4;
+        hipLaunchKernelGGL(reconstruct_t16_kernel, dim3((unsigned) ((npieces + 255) / 256)), dim3(256), 0, s,
+                           (const uint4*) m->qweight, out, m->scales, m->qzeros, m->height / 128, m->width, m->groupsize, npieces);
+        EXL_LAUNCH_CHECK();
+        return 0;
+    }
     const int n4 = m->width / 4;
     dim3 grid((n4 + 255) / 256, m->height / 8);
     hipLaunchKernelGGL(reconstruct_kernel, grid, dim3(256), 0, s, (const uint4*) m->qweight, out, m->scales,

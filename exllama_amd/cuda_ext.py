@@ -136,6 +136,9 @@ class _ExllamaExt:
         keys = ("device", "height", "width", "groups", "groupsize")
         d = {k: v.value for k, v in zip(keys, vals)}
         d["x_map"] = xm.value
+        lay = C.c_int()
+        check(self._lib.exl_q4_layout(w, C.byref(lay)), "q4_layout")
+        d["layout"] = lay.value          # 1: qweight was re-tiled in place into the T16 streaming layout
         return d
 
     def _check_mm(self, x, w, out):

@@ -81,6 +81,14 @@ int exl_free_q4(void* handle);
 /* Introspection used by tests: any out pointer may be NULL. x_map is the DEVICE pointer (uint32 [K]) or NULL. */
 int exl_q4_info(void* handle, int* device, int* height, int* width, int* groups, int* groupsize,
                 const uint32_t** x_map_dev);
+/* Weight layout the handle ended up with: EXL_LAYOUT_T16 (1) when height % 128 == 0, width % 16 == 0 and
+ * groupsize % 32 == 0 -- make_q4 then RE-TILES the caller's qweight tensor in place (same bytes, same buffer) into the
+ * 16-column-tile streaming layout documented in DESIGN.md ("T16"); otherwise EXL_LAYOUT_GPTQ (0), served by slower
+ * generic kernels.  Either way the tensor must not be interpreted by the caller after make_q4 (the reference already
+ * rewrites it for act-order weights, q4_matrix.cu:159). */
+#define EXL_LAYOUT_GPTQ 0
+#define EXL_LAYOUT_T16  1
+int exl_q4_layout(void* handle, int* layout);
 
 /* ---- q4 matmul: out[M,N] (+)= x[M,K] @ dequant(W)  (reference: exllama_ext.cpp:199-240 q4_matmul) ---- */
 /* Dispatch on the tuning threshold exactly like the reference: rows < matmul_recons_thd (or thd == 0)

@@ -74,13 +74,16 @@ def test_make_q4_and_reconstruct_bit_exact(ce, K, N, gs, act):
     ow = _oracle_w(lin)
     info = ce.exllama_ext.q4_info(h)
     assert (info["height"], info["width"], info["groups"], info["groupsize"]) == (K, N, K // gs, gs)
-    if act:
-        assert info["x_map"], "act-order weight must own a device x_map"
-        # in-place repack of the caller's qweight tensor (reference: q4_matrix.cu:159)
-        assert np.array_equal(d["qweight"].cpu().numpy().view(np.uint32), ow["qweight"])
+    assert bool(info["x_map"]) == act, "act-order weights (and only those) own a device x_map"
+    # the caller's qweight tensor is rewritten in place: act-order row repack (reference: q4_matrix.cu:159), then the
+    # product's T16 re-tiling for every shape it covers -- both integer-exact against the oracle
+    expect = ow["qweight"]
+    assert info["layout"] == int(O.t16_eligible(K, N, gs))
+    got = d["qweight"].cpu().numpy().view(np.uint32)
+    if info["layout"] == 1:
+        assert np.array_equal(got.reshape(-1), O.retile_t16(expect))
     else:
-        assert not info["x_map"]
-        assert np.array_equal(d["qweight"].cpu().numpy().view(np.uint32), lin["qweight"].numpy().view(np.uint32))
+        assert np.array_equal(got, expect)
     w16 = torch.empty((K, N), dtype=torch.float16, device=DEV)
     ce.exllama_ext.q4_reconstruct(h, w16)
     ref = O.dequant_w16(ow["qweight"], ow["qzeros"], ow["scales"])
@@ -95,7 +98,12 @@ def test_make_q4_golden_fixture(ce, golden_dir):
         sc = torch.from_numpy(g[f"q4{tag}_scales"].copy()).to(DEV)
         gi = torch.from_numpy(g[f"q4{tag}_g_idx"].copy())
         h = ce.ext_make_q4(qw, qz, sc, gi, 0)
-        assert np.array_equal(qw.cpu().numpy().view(np.uint32), g[f"q4{tag}_qweight_seq"])
+        seq = g[f"q4{tag}_qweight_seq"]
+        got = qw.cpu().numpy().view(np.uint32)
+        if ce.exllama_ext.q4_info(h)["layout"] == 1:
+            assert np.array_equal(got.reshape(-1), O.retile_t16(seq))
+        else:
+            assert np.array_equal(got, seq)
         x = torch.from_numpy(g[f"q4{tag}_x"].copy()).to(DEV)
         out = ce.ext_q4_matmul(x[:3], h, qw.shape[1])
         _close(out.cpu().numpy(), g[f"q4{tag}_out_gemv"])
