@@ -209,7 +209,10 @@ def main():
 
     # ---- dominant-kernel roofline: the q4 decode GEMV, timed per launch with HIP events on the launch stream --
     if rank == 0 and not args.no_roofline_probe:
-        result["roofline"] = gemv_roofline_probe(model, args.groupsize, dev)
+        if use_graph:
+            result["roofline"] = decoder_roofline_probe(model, cache, full, args.groupsize, S)
+        else:
+            result["roofline"] = gemv_roofline_probe(model, args.groupsize, dev)
     # ---- CPU baseline: the oracle ("port") on a bounded sample of the same workload ----------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(dims, args.groupsize)
@@ -219,6 +222,44 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def decoder_roofline_probe(model, cache, dims, g, ctx, steps=6):
+    """Per-kernel-class timing of the decode path itself: the native executor launched eagerly with a hipEvent between
+    consecutive kernels on the launch stream (exl_decoder_step_timed), at context `ctx`, averaged over `steps` tokens.
+    The dominant kernel is the fused gate/up projection (dec_gemv_kernel<..., PNORM=1, EMODE=2>): one launch streams the
+    packed gate and up matrices of one layer."""
+    h, I, L = dims.hidden_size, dims.intermediate_size, dims.num_hidden_layers
+    kvd = dims.num_key_value_heads * dims.head_dim
+    wbytes = lambda K, N: K * N / 2 + (K / g) * N * 2.5
+    cache.current_seq_len = ctx
+    tok = torch.zeros((1, 1), dtype=torch.int64, device=model.embed_weight.device)
+    ms = model.decoder_profile(tok, cache, steps=steps)
+    # algorithmic bytes per launch of each class (weights + activations in/out; attention: K and V rows of the context)
+    per_launch = {
+        "qkv": wbytes(h, h) + 2 * wbytes(h, kvd) + 2 * h + 2 * (h + 2 * kvd),
+        "attn": 2 * (ctx + 1) * kvd * 2 + 2 * (h + 2 * kvd),
+        "merge": 0,
+        "o_proj": wbytes(h, h) + 2 * h + 4 * h,
+        "gate_up": 2 * wbytes(h, I) + 2 * h + 2 * I,
+        "down": wbytes(I, h) + 2 * I + 4 * h,
+        "head": dims.vocab_size * h * 2 + 2 * h + 4 * dims.vocab_size,
+    }
+    classes = {}
+    for k, v in ms.items():
+        n = 1 if k == "head" else L
+        us = v * 1e3 / n
+        classes[k] = {"us_per_launch": round(us, 3), "GBps": round(per_launch[k] / us / 1e3, 1) if per_launch[k] else None}
+    dom = "gate_up"
+    achieved = per_launch[dom] / (ms[dom] / L / 1e3) / 1e9
+    return {"bound": "hbm", "kernel": "dec_stream_kernel<PNORM=1, EMODE=2> (fused RMSNorm + gate/up projections + SiLU*mul, one launch per layer)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None, "launches": L * steps, "avg_launch_us": round(ms[dom] * 1e3 / L, 3),
+            "algorithmic_bytes_per_launch": int(per_launch[dom]), "classes": classes,
+            "token_ms_sum_of_classes": round(sum(ms.values()), 4),
+            "note": "per class: %d passes over all %d layers' launches of that kernel, back to back between two HIP events on the "
+                    "launch stream (kernel + launch boundary), context %d; peak = 8.0 TB/s spec (6.29 TB/s measured copy => "
+                    "frac_of_measured = %.4f)" % (steps, L, ctx, achieved / 6290.0)}
 
 
 def gemv_roofline_probe(model, groupsize, dev, tokens=3):

@@ -22,6 +22,7 @@
 #include "gemv_t16.h"
 
 #include <vector>
+#include <stdlib.h>
 
 #define DEC_MAX_MATS 3
 #define DEC_ATT_MAX_KEYS 1024
@@ -59,31 +60,50 @@ __device__ __forceinline__ f16 silu_mul_f16(f16 x, f16 y)
 
 // PNORM: 0 plain vector, 1 RMSNorm(residual stream).  EMODE: 0 store fp16, 1 residual add, 2 silu(gate) * up pair.
 // NV = 8-half vectors of the activation per thread (K <= 4096 * NV).
-// Load order matters: the small L2-resident prologue loads (x, norm weight, scale/zero entries) are issued BEFORE the
-// streaming weight loads (loads return in order), and the weight loads are in flight while the block builds its
-// activation image in LDS.
+//
+// PERSISTENT: the grid is one block per CU (not one per tile).  A block builds its activation image in LDS ONCE, then
+// walks its share of the 16-column tiles; the 8 waves split the K range of each tile, and every wave keeps the loads of
+// its NEXT step (next pass of this tile, or first pass of the next tile, plus that tile's scale/zero entries) in flight
+// while it dequantises and multiplies the current one -- so after the start-up the weight stream never stops and the
+// only per-tile synchronisation is one barrier for the 8-way partial-sum reduction (double-buffered by tile parity).
+// Load order matters: the small L2-resident prologue loads (x, norm weight) are issued BEFORE the first weight loads
+// (loads return in order).
 template <int U, int NP, bool G16, int PNORM, int EMODE, int NV>
-__global__ __launch_bounds__(DEC_THREADS) void dec_gemv_kernel(const DecGemvArgs a)
+__global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int K = a.mat[0].K, R = a.mat[0].R;
-    uint4* xs = (uint4*) smem;                                       // [xs_images][R]
-    float* red = (float*) (smem + (size_t) a.xs_images * R * 16);    // [DEC_WAVES][16] + [DEC_WAVES]
-    f16* xlin = (f16*) (smem + (size_t) a.xs_images * R * 16 + (DEC_WAVES * 16 + DEC_WAVES) * sizeof(float));   // [K], act-order only
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    int b = blockIdx.x;
-    if ((gridDim.x & 7) == 0) { const int per = gridDim.x >> 3; b = (b & 7) * per + (b >> 3); }   // neighbours share an XCD L2
-    int mi = 0, tile = b;
+    constexpr int NSLOT = G16 ? (U * NP + 3) / 4 : 1;
     constexpr int WPT = EMODE == 2 ? DEC_WAVES / 2 : DEC_WAVES;      // waves per tile
-    if constexpr (EMODE == 2) {
-        mi = wave / WPT;                                             // waves 0-3: gate tile b, waves 4-7: up tile b
-    } else {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int K = a.mat[0].K, R = a.mat[0].R, RB = a.mat[0].RB;
+    uint4* xs = (uint4*) smem;                                       // [xs_images][R]
+    float* red = (float*) (smem + (size_t) a.xs_images * R * 16);    // [2][DEC_WAVES][16] + [DEC_WAVES]
+    constexpr int RED_FLOATS = 2 * DEC_WAVES * 16 + DEC_WAVES;
+    f16* xlin = (f16*) (smem + (size_t) a.xs_images * R * 16 + RED_FLOATS * sizeof(float));   // [K], act-order only
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rsub = lane >> 4;
+    const int nunits = a.tile_end[EMODE == 2 ? 0 : a.nmat - 1];
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int n_my = (nunits - b + nb - 1) / nb;
+    const bool remap = (nunits & 7) == 0 && (nb & 7) == 0;           // XCD x (= b % 8) walks one contiguous eighth of the tiles
+    const int per = nunits >> 3;
+    const int rb_lo = (wave % WPT) * a.rb_per_wave;
+    const int rb_hi = min(RB, rb_lo + a.rb_per_wave);
+
+    // unit i of this block -> (matrix, tile) of this wave
+    auto describe = [&](int i, int& mi, int& tile) {
+        const int v = b + i * nb;
+        const int g = remap ? (v & 7) * per + (v >> 3) : v;
+        mi = 0; tile = g;
+        if constexpr (EMODE == 2) {
+            mi = wave / WPT;                                         // waves 0-3: gate tile g, waves 4-7: up tile g
+        } else {
 #pragma unroll
-        for (int i = 0; i < DEC_MAX_MATS - 1; ++i)
-            if (mi == i && i + 1 < a.nmat && b >= a.tile_end[i]) { mi = i + 1; tile = b - a.tile_end[i]; }
-    }
-    const T16Matrix& m = a.mat[mi];
+            for (int k = 0; k < DEC_MAX_MATS - 1; ++k)
+                if (mi == k && k + 1 < a.nmat && g >= a.tile_end[k]) { mi = k + 1; tile = g - a.tile_end[k]; }
+        }
+    };
 
     // ---- 1. prologue loads ------------------------------------------------------------------------------------
     const int nvec = K >> 3;
@@ -97,14 +117,20 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_gemv_kernel(const DecGemvArgs
         xraw[i] = *(const uint4*) (src + ci * 8);
         if constexpr (PNORM == 1) wraw[i] = *(const uint4*) (a.norm_w + ci * 8);
     }
-    // ---- 2. weight stream -------------------------------------------------------------------------------------
-    T16Wave<U, NP, G16> w;
-    const int rb0 = (wave % WPT) * a.rb_per_wave;
-    w.init(m, tile, lane, rb0, min(m.RB, rb0 + a.rb_per_wave));
-    w.load_entries(m);
-    w.issue(m, 0);
+    // ---- 2. first unit's weight stream ----------------------------------------------------------------------
+    uint4 wv0[U], wv1[U];
+    uint32_t ep0[U], ep1[U];
+    uint32_t entA[NSLOT], entB[NSLOT];
+    T16Unit uA, uB;
+    int miA = 0, miB = 0, tileA = 0, tileB = 0;
+    float resA = 0.f, resB = 0.f;                                    // EMODE 1: residual value of this thread's column
+    describe(0, miA, tileA);
+    uA = t16_unit(a.mat[miA], tileA, lane, rb_lo, rb_hi);
+    if constexpr (G16) t16_unit_entries<NSLOT>(a.mat[miA], uA, rsub, entA);
+    if constexpr (EMODE == 1) { if (tid < 16) resA = (float) a.hid_io[tileA * 16 + tid]; }
+    t16_unit_issue<U, G16>(a.mat[miA], uA, 0, rsub, wv0, ep0);
 
-    // ---- 3. activation image --------------------------------------------------------------------------------
+    // ---- 3. activation image (once per block) ---------------------------------------------------------------
     f16x8 xv[NV];
     if constexpr (PNORM == 1) {
         float ss = 0.f;
@@ -113,18 +139,18 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_gemv_kernel(const DecGemvArgs
             const int idx = tid + i * DEC_THREADS;
             xv[i] = __builtin_bit_cast(f16x8, xraw[i]);
             if (idx < nvec) {
-                if (a.tok && a.hid_copy && blockIdx.x == 0) *(f16x8*) (a.hid_copy + idx * 8) = xv[i];
+                if (a.tok && a.hid_copy && b == 0) *(f16x8*) (a.hid_copy + idx * 8) = xv[i];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float f = (float) xv[i][j]; ss = fmaf(f, f, ss); }
             }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
-        if (lane == 0) red[DEC_WAVES * 16 + wave] = ss;
+        if (lane == 0) red[2 * DEC_WAVES * 16 + wave] = ss;
         __syncthreads();
         float total = 0.f;
 #pragma unroll
-        for (int i = 0; i < DEC_WAVES; ++i) total += red[DEC_WAVES * 16 + i];
+        for (int i = 0; i < DEC_WAVES; ++i) total += red[2 * DEC_WAVES * 16 + i];
         const f16 rm = (f16) (1.0f / sqrtf(total * (1.0f / (float) K) + a.eps));
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -136,41 +162,72 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_gemv_kernel(const DecGemvArgs
 #pragma unroll
         for (int i = 0; i < NV; ++i) xv[i] = __builtin_bit_cast(f16x8, xraw[i]);
     }
+    const bool gather = a.mat[0].x_map != nullptr;                   // all matrices of a launch agree (checked on the host)
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = tid + i * DEC_THREADS;
         if (idx < nvec) {
-            if (m.x_map) *(f16x8*) (xlin + idx * 8) = xv[i];
-            else         xs[idx] = t16_permute(__builtin_bit_cast(uint4, xv[i]));
+            if (gather) *(f16x8*) (xlin + idx * 8) = xv[i];
+            else        xs[idx] = t16_permute(__builtin_bit_cast(uint4, xv[i]));
         }
     }
     __syncthreads();
-    if (m.x_map) {                                                   // act-order: gather through this matrix' x_map
-        if (a.xs_images > 1) xs += (size_t) mi * R;                  // gate and up permute k differently: one image each
-        t16_stage_from_lds(xlin, m.x_map, R, xs, tid % (WPT * 64), WPT * 64);
+    if (gather) {                                                    // act-order: one image per distinct x_map
+        if (a.xs_images > 1) {                                       // EMODE 2: gate image built by waves 0-3, up image by 4-7
+            const int mi = wave / WPT;
+            t16_stage_from_lds(xlin, a.mat[mi].x_map, R, xs + (size_t) mi * R, tid % (WPT * 64), WPT * 64);
+        } else {
+            t16_stage_from_lds(xlin, a.mat[0].x_map, R, xs, tid, DEC_THREADS);
+        }
         __syncthreads();
     }
+    // EMODE 0 with several act-order matrices (q, k, v) shares ONE image only if they share the map; the host checks it.
 
-    // ---- 4. stream, dot, reduce -----------------------------------------------------------------------------
-    f32x4 c = {0.f, 0.f, 0.f, 0.f};
-    w.run(m, xs, c);
-    if (lane < 16) red[wave * 16 + lane] = c[0];
-    __syncthreads();
-    if (tid < 16) {
-        const int n = tile * 16 + tid;
-        if constexpr (EMODE == 2) {
-            float g = 0.f, u = 0.f;
-#pragma unroll
-            for (int i = 0; i < WPT; ++i) { g += red[i * 16 + tid]; u += red[(WPT + i) * 16 + tid]; }
-            a.out[0][n] = silu_mul_f16((f16) g, (f16) u);
-        } else {
-            float v = 0.f;
-#pragma unroll
-            for (int i = 0; i < DEC_WAVES; ++i) v += red[i * 16 + tid];
-            if constexpr (EMODE == 0) a.out[mi][n] = (f16) v;
-            else a.hid_io[n] = (f16) (v + (float) a.hid_io[n]);
-        }
+    // ---- 4. walk the tiles ----------------------------------------------------------------------------------
+#define DEC_BUF(k) (((k) & 1) ? wv1 : wv0)
+#define DEC_EP(k)  (((k) & 1) ? ep1 : ep0)
+#define DEC_UNIT_BODY(P, uC, miC, tileC, entC, resC, uN, miN, tileN, entN, resN)                                            \
+    {                                                                                                                       \
+        const int i = 2 * j + P;                                                                                            \
+        if (i >= n_my) break;                                                                                               \
+        const bool have_next = i + 1 < n_my;                                                                                \
+        if (have_next) { describe(i + 1, miN, tileN); uN = t16_unit(a.mat[miN], tileN, lane, rb_lo, rb_hi); }               \
+        const uint4* xrow = xs + (a.xs_images > 1 ? (size_t) miC * R : 0);                                                  \
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};                                                                                     \
+        _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                                                    \
+            if (p + 1 < NP) {                                                                                               \
+                if (uC.rb0 + (p + 1) * U < uC.rb1) t16_unit_issue<U, G16>(a.mat[miC], uC, p + 1, rsub, DEC_BUF(P * NP + p + 1), DEC_EP(P * NP + p + 1)); \
+            } else if (have_next) {                                                                                         \
+                if constexpr (G16) t16_unit_entries<NSLOT>(a.mat[miN], uN, rsub, entN);                                     \
+                if constexpr (EMODE == 1) { if (tid < 16) resN = (float) a.hid_io[tileN * 16 + tid]; }                      \
+                t16_unit_issue<U, G16>(a.mat[miN], uN, 0, rsub, DEC_BUF((P ^ 1) * NP), DEC_EP((P ^ 1) * NP));               \
+            }                                                                                                               \
+            if (uC.rb0 + p * U < uC.rb1) t16_unit_consume<U, G16, NSLOT>(uC, p, lane, DEC_BUF(P * NP + p), entC, DEC_EP(P * NP + p), xrow, c); \
+        }                                                                                                                   \
+        float* rp = red + P * DEC_WAVES * 16;                                                                               \
+        if (lane < 16) rp[wave * 16 + lane] = c[0];                                                                         \
+        __syncthreads();                                                                                                    \
+        if (tid < 16) {                                                                                                     \
+            const int n = tileC * 16 + tid;                                                                                 \
+            if constexpr (EMODE == 2) {                                                                                     \
+                float g = 0.f, u = 0.f;                                                                                     \
+                _Pragma("unroll") for (int k = 0; k < WPT; ++k) { g += rp[k * 16 + tid]; u += rp[(WPT + k) * 16 + tid]; }   \
+                a.out[0][n] = silu_mul_f16((f16) g, (f16) u);                                                               \
+            } else {                                                                                                        \
+                float v = 0.f;                                                                                              \
+                _Pragma("unroll") for (int k = 0; k < DEC_WAVES; ++k) v += rp[k * 16 + tid];                                \
+                if constexpr (EMODE == 0) a.out[miC][n] = (f16) v;                                                          \
+                else a.hid_io[n] = (f16) (v + resC);                                                                        \
+            }                                                                                                               \
+        }                                                                                                                   \
     }
+    for (int j = 0;; ++j) {
+        DEC_UNIT_BODY(0, uA, miA, tileA, entA, resA, uB, miB, tileB, entB, resB)
+        DEC_UNIT_BODY(1, uB, miB, tileB, entB, resB, uA, miA, tileA, entA, resA)
+    }
+#undef DEC_UNIT_BODY
+#undef DEC_BUF
+#undef DEC_EP
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -314,20 +371,29 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
 // K2b: merge the split-KV partials of one head -> fp16 attention output (the value the reference's ATen attention
 // rounds to fp16 before o_proj, model.py:407-409)
 // ---------------------------------------------------------------------------------------------------------------
+#define DEC_MAX_NSPLIT 8
 __global__ __launch_bounds__(128) void dec_attn_merge_kernel(const float* __restrict__ partial, f16* __restrict__ out, int nsplit)
 {
     const int h = blockIdx.x, d = threadIdx.x;
     const float* pp = partial + (size_t) h * nsplit * 130;
+    // every load up front, no data-dependent control flow: one L2 round trip instead of 2 * nsplit
+    float ms[DEC_MAX_NSPLIT], ls[DEC_MAX_NSPLIT], os[DEC_MAX_NSPLIT];
+#pragma unroll
+    for (int s = 0; s < DEC_MAX_NSPLIT; ++s) {
+        const int cs = s < nsplit ? s : 0;
+        ms[s] = pp[cs * 130 + 128];
+        ls[s] = pp[cs * 130 + 129];
+        os[s] = pp[cs * 130 + d];
+    }
     float M = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pp[s * 130 + 128]);
+#pragma unroll
+    for (int s = 0; s < DEC_MAX_NSPLIT; ++s) if (s < nsplit) M = fmaxf(M, ms[s]);
     float l = 0.f, o = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float ms = pp[s * 130 + 128];
-        if (ms > -INFINITY) {
-            const float w = __expf(ms - M);
-            l = fmaf(pp[s * 130 + 129], w, l);
-            o = fmaf(pp[s * 130 + d], w, o);
-        }
+#pragma unroll
+    for (int s = 0; s < DEC_MAX_NSPLIT; ++s) {
+        const float w = (s < nsplit && ms[s] > -INFINITY) ? __expf(ms[s] - M) : 0.f;
+        l = fmaf(ls[s], w, l);
+        o = fmaf(os[s], w, o);
     }
     out[h * 128 + d] = (f16) (o / l);
 }
@@ -408,6 +474,7 @@ struct Decoder {
     f16 *hid, *qbuf, *kbuf, *vbuf, *attn_out, *act;
     float* partial;
     int nsplit;
+    int max_blocks;               // persistent GEMV grid: blocks per CU x CUs
     void* block;                  // one hipMalloc
 };
 #define DEC_MAGIC 0x44454332u
@@ -434,8 +501,9 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     for (auto& l : d->layers) l.set = false;
     int ns = 256 / heads;
     if (ns < 1) ns = 1;
-    if (ns > 8) ns = 8;
+    if (ns > DEC_MAX_NSPLIT) ns = DEC_MAX_NSPLIT;
     while ((max_seq_len + ns - 1) / ns + 16 > DEC_ATT_MAX_KEYS) ++ns;
+    if (ns > DEC_MAX_NSPLIT) { delete d; EXL_FAIL(EXL_E_UNSUPPORTED, "decoder: max_seq_len %d too long (max %d)", max_seq_len, DEC_MAX_NSPLIT * (DEC_ATT_MAX_KEYS - 16)); }
     d->nsplit = ns;
     const int kvd = kv_heads * head_dim;
     size_t bytes = 0;
@@ -447,6 +515,8 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     int prev = 0;
     hipError_t e = hipGetDevice(&prev);
     if (e == hipSuccess) e = hipSetDevice(device);
+    int cus = 0;
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     if (e == hipSuccess) e = hipMalloc(&d->block, bytes);
     (void) hipSetDevice(prev);
     if (e != hipSuccess) { delete d; EXL_FAIL((int) e, "decoder_create: %s", hipGetErrorString(e)); }
@@ -454,6 +524,9 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     d->hid = (f16*) (b + o_hid); d->qbuf = (f16*) (b + o_q);
     d->kbuf = (f16*) (b + o_k); d->vbuf = (f16*) (b + o_v); d->attn_out = (f16*) (b + o_ao); d->act = (f16*) (b + o_act);
     d->partial = (float*) (b + o_p);
+    int bpc = 2;
+    if (const char* env = getenv("EXL_DEC_BLOCKS_PER_CU")) { bpc = atoi(env); if (bpc < 1) bpc = 1; if (bpc > 4) bpc = 4; }
+    d->max_blocks = (cus > 0 ? cus : 256) * bpc;
     *out = d;
     return 0;
 }
@@ -508,8 +581,8 @@ extern "C" int exl_decoder_free(void* dec)
 template <int PNORM, int EMODE, int NV>
 static int launch_dec_gemv_cfg(bool g16, int rbw, dim3 grid, size_t smem, hipStream_t s, const DecGemvArgs& a)
 {
-#define DEC_LAUNCH(U, NP) do { if (g16) hipLaunchKernelGGL((dec_gemv_kernel<U, NP, true, PNORM, EMODE, NV>), grid, dim3(DEC_THREADS), smem, s, a); \
-                               else     hipLaunchKernelGGL((dec_gemv_kernel<U, NP, false, PNORM, EMODE, NV>), grid, dim3(DEC_THREADS), smem, s, a); } while (0)
+#define DEC_LAUNCH(U, NP) do { if (g16) hipLaunchKernelGGL((dec_stream_kernel<U, NP, true, PNORM, EMODE, NV>), grid, dim3(DEC_THREADS), smem, s, a); \
+                               else     hipLaunchKernelGGL((dec_stream_kernel<U, NP, false, PNORM, EMODE, NV>), grid, dim3(DEC_THREADS), smem, s, a); } while (0)
     if (rbw <= 4)       DEC_LAUNCH(4, 1);
     else if (rbw <= 8)  DEC_LAUNCH(4, 2);
     else if (rbw <= 12) DEC_LAUNCH(6, 2);
@@ -520,7 +593,7 @@ static int launch_dec_gemv_cfg(bool g16, int rbw, dim3 grid, size_t smem, hipStr
 }
 
 // pnorm / emode as in dec_gemv_kernel.  mats: nmat matrices sharing K (emode 2: gate, up).
-static int launch_dec_gemv(int pnorm, int emode, const f16* vec, const int64_t* tok, const f16* norm_w, float eps, f16* hid_copy,
+static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec, const int64_t* tok, const f16* norm_w, float eps, f16* hid_copy,
                            int nmat, Q4Matrix* const* mats, f16* const* outs, f16* hid_io, hipStream_t s)
 {
     DecGemvArgs a;
@@ -548,10 +621,14 @@ static int launch_dec_gemv(int pnorm, int emode, const f16* vec, const int64_t* 
     for (int i = 1; i < nmat; ++i)
         EXL_REQUIRE((mats[i]->groupsize % 128 == 0) == g16 && mats[i]->height == K, EXL_E_UNSUPPORTED, "decoder: fused matrices must share K and group-size class");
     a.xs_images = (emode == 2 && any_map) ? 2 : 1;
-    const size_t smem = (size_t) a.xs_images * (K / 8) * 16 + (DEC_WAVES * 16 + DEC_WAVES) * sizeof(float) + (any_map ? (size_t) K * 2 : 0);
+    const size_t smem = (size_t) a.xs_images * (K / 8) * 16 + (2 * DEC_WAVES * 16 + DEC_WAVES) * sizeof(float) + (any_map ? (size_t) K * 2 : 0);
     EXL_REQUIRE(smem <= 64 * 1024, EXL_E_UNSUPPORTED, "decoder: activation stage (%zu bytes of LDS) exceeds 64 KiB", smem);
     const int nv = (K / 8 + DEC_THREADS - 1) / DEC_THREADS;
-    dim3 grid(tiles);
+    if (emode != 2)
+        for (int i = 1; i < nmat; ++i)
+            EXL_REQUIRE(mats[i]->x_map == nullptr && mats[0]->x_map == nullptr, EXL_E_UNSUPPORTED,
+                        "decoder: act-order matrices cannot share one launch (each needs its own activation gather)");
+    dim3 grid(tiles < max_blocks ? tiles : max_blocks);
 #define DEC_NV(P, E) (nv <= 1 ? launch_dec_gemv_cfg<P, E, 1>(g16, rbw, grid, smem, s, a) : nv <= 2 ? launch_dec_gemv_cfg<P, E, 2>(g16, rbw, grid, smem, s, a) \
                       : nv <= 3 ? launch_dec_gemv_cfg<P, E, 3>(g16, rbw, grid, smem, s, a) : launch_dec_gemv_cfg<P, E, 6>(g16, rbw, grid, smem, s, a))
     if (pnorm == 1 && emode == 0) return DEC_NV(1, 0);
@@ -559,6 +636,60 @@ static int launch_dec_gemv(int pnorm, int emode, const f16* vec, const int64_t* 
     if (pnorm == 0 && emode == 1) return DEC_NV(0, 1);
 #undef DEC_NV
     EXL_FAIL(EXL_E_INVALID, "decoder: unsupported kernel combination");
+}
+
+// One kernel class of one layer (EXL_DEC_* in include/exl_amd.h); EXL_DEC_HEAD ignores `i`.
+static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int32_t* pos_dev, float* logits_out, int advance,
+                      hipStream_t s)
+{
+    const DecLayer& l = d->layers[cls == EXL_DEC_HEAD ? 0 : i];
+    switch (cls) {
+    case EXL_DEC_QKV: {
+        Q4Matrix* qkv[3] = {l.q, l.k, l.v};
+        f16* qkv_out[3] = {d->qbuf, d->kbuf, d->vbuf};
+        const f16* xin = i == 0 ? d->embed : d->hid;
+        const int64_t* tk = i == 0 ? token_dev : nullptr;
+        f16* hc = i == 0 ? d->hid : nullptr;
+        if (!l.q->x_map && !l.k->x_map && !l.v->x_map)
+            return launch_dec_gemv(d->max_blocks, 1, 0, xin, tk, l.in_norm, d->eps, hc, 3, qkv, qkv_out, nullptr, s);
+        for (int k = 0; k < 3; ++k)                                  // act-order: every matrix gathers x through its own map
+            EXL_TRY(launch_dec_gemv(d->max_blocks, 1, 0, xin, tk, l.in_norm, d->eps, k == 0 ? hc : nullptr, 1, qkv + k, qkv_out + k, nullptr, s));
+        return 0;
+    }
+    case EXL_DEC_ATTN:
+        hipLaunchKernelGGL(dec_attn_kernel, dim3(d->nsplit, d->heads), dim3(256), 0, s, d->qbuf, d->kbuf, d->vbuf, l.kc, l.vc,
+                           d->sin, d->cos, d->partial, pos_dev, d->heads, d->kv_heads, d->max_seq, d->nsplit,
+                           1.0f / sqrtf((float) d->hd));
+        EXL_LAUNCH_CHECK();
+        return 0;
+    case EXL_DEC_MERGE:
+        hipLaunchKernelGGL(dec_attn_merge_kernel, dim3(d->heads), dim3(128), 0, s, d->partial, d->attn_out, d->nsplit);
+        EXL_LAUNCH_CHECK();
+        return 0;
+    case EXL_DEC_O: {
+        Q4Matrix* om[1] = {l.o};
+        return launch_dec_gemv(d->max_blocks, 0, 1, d->attn_out, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s);
+    }
+    case EXL_DEC_GATE_UP: {
+        Q4Matrix* gu[2] = {l.gate, l.up};
+        f16* gu_out[2] = {d->act, nullptr};
+        return launch_dec_gemv(d->max_blocks, 1, 2, d->hid, nullptr, l.post_norm, d->eps, nullptr, 2, gu, gu_out, nullptr, s);
+    }
+    case EXL_DEC_DOWN: {
+        Q4Matrix* dm[1] = {l.down};
+        return launch_dec_gemv(d->max_blocks, 0, 1, d->act, nullptr, nullptr, 0.f, nullptr, 1, dm, nullptr, d->hid, s);
+    }
+    case EXL_DEC_HEAD: {
+        const int rows_per_block = 32;
+        const int blocks = (d->vocab + rows_per_block - 1) / rows_per_block;
+        const size_t smem = (size_t) d->h * 2 + 8 * sizeof(float);
+        hipLaunchKernelGGL(dec_head_kernel, dim3(blocks), dim3(256), smem, s, d->hid, d->final_norm, d->eps, d->h, d->lm_head,
+                           d->vocab, logits_out, rows_per_block, pos_dev, advance);
+        EXL_LAUNCH_CHECK();
+        return 0;
+    }
+    }
+    EXL_FAIL(EXL_E_INVALID, "decoder: unknown kernel class %d", cls);
 }
 
 extern "C" int exl_decoder_step(void* dec, const int64_t* token_dev, int32_t* pos_dev, float* logits_out, int advance,
@@ -572,38 +703,50 @@ extern "C" int exl_decoder_step(void* dec, const int64_t* token_dev, int32_t* po
     int prev = 0;
     EXL_HIP(hipGetDevice(&prev));
     if (prev != d->device) EXL_HIP(hipSetDevice(d->device));
-    const float scale = 1.0f / sqrtf((float) d->hd);
     int rc = 0;
-    for (int i = 0; i < d->L && rc == 0; ++i) {
-        const DecLayer& l = d->layers[i];
-        Q4Matrix* qkv[3] = {l.q, l.k, l.v};
-        f16* qkv_out[3] = {d->qbuf, d->kbuf, d->vbuf};
-        if (i == 0) rc = launch_dec_gemv(1, 0, d->embed, token_dev, l.in_norm, d->eps, d->hid, 3, qkv, qkv_out, nullptr, s);
-        else        rc = launch_dec_gemv(1, 0, d->hid, nullptr, l.in_norm, d->eps, nullptr, 3, qkv, qkv_out, nullptr, s);
+    for (int i = 0; i < d->L && rc == 0; ++i)
+        for (int cls = EXL_DEC_QKV; cls <= EXL_DEC_DOWN && rc == 0; ++cls)
+            rc = dec_launch(d, cls, i, token_dev, pos_dev, logits_out, advance, s);
+    if (rc == 0) rc = dec_launch(d, EXL_DEC_HEAD, 0, token_dev, pos_dev, logits_out, advance, s);
+    if (prev != d->device) (void) hipSetDevice(prev);
+    return rc;
+}
+
+// Measurement aid: for each kernel class, `reps` passes over ALL layers' launches of that class back to back (so the
+// weights stream from HBM exactly as in a real step: one pass touches every layer's matrices once) between two events on
+// `stream`.  class_ms_host[c] = mean time of one pass (= that class' share of one token).  The data flowing through is
+// whatever the buffers hold; the K/V slot at *pos_dev is overwritten.  Synchronises.
+extern "C" int exl_decoder_step_timed(void* dec, const int64_t* token_dev, int32_t* pos_dev, float* logits_out, int reps,
+                                      void* stream, float* class_ms_host)
+{
+    Decoder* d = dec_from(dec);
+    EXL_REQUIRE(d && class_ms_host && token_dev && pos_dev && logits_out, EXL_E_INVALID, "decoder_step_timed: invalid argument");
+    for (const DecLayer& l : d->layers) EXL_REQUIRE(l.set, EXL_E_INVALID, "decoder_step_timed: a layer was not set");
+    if (reps < 1) reps = 1;
+    hipStream_t s = (hipStream_t) stream;
+    int prev = 0;
+    EXL_HIP(hipGetDevice(&prev));
+    if (prev != d->device) EXL_HIP(hipSetDevice(d->device));
+    hipEvent_t e0, e1;
+    EXL_HIP(hipEventCreate(&e0));
+    EXL_HIP(hipEventCreate(&e1));
+    int rc = 0;
+    for (int cls = 0; cls < EXL_DEC_NCLASS && rc == 0; ++cls) {
+        const int nl = cls == EXL_DEC_HEAD ? 1 : d->L;
+        for (int i = 0; i < nl && rc == 0; ++i) rc = dec_launch(d, cls, i, token_dev, pos_dev, logits_out, 0, s);   // warm-up pass
         if (rc) break;
-        hipLaunchKernelGGL(dec_attn_kernel, dim3(d->nsplit, d->heads), dim3(256), 0, s, d->qbuf, d->kbuf, d->vbuf, l.kc, l.vc,
-                           d->sin, d->cos, d->partial, pos_dev, d->heads, d->kv_heads, d->max_seq, d->nsplit, scale);
-        hipLaunchKernelGGL(dec_attn_merge_kernel, dim3(d->heads), dim3(128), 0, s, d->partial, d->attn_out, d->nsplit);
-        { hipError_t e = hipGetLastError(); if (e != hipSuccess) { exl_set_error("decoder attn launch: %s", hipGetErrorString(e)); rc = (int) e; break; } }
-        Q4Matrix* om[1] = {l.o};
-        rc = launch_dec_gemv(0, 1, d->attn_out, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s);
-        if (rc) break;
-        Q4Matrix* gu[2] = {l.gate, l.up};
-        f16* gu_out[2] = {d->act, nullptr};
-        rc = launch_dec_gemv(1, 2, d->hid, nullptr, l.post_norm, d->eps, nullptr, 2, gu, gu_out, nullptr, s);
-        if (rc) break;
-        Q4Matrix* dm[1] = {l.down};
-        rc = launch_dec_gemv(0, 1, d->act, nullptr, nullptr, 0.f, nullptr, 1, dm, nullptr, d->hid, s);
+        (void) hipEventRecord(e0, s);
+        for (int r = 0; r < reps && rc == 0; ++r)
+            for (int i = 0; i < nl && rc == 0; ++i) rc = dec_launch(d, cls, i, token_dev, pos_dev, logits_out, 0, s);
+        (void) hipEventRecord(e1, s);
+        hipError_t e = hipEventSynchronize(e1);
+        if (rc == 0 && e != hipSuccess) { exl_set_error("decoder_step_timed: %s", hipGetErrorString(e)); rc = (int) e; }
+        float ms = 0.f;
+        if (rc == 0) (void) hipEventElapsedTime(&ms, e0, e1);
+        class_ms_host[cls] = ms / (float) reps;
     }
-    if (rc == 0) {
-        const int rows_per_block = 32;
-        const int blocks = (d->vocab + rows_per_block - 1) / rows_per_block;
-        const size_t smem = (size_t) d->h * 2 + 8 * sizeof(float);
-        hipLaunchKernelGGL(dec_head_kernel, dim3(blocks), dim3(256), smem, s, d->hid, d->final_norm, d->eps, d->h, d->lm_head,
-                           d->vocab, logits_out, rows_per_block, pos_dev, advance);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { exl_set_error("decoder head launch: %s", hipGetErrorString(e)); rc = (int) e; }
-    }
+    (void) hipEventDestroy(e0);
+    (void) hipEventDestroy(e1);
     if (prev != d->device) (void) hipSetDevice(prev);
     return rc;
 }

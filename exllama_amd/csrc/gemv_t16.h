@@ -80,8 +80,8 @@ struct T16Wave {
     static_assert(U * NP <= 4 * T16_EH, "too many row-blocks per wave");
     const uint4* base;
     int rb0, rb1, rbsafe, col, rsub, n;
-    uint32_t ent[G16 ? T16_EH : U];
-    uint4 wv[U];
+    uint32_t ent[G16 ? T16_EH : 2 * U];     // !G16: per-piece entries, double-buffered with the pieces
+    uint4 wv[2][U];                          // double buffer: pass p lives in wv[p & 1]
 
     __device__ __forceinline__ void init(const T16Matrix& m, int t, int lane, int rb_begin, int rb_end)
     {
@@ -110,8 +110,8 @@ struct T16Wave {
         for (int i = 0; i < U; ++i) {
             const int rb = rb0 + pass * U + i;
             const int rbc = rb < rb1 ? rb : rbsafe;                    // clamped: always a valid address
-            if constexpr (!G16) ent[i] = t16_load_entry(m, t16_group_of_row(m, rbc * 16 + rsub * 4), n);
-            wv[i] = nt_load16(base + (size_t) rbc * 64);
+            if constexpr (!G16) ent[(pass & 1) * U + i] = t16_load_entry(m, t16_group_of_row(m, rbc * 16 + rsub * 4), n);
+            wv[pass & 1][i] = nt_load16(base + (size_t) rbc * 64);
         }
     }
     // xrow: LDS activation image (permuted 8-half groups per packed row) of the activation row this lane feeds to the
@@ -126,7 +126,7 @@ struct T16Wave {
             if (rb < rb1) {                                             // wave-uniform
                 uint32_t e;
                 if constexpr (G16) e = (uint32_t) __shfl((int) ent[li >> 2], ((li & 3) << 4) | col, 64);
-                else e = ent[i];
+                else e = ent[(pass & 1) * U + i];
                 const f16 sc = __builtin_bit_cast(f16, (uint16_t) (e & 0xFFFFu));
                 const f16 za = (f16) (float) (-(1024 + (int) (e >> 16)));
                 const f16x2 s2 = {sc, sc};
@@ -134,23 +134,21 @@ struct T16Wave {
                 const f16x2 zc1 = zc0 + c960;
                 const int r = rb * 16 + rsub * 4;
                 const uint4 x0 = xrow[r], x1 = xrow[r + 1], x2 = xrow[r + 2], x3 = xrow[r + 3];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x0), t16_dequant(wv[i].x, zc0, zc1, s2), c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x1), t16_dequant(wv[i].y, zc0, zc1, s2), c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x2), t16_dequant(wv[i].z, zc0, zc1, s2), c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x3), t16_dequant(wv[i].w, zc0, zc1, s2), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x0), t16_dequant(wv[pass & 1][i].x, zc0, zc1, s2), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x1), t16_dequant(wv[pass & 1][i].y, zc0, zc1, s2), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x2), t16_dequant(wv[pass & 1][i].z, zc0, zc1, s2), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x3), t16_dequant(wv[pass & 1][i].w, zc0, zc1, s2), c, 0, 0, 0);
             }
         }
     }
-    // all passes; the loads of pass 0 must already be in flight (issued ahead of the block's prologue)
+    // all passes; the loads of pass 0 must already be in flight (issued ahead of the block's prologue).  Software
+    // pipeline: pass p + 1 is issued into the other buffer before pass p is consumed.
     __device__ __forceinline__ void run(const T16Matrix& m, const uint4* xrow, f32x4& c)
     {
-        consume(0, xrow, c);
 #pragma unroll
-        for (int p = 1; p < NP; ++p) {
-            if (rb0 + p * U < rb1) {                                    // wave-uniform
-                issue(m, p);
-                consume(p, xrow, c);
-            }
+        for (int p = 0; p < NP; ++p) {
+            if (p + 1 < NP && rb0 + (p + 1) * U < rb1) issue(m, p + 1);     // wave-uniform
+            if (rb0 + p * U < rb1) consume(p, xrow, c);
         }
     }
 };
@@ -173,5 +171,79 @@ __device__ __forceinline__ void t16_stage_from_lds(const f16* xlin, const uint32
             v = *(const uint4*) (xlin + k);
         }
         xs[idx] = t16_permute(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Explicit-buffer form of the same streaming steps, for the persistent decode kernel (decode_fused.hip), which keeps
+// the loads of the NEXT work unit in flight while the current one is consumed.
+// ---------------------------------------------------------------------------------------------------------------
+struct T16Unit {                    // one wave's share of one 16-column tile
+    const uint4* base;              // tile base + lane
+    int rb0, rb1, rbsafe;           // row-block range [rb0, rb1); rbsafe: a valid row-block for clamped addresses
+    int n;                          // this lane's column
+};
+
+__device__ __forceinline__ T16Unit t16_unit(const T16Matrix& m, int t, int lane, int rb_begin, int rb_end)
+{
+    T16Unit u;
+    u.base = m.qw + (size_t) t * m.RB * 64 + lane;
+    u.rb0 = rb_begin; u.rb1 = rb_end < rb_begin ? rb_begin : rb_end;
+    u.rbsafe = min(rb_begin, m.RB - 1);
+    u.n = t * 16 + (lane & 15);
+    return u;
+}
+
+// G16 entries of a unit: slot h holds the entry of row-block rb0 + 4h + rsub
+template <int NSLOT>
+__device__ __forceinline__ void t16_unit_entries(const T16Matrix& m, const T16Unit& u, int rsub, uint32_t (&ent)[NSLOT])
+{
+#pragma unroll
+    for (int h = 0; h < NSLOT; ++h) {
+        const int rb = min(u.rb0 + 4 * h + rsub, m.RB - 1);
+        ent[h] = (u.rb0 + 4 * h < u.rb1) ? t16_load_entry(m, t16_group_of_row(m, rb * 16), u.n) : 0u;
+    }
+}
+
+template <int U, bool G16>
+__device__ __forceinline__ void t16_unit_issue(const T16Matrix& m, const T16Unit& u, int pass, int rsub, uint4 (&wv)[U],
+                                               uint32_t (&entp)[U])
+{
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int rb = u.rb0 + pass * U + i;
+        const int rbc = rb < u.rb1 ? rb : u.rbsafe;
+        if constexpr (!G16) entp[i] = t16_load_entry(m, t16_group_of_row(m, rbc * 16 + rsub * 4), u.n);
+        wv[i] = nt_load16(u.base + (size_t) rbc * 64);
+    }
+}
+
+template <int U, bool G16, int NSLOT>
+__device__ __forceinline__ void t16_unit_consume(const T16Unit& u, int pass, int lane, const uint4 (&wv)[U],
+                                                 const uint32_t (&ent)[NSLOT], const uint32_t (&entp)[U], const uint4* xrow,
+                                                 f32x4& c)
+{
+    const f16x2 c960 = {(f16) 960.f, (f16) 960.f};
+    const int col = lane & 15, rsub = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int li = pass * U + i;
+        const int rb = u.rb0 + li;
+        if (rb < u.rb1) {                                               // wave-uniform
+            uint32_t e;
+            if constexpr (G16) e = (uint32_t) __shfl((int) ent[(li >> 2) < NSLOT ? (li >> 2) : 0], ((li & 3) << 4) | col, 64);
+            else e = entp[i];
+            const f16 sc = __builtin_bit_cast(f16, (uint16_t) (e & 0xFFFFu));
+            const f16 za = (f16) (float) (-(1024 + (int) (e >> 16)));
+            const f16x2 s2 = {sc, sc};
+            const f16x2 zc0 = {za, za};
+            const f16x2 zc1 = zc0 + c960;
+            const int r = rb * 16 + rsub * 4;
+            const uint4 x0 = xrow[r], x1 = xrow[r + 1], x2 = xrow[r + 2], x3 = xrow[r + 3];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x0), t16_dequant(wv[i].x, zc0, zc1, s2), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x1), t16_dequant(wv[i].y, zc0, zc1, s2), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x2), t16_dequant(wv[i].z, zc0, zc1, s2), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x3), t16_dequant(wv[i].w, zc0, zc1, s2), c, 0, 0, 0);
+        }
     }
 }

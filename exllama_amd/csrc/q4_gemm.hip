@@ -18,6 +18,7 @@
 // Act-order weights: x is gathered through x_map by column_remap into the borrowed temp_state buffer first
 // (same as the reference, q4_matmul.cu:320-325); folding the gather into the A-tile load is future work.
 #include "common.h"
+#include <stdlib.h>
 
 #define MAGIC_1024 0x64006400u
 #define BM 128
@@ -226,6 +227,179 @@ __global__ __launch_bounds__(256) void q4_gemm_kernel(const f16* __restrict__ x,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// T16 layout, LDS-staged B: the prefill kernel of the product path.
+//
+//   * block tile 128(M) x 128(N), K step 64, 256 threads = 4 waves as 2(M) x 2(N), each wave 64 x 64 =
+//     4 x 4 tiles of v_mfma_f32_16x16x32_f16, fp32 accumulate (64 accumulator registers);
+//   * activations: global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip), 128-byte rows XOR-swizzled
+//     through the per-lane SOURCE address (the LDS image of a DMA is lane-linear), so the fragment reads
+//     (ds_read_b128, 16 rows x 4 k-chunks per wave) are bank-conflict free;
+//   * weights: each thread loads ONE 16-byte T16 piece per K step (4 packed rows = 32 k of one column; 32 lanes read
+//     512 contiguous bytes), expands it ONCE per block to 32 fp16 values h(h(q - z) * s) -- bit-identical to the
+//     reference's reconstruct (q4_matrix.cu:207) -- un-permutes the nibble-pair order with 4 v_perm per word and writes
+//     64 bytes of the swizzled [n][k] LDS tile.  The dequantisation cost is paid once per 128 rows of M instead of once
+//     per wave as in the register-B kernel above;
+//   * double-buffered LDS (64 KiB per block, 2 blocks per CU): tile t+1 is staged while tile t feeds the MFMAs, one
+//     barrier per K step;
+//   * MFMA roles are swapped (A operand = weights, B operand = activations) so that a lane ends up with 4 CONSECUTIVE
+//     output columns of one row: 8-byte stores instead of 2-byte ones;
+//   * blocks of one XCD walk the m-tiles of the same weight column tile first (weights are pulled from HBM once per
+//     XCD L2, not once per m-tile).
+// ---------------------------------------------------------------------------------------------------------------
+#define GT_BM 128
+#define GT_BN 128
+#define GT_BK 64
+#define GT_TILE_BYTES (128 * 64 * 2)
+
+// byte offset of the 16-byte chunk c (8 halves) of row r in a swizzled [128][64] fp16 tile
+__device__ __forceinline__ int gt_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
+
+__global__ __launch_bounds__(256, 2) void q4_gemm_t16_kernel(const f16* __restrict__ x, const uint4* __restrict__ qw,
+                                                             const uint32_t* __restrict__ qzeros,
+                                                             const f16* __restrict__ scales, f16* __restrict__ out, int M,
+                                                             int K, int N, int gshift, int groupsize, int no_zero, int mtiles,
+                                                             int ntiles)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * GT_TILE_BYTES];       // [buf][A | B]
+
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int idx = b >> 3;
+    const int nl = idx / mtiles;
+    const int mt = idx - nl * mtiles;
+    const int nt = nl * 8 + xcd;
+    if (nt >= ntiles) return;
+    const int m0 = mt * GT_BM;
+    const int n0 = nt * GT_BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int RB = K >> 7;
+    const int nk = K / GT_BK;
+
+    // ---- A staging (LDS-DMA): 16 pieces of 1 KiB per tile, 4 per wave; piece c = rows 8c .. 8c+7 ---------------------
+    const f16* a_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = wave * 4 + i;
+        const int row = c * 8 + (lane >> 3);
+        const int slot = lane & 7;
+        const int grow = min(m0 + row, M - 1);                       // rows past M re-read the last row (never stored)
+        a_src[i] = x + (size_t) grow * K + ((slot ^ (row & 7)) << 3);
+    }
+    auto stage_a = [&](int buf, int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __attribute__((address_space(3))) unsigned char* dst =
+                (__attribute__((address_space(3))) unsigned char*) (lds + (size_t) buf * 2 * GT_TILE_BYTES + (wave * 4 + i) * 1024);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (a_src[i] + k0), dst, 16, 0, 0);
+        }
+    };
+
+    // ---- B staging: thread -> one T16 piece per K step --------------------------------------------------------------
+    const int b_tile = tid >> 5;                                      // 16-column tile within the block (0..7)
+    const int b_rs = (tid >> 4) & 1;                                  // which 32-k half of the K step
+    const int b_col = tid & 15;
+    const int b_nloc = b_tile * 16 + b_col;                           // row of the LDS B tile
+    const int b_n = min(n0 + b_nloc, N - 1);                          // clamped column (a partial last n-tile is never stored)
+    const uint4* b_src = qw + ((size_t) (b_n >> 4) * RB) * 64 + (b_n & 15);
+    const int b_zsh = (b_n & 7) * 4;
+    uint4 breg;
+    uint32_t bzw;
+    f16 bsc;
+    auto issue_b = [&](int it) {
+        const int rb = it >> 1, rsub = (it & 1) * 2 + b_rs;
+        breg = b_src[(size_t) rb * 64 + rsub * 16];
+        const int k = it * GT_BK + b_rs * 32;
+        const int grp = gshift >= 0 ? (k >> gshift) : (k / groupsize);
+        bzw = qzeros[(size_t) grp * (N >> 3) + (b_n >> 3)];
+        bsc = scales[(size_t) grp * N + b_n];
+    };
+    auto store_b = [&](int buf) {
+        const int z = (int) ((bzw >> b_zsh) & 0xFu) + 1;
+        const f16 za = (f16) (float) (-(1024 + z));
+        const f16 zb = (f16) (float) (-(64 + z));
+        const f16x2 zc0 = {za, za}, zc1 = {zb, zb}, s2 = {bsc, bsc};
+        unsigned char* base = lds + (size_t) buf * 2 * GT_TILE_BYTES + GT_TILE_BYTES;
+        const uint32_t words[4] = {breg.x, breg.y, breg.z, breg.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f16x8 d = dequant_word(words[j], zc0, zc1, s2);       // (q0,q4,q1,q5,q2,q6,q3,q7)
+            const uint4 u = __builtin_bit_cast(uint4, d);
+            uint4 o;                                                    // -> natural k order (q0..q7)
+            o.x = __builtin_amdgcn_perm(u.y, u.x, 0x05040100u);         // (q0, q1)
+            o.y = __builtin_amdgcn_perm(u.w, u.z, 0x05040100u);         // (q2, q3)
+            o.z = __builtin_amdgcn_perm(u.y, u.x, 0x07060302u);         // (q4, q5)
+            o.w = __builtin_amdgcn_perm(u.w, u.z, 0x07060302u);         // (q6, q7)
+            *(uint4*) (base + gt_off(b_nloc, b_rs * 4 + j)) = o;
+        }
+    };
+
+    f32x4 acc[4][4];                                                    // [n-tile][m-tile]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    stage_a(0, 0);
+    issue_b(0);
+    store_b(0);
+    __syncthreads();
+
+    const int fr = lane & 15, fk = lane >> 4;
+    for (int it = 0; it < nk; ++it) {
+        const int cur = it & 1;
+        const bool more = it + 1 < nk;
+        if (more) {
+            stage_a(cur ^ 1, (it + 1) * GT_BK);
+            issue_b(it + 1);
+        }
+        const unsigned char* at = lds + (size_t) cur * 2 * GT_TILE_BYTES;
+        const unsigned char* bt = at + GT_TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f16x8 xf[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xf[i] = *(const f16x8*) (at + gt_off(wm * 64 + i * 16 + fr, kk * 4 + fk));
+                wf[i] = *(const f16x8*) (bt + gt_off(wn * 64 + i * 16 + fr, kk * 4 + fk));
+            }
+#pragma unroll
+            for (int in = 0; in < 4; ++in)
+#pragma unroll
+                for (int im = 0; im < 4; ++im)
+                    acc[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[in], xf[im], acc[in][im], 0, 0, 0);
+        }
+        if (more) store_b(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds D[n = 4 * fk + j][m = fr] of each 16 x 16 tile: 4 consecutive columns of one row -----------
+#pragma unroll
+    for (int im = 0; im < 4; ++im) {
+        const int row = m0 + wm * 64 + im * 16 + fr;
+        if (row < M) {
+#pragma unroll
+            for (int in = 0; in < 4; ++in) {
+                const int n = n0 + wn * 64 + in * 16 + fk * 4;
+                if (n < N) {
+                    f16* op = out + (size_t) row * N + n;
+                    float v[4] = {acc[in][im][0], acc[in][im][1], acc[in][im][2], acc[in][im][3]};
+                    if (no_zero) {
+                        const f16x4 prev = *(const f16x4*) op;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += (float) prev[j];
+                    }
+                    *(f16x4*) op = (f16x4){(f16) v[0], (f16) v[1], (f16) v[2], (f16) v[3]};
+                }
+            }
+        }
+    }
+}
+
 int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_zero, f16* remap_tmp,
                    size_t remap_tmp_numel, hipStream_t s)
 {
@@ -246,7 +420,11 @@ int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
     const int mtiles = (rows + BM - 1) / BM;
     const int ntiles = (N + BN - 1) / BN;
     const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
-    if (w->layout == EXL_LAYOUT_T16)
+    static const bool use_reg_b = getenv("EXL_GEMM_REGISTER_B") != nullptr;     // A/B switch for measurements
+    if (w->layout == EXL_LAYOUT_T16 && !use_reg_b)
+        hipLaunchKernelGGL(q4_gemm_t16_kernel, dim3(grid), dim3(256), 0, s, xin, (const uint4*) w->qweight, w->qzeros, w->scales, out,
+                           rows, K, N, gshift, w->groupsize, no_zero, mtiles, ntiles);
+    else if (w->layout == EXL_LAYOUT_T16)
         hipLaunchKernelGGL(q4_gemm_kernel<true>, dim3(grid), dim3(256), 0, s, xin, w->qweight, w->qzeros, w->scales, out, rows, K,
                            N, gshift, w->groupsize, no_zero, mtiles, ntiles);
     else

@@ -316,7 +316,7 @@ static int launch_t16_cfg(int rbw, dim3 grid, size_t smem, hipStream_t s, const 
 {
 #define T16_LAUNCH(U, NP) hipLaunchKernelGGL((q4_gemv_t16_kernel<U, NP, G16, MR>), grid, dim3(T16_WAVES * 64), smem, s, m, x, out, rows, no_zero, rbw, xstride)
     if (rbw <= 4)       T16_LAUNCH(4, 1);
-    else if (rbw <= 8)  T16_LAUNCH(4, 2);
+    else if (rbw <= 8)  T16_LAUNCH(8, 1);
     else if (rbw <= 12) T16_LAUNCH(6, 2);
     else                T16_LAUNCH(6, 4);
 #undef T16_LAUNCH

@@ -665,6 +665,26 @@ class ExLlama:
         st["dev_pos"] = cache.current_seq_len
         return _move_tensor(st["logits"].clone(), output_device, "logits", self.config)
 
+    DECODER_CLASSES = ("qkv", "attn", "merge", "o_proj", "gate_up", "down", "head")
+
+    def decoder_profile(self, input_ids, cache, steps=4):
+        """Measurement aid for bench.py: per kernel class of the native executor, `steps` passes over all layers' launches
+        of that class back to back between two hipEvents (include/exl_amd.h: exl_decoder_step_timed), at the cache's current
+        position (not advanced; the K/V slot there is overwritten).  Returns {class: ms per token} for DECODER_CLASSES."""
+        import ctypes as C
+        st = self._decoder
+        if st is None or st["cache"] is not cache:
+            raise RuntimeError("decoder_profile needs enable_decode_graph(cache) first")
+        st["tok"].copy_(input_ids.view(1, 1))
+        st["pos"].fill_(cache.current_seq_len)
+        st["dev_pos"] = -1
+        buf = (C.c_float * len(self.DECODER_CLASSES))()
+        with cuda_ext._Guard(st["dev"]):
+            stream = torch.cuda.current_stream(st["dev"]).cuda_stream
+            cuda_ext.check(ext._lib.exl_decoder_step_timed(st["handle"], st["tok"].data_ptr(), st["pos"].data_ptr(),
+                                                           st["logits"].data_ptr(), int(steps), stream, buf), "decoder_step_timed")
+        return {k: float(buf[j]) for j, k in enumerate(self.DECODER_CLASSES)}
+
     def disable_decode_graph(self):
         st = getattr(self, "_decoder", None)
         if st is not None:

@@ -171,9 +171,23 @@ int exl_decoder_set_layer(void* decoder, int index, void* q, void* k, void* v, v
                           void* down, const void* in_norm, const void* post_norm, void* key_cache, void* value_cache);
 /* One token: reads the token id (int64) and the position (int32) from DEVICE memory, appends K/V at that position,
  * writes fp32 logits [vocab]; when advance != 0 the device position is incremented at the end of the step.
- * 5 kernels per layer + 1, no allocation, no synchronisation: capturable in a hipGraph. */
+ * 6 kernels per layer + 1, no allocation, no synchronisation: capturable in a hipGraph. */
 int exl_decoder_step(void* decoder, const int64_t* token_dev, int32_t* pos_dev, float* logits_out, int advance,
                      void* stream);
+/* Measurement aid (bench.py): for each kernel class, `reps` passes over all layers' launches of that class back to
+ * back between two hipEvents on `stream` (the weights stream from HBM as in a real step); class_ms_host[c] (HOST memory,
+ * EXL_DEC_NCLASS floats) = mean time of one pass = that class' share of one token.  Overwrites the K/V slot at *pos_dev,
+ * does not advance the position, synchronises. */
+#define EXL_DEC_QKV     0
+#define EXL_DEC_ATTN    1
+#define EXL_DEC_MERGE   2
+#define EXL_DEC_O       3
+#define EXL_DEC_GATE_UP 4
+#define EXL_DEC_DOWN    5
+#define EXL_DEC_HEAD    6
+#define EXL_DEC_NCLASS  7
+int exl_decoder_step_timed(void* decoder, const int64_t* token_dev, int32_t* pos_dev, float* logits_out, int reps,
+                           void* stream, float* class_ms_host);
 int exl_decoder_free(void* decoder);
 
 /* ---- repetition penalty, HOST memory, fp32 (reference: exllama_ext.cpp:684-741, cpu_func/rep_penalty.cpp) */

@@ -145,35 +145,42 @@ def test_7b_layer_shapes_finite_and_consistent():
 
 @pytest.mark.parametrize("name,gs,act", [("tiny_hd128", 128, False), ("tiny_hd128_gqa", 64, True)])
 def test_native_decode_executor_matches_op_path_and_oracle(name, gs, act):
-    """The 5-kernels-per-layer decode executor (decode_fused.hip), eager and as a replayed hipGraph, against (a) the
+    """The native decode executor (decode_fused.hip), eager and as a replayed hipGraph, against (a) the
     op-by-op fused path (q4_attn -> attention -> q4_attn_2 -> q4_mlp) and (b) the CPU oracle model."""
     from exllama_amd.model import ExLlamaCache
     model, cache, tensors, dims = _build(name, gs, act, seed=21, max_seq_len=96)
     ids = torch.randint(1, dims.vocab_size, (1, 20), generator=torch.Generator().manual_seed(4)).to("cuda:0")
     n_new = 12
 
-    def run(mode):
+    def run(mode, forced=None):
+        """Greedy decode; with `forced` the token history of another run is replayed (teacher forcing), so that a near-tie
+        in the argmax of two numerically different paths cannot make the histories -- and every later logit -- diverge."""
         c = ExLlamaCache(model)
         model.disable_decode_graph()
         logits = model.forward(ids, c)
         if mode != "ops":
             model.enable_decode_graph(c, use_graph=(mode == "graph"))
         outs, toks = [], []
-        for _ in range(n_new):
-            tok = logits[0, -1].argmax().view(1, 1)
-            toks.append(int(tok))
+        for i in range(n_new):
+            own = int(logits[0, -1].argmax())
+            toks.append(own)
+            tok = torch.tensor([[forced[i] if forced is not None else own]], device="cuda:0")
             logits = model.forward(tok, c)
             outs.append(logits[0, 0].float().cpu())
         assert c.current_seq_len == 20 + n_new
         return torch.stack(outs), toks, c
 
     ops, toks_ops, c_ops = run("ops")
-    eager, toks_eager, c_eager = run("eager")
-    graph, toks_graph, c_graph = run("graph")
+    eager, toks_eager, c_eager = run("eager", forced=toks_ops)
+    graph, toks_graph, c_graph = run("graph", forced=toks_ops)
     scale = ops.abs().max().item()
     assert torch.isfinite(eager).all()
     assert (eager - ops).abs().max().item() <= 2e-2 * scale, (eager - ops).abs().max().item()
-    assert toks_eager == toks_ops
+    # same greedy choice wherever the op path's top-2 margin is not within the tolerance
+    prev = torch.cat([model.forward(ids, ExLlamaCache(model))[0, -1:].float().cpu(), ops[:-1]])
+    top2 = prev.topk(2, dim=-1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 4e-2 * scale
+    assert all(a == b for a, b, ok in zip(toks_eager, toks_ops, clear.tolist()) if ok)
     assert torch.equal(graph, eager) and toks_graph == toks_eager          # replayed graph == eager launches, bit for bit
     for l in range(len(c_ops.key_states)):
         ka, kb = c_ops.key_states[l][:, :, :32].float(), c_graph.key_states[l][:, :, :32].float()
@@ -189,6 +196,6 @@ def test_native_decode_executor_matches_op_path_and_oracle(name, gs, act):
     # rewinding the cache on the host is picked up by the device-side position
     model.enable_decode_graph(c_graph, use_graph=True)
     c_graph.current_seq_len = 20
-    again = model.forward(torch.tensor([[toks_graph[0]]], device="cuda:0"), c_graph)[0, 0].float().cpu()
+    again = model.forward(torch.tensor([[toks_ops[0]]], device="cuda:0"), c_graph)[0, 0].float().cpu()
     assert torch.equal(again, graph[0])
     model.free_unmanaged()
