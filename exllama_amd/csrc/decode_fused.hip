@@ -47,6 +47,7 @@ struct DecGemvArgs {
     f16* hid_io;                  // EMODE 1: hid_io[n] = h(hid_io[n] + y)
     int rb_per_wave;
     int xs_images;                // 1, or 2 when gate and up carry different act-order maps (EMODE 2)
+    int ablate;                   // measurement only (EXL_DEC_ABLATE): 1 = skip the dequant + MFMA work, 2 = also skip the norm
 };
 
 __device__ __forceinline__ f16 silu_mul_f16(f16 x, f16 y)
@@ -202,7 +203,8 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
                 if constexpr (EMODE == 1) { if (tid < 16) resN = (float) a.hid_io[tileN * 16 + tid]; }                      \
                 t16_unit_issue<U, G16>(a.mat[miN], uN, 0, rsub, DEC_BUF((P ^ 1) * NP), DEC_EP((P ^ 1) * NP));               \
             }                                                                                                               \
-            if (uC.rb0 + p * U < uC.rb1) t16_unit_consume<U, G16, NSLOT>(uC, p, lane, DEC_BUF(P * NP + p), entC, DEC_EP(P * NP + p), xrow, c); \
+            if (a.ablate) { _Pragma("unroll") for (int q = 0; q < U; ++q) c[0] += __builtin_bit_cast(float, DEC_BUF(P * NP + p)[q].x ^ DEC_BUF(P * NP + p)[q].w); } \
+            else if (uC.rb0 + p * U < uC.rb1) t16_unit_consume<U, G16, NSLOT>(uC, p, lane, DEC_BUF(P * NP + p), entC, DEC_EP(P * NP + p), xrow, c); \
         }                                                                                                                   \
         float* rp = red + P * DEC_WAVES * 16;                                                                               \
         if (lane < 16) rp[wave * 16 + lane] = c[0];                                                                         \
@@ -621,6 +623,8 @@ static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec,
     for (int i = 1; i < nmat; ++i)
         EXL_REQUIRE((mats[i]->groupsize % 128 == 0) == g16 && mats[i]->height == K, EXL_E_UNSUPPORTED, "decoder: fused matrices must share K and group-size class");
     a.xs_images = (emode == 2 && any_map) ? 2 : 1;
+    static const int ablate = getenv("EXL_DEC_ABLATE") ? atoi(getenv("EXL_DEC_ABLATE")) : 0;
+    a.ablate = ablate;
     const size_t smem = (size_t) a.xs_images * (K / 8) * 16 + (2 * DEC_WAVES * 16 + DEC_WAVES) * sizeof(float) + (any_map ? (size_t) K * 2 : 0);
     EXL_REQUIRE(smem <= 64 * 1024, EXL_E_UNSUPPORTED, "decoder: activation stage (%zu bytes of LDS) exceeds 64 KiB", smem);
     const int nv = (K / 8 + DEC_THREADS - 1) / DEC_THREADS;

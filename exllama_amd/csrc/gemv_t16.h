@@ -10,9 +10,10 @@
 //
 // The lane layout of a piece is exactly the B operand of v_mfma_f32_16x16x32_f16 (lane = (k-group, column), 8 k per
 // lane): the matrix core is used as the wave-wide dot-product AND reduction engine.  Per 1 KiB instruction a lane
-// expands its 4 words to fp16 (magic-number nibble expansion, exact zero-point subtraction, ONE fp16 multiply by the
-// group scale = bit-identical to the reference's reconstruct, q4_matrix.cu:207) and issues 4 MFMAs against the
-// activation k-groups read from LDS; D accumulates in fp32 across the whole K range.  No shuffles, no atomics.
+// expands its 4 words to fp16 (magic-number nibble expansion, exact zero-point subtraction) and issues 4 MFMAs against
+// the activation k-groups read from LDS, fp32 accumulate; the group scale is applied to the fp32 sum of the row-block
+// (groupsize % 128 == 0) or folded into the weights as ONE fp16 multiply, the reference's reconstruct bits,
+// q4_matrix.cu:207 (groupsize 32 / 64).  No shuffles, no atomics.
 //
 // A operand: lane (m = l & 15, kg = l >> 4) supplies activation row m, k-group kg.  With one activation row every m
 // reads the same LDS address (broadcast) and every D row is the same dot product; with up to 16 rows (op-level
@@ -36,6 +37,29 @@ __device__ __forceinline__ uint4 t16_permute(uint4 d)
     return o;
 }
 
+// The magic constant lives in a VGPR the compiler cannot fold: (w & mask) | magic then becomes ONE v_and_or_b32
+// (gfx9-family VALU instructions take a single literal / scalar operand: with two constants hipcc emits v_and + v_or).
+__device__ __forceinline__ uint32_t t16_magic()
+{
+    uint32_t m;
+    asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(m));
+    return m;
+}
+
+// 8 weights of one word as EXACT fp16 integers (q - z), order (q0,q4,q1,q5,q2,q6,q3,q7): 4 shifts/and_or + 4 packed ops
+__device__ __forceinline__ f16x8 t16_dequant_exact(uint32_t w, uint32_t magic, f16x2 zc0, f16x2 zc1)
+{
+    const f16x2 sixteenth = {(f16) 0.0625f, (f16) 0.0625f};
+    const uint32_t w8 = w >> 8;
+    const f16x2 d0 = t16_h2((w & 0x000F000Fu) | magic) + zc0;
+    const f16x2 d1 = t16_h2((w & 0x00F000F0u) | magic) * sixteenth + zc1;
+    const f16x2 d2 = t16_h2((w8 & 0x000F000Fu) | magic) + zc0;
+    const f16x2 d3 = t16_h2((w8 & 0x00F000F0u) | magic) * sixteenth + zc1;
+    const uint4 u = make_uint4(__builtin_bit_cast(uint32_t, d0), __builtin_bit_cast(uint32_t, d1),
+                               __builtin_bit_cast(uint32_t, d2), __builtin_bit_cast(uint32_t, d3));
+    return __builtin_bit_cast(f16x8, u);
+}
+
 // 8 weights of one word as fp16, order (q0,q4,q1,q5,q2,q6,q3,q7), each h( h(q - z) * s )
 __device__ __forceinline__ f16x8 t16_dequant(uint32_t w, f16x2 zc0, f16x2 zc1, f16x2 s2)
 {
@@ -48,6 +72,39 @@ __device__ __forceinline__ f16x8 t16_dequant(uint32_t w, f16x2 zc0, f16x2 zc1, f
     const uint4 u = make_uint4(__builtin_bit_cast(uint32_t, d0), __builtin_bit_cast(uint32_t, d1),
                                __builtin_bit_cast(uint32_t, d2), __builtin_bit_cast(uint32_t, d3));
     return __builtin_bit_cast(f16x8, u);
+}
+
+// One 1 KiB row-block against the activation: 4 MFMAs.
+//   G16 (groupsize % 128 == 0): the whole row-block lies in one group -> weights enter the MFMA as exact integers
+//       (q - z) and the fp32 sum of the row-block is scaled once: acc += s * sum   (fp32 dot per group, fp32 scale --
+//       the accumulation the oracle's q4_matmul_gemv_f32 states);
+//   otherwise (groupsize 32 / 64: the 4 k-groups of the MFMA belong to different GPTQ groups) the scale is folded into
+//       the weights, h(h(q - z) * s) -- the reference's reconstruct bits -- and the MFMA accumulates straight into acc.
+template <bool G16>
+__device__ __forceinline__ void t16_rowblock(const uint4& w, uint32_t e, uint32_t magic, const uint4* xr, f32x4& acc)
+{
+    const f16x2 c960 = {(f16) 960.f, (f16) 960.f};
+    const f16 sc = __builtin_bit_cast(f16, (uint16_t) (e & 0xFFFFu));
+    const f16 za = (f16) (float) (-(1024 + (int) (e >> 16)));
+    const f16x2 zc0 = {za, za};
+    const f16x2 zc1 = zc0 + c960;
+    const uint4 x0 = xr[0], x1 = xr[1], x2 = xr[2], x3 = xr[3];
+    if constexpr (G16) {
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x0), t16_dequant_exact(w.x, magic, zc0, zc1), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x1), t16_dequant_exact(w.y, magic, zc0, zc1), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x2), t16_dequant_exact(w.z, magic, zc0, zc1), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x3), t16_dequant_exact(w.w, magic, zc0, zc1), c, 0, 0, 0);
+        const float sf = (float) sc;
+        acc[0] = fmaf(sf, c[0], acc[0]); acc[1] = fmaf(sf, c[1], acc[1]);
+        acc[2] = fmaf(sf, c[2], acc[2]); acc[3] = fmaf(sf, c[3], acc[3]);
+    } else {
+        const f16x2 s2 = {sc, sc};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x0), t16_dequant(w.x, zc0, zc1, s2), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x1), t16_dequant(w.y, zc0, zc1, s2), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x2), t16_dequant(w.z, zc0, zc1, s2), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x3), t16_dequant(w.w, zc0, zc1, s2), acc, 0, 0, 0);
+    }
 }
 
 struct T16Matrix {                  // device-visible view of a Q4Matrix in T16 layout
@@ -99,7 +156,8 @@ struct T16Wave {
             for (int h = 0; h < T16_EH; ++h) {
                 if (h * 4 < U * NP) {
                     const int rb = min(rb0 + 4 * h + rsub, m.RB - 1);
-                    ent[h] = (rb0 + 4 * h < rb1) ? t16_load_entry(m, t16_group_of_row(m, rb * 16), n) : 0u;
+                    const uint32_t e = t16_load_entry(m, t16_group_of_row(m, rb * 16), n);
+                    ent[h] = (rb0 + 4 * h + rsub < rb1) ? e : 0u;       // rows past the range: scale 0 -> contribute nothing
                 }
             }
         }
@@ -110,7 +168,10 @@ struct T16Wave {
         for (int i = 0; i < U; ++i) {
             const int rb = rb0 + pass * U + i;
             const int rbc = rb < rb1 ? rb : rbsafe;                    // clamped: always a valid address
-            if constexpr (!G16) ent[(pass & 1) * U + i] = t16_load_entry(m, t16_group_of_row(m, rbc * 16 + rsub * 4), n);
+            if constexpr (!G16) {
+                const uint32_t e = t16_load_entry(m, t16_group_of_row(m, rbc * 16 + rsub * 4), n);
+                ent[(pass & 1) * U + i] = rb < rb1 ? e : 0u;
+            }
             wv[pass & 1][i] = nt_load16(base + (size_t) rbc * 64);
         }
     }
@@ -118,27 +179,16 @@ struct T16Wave {
     // A operand (row m = lane & 15; with a single activation row every lane passes the same pointer).
     __device__ __forceinline__ void consume(int pass, const uint4* xrow, f32x4& c)
     {
-        const f16x2 c960 = {(f16) 960.f, (f16) 960.f};
+        const uint32_t magic = t16_magic();
 #pragma unroll
         for (int i = 0; i < U; ++i) {
             const int li = pass * U + i;
             const int rb = rb0 + li;
-            if (rb < rb1) {                                             // wave-uniform
-                uint32_t e;
-                if constexpr (G16) e = (uint32_t) __shfl((int) ent[li >> 2], ((li & 3) << 4) | col, 64);
-                else e = ent[(pass & 1) * U + i];
-                const f16 sc = __builtin_bit_cast(f16, (uint16_t) (e & 0xFFFFu));
-                const f16 za = (f16) (float) (-(1024 + (int) (e >> 16)));
-                const f16x2 s2 = {sc, sc};
-                const f16x2 zc0 = {za, za};
-                const f16x2 zc1 = zc0 + c960;
-                const int r = rb * 16 + rsub * 4;
-                const uint4 x0 = xrow[r], x1 = xrow[r + 1], x2 = xrow[r + 2], x3 = xrow[r + 3];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x0), t16_dequant(wv[pass & 1][i].x, zc0, zc1, s2), c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x1), t16_dequant(wv[pass & 1][i].y, zc0, zc1, s2), c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x2), t16_dequant(wv[pass & 1][i].z, zc0, zc1, s2), c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x3), t16_dequant(wv[pass & 1][i].w, zc0, zc1, s2), c, 0, 0, 0);
-            }
+            const int rbc = rb < rb1 ? rb : rbsafe;                     // branch-free: out-of-range row-blocks carry scale 0
+            uint32_t e;
+            if constexpr (G16) e = (uint32_t) __shfl((int) ent[li >> 2], ((li & 3) << 4) | col, 64);
+            else e = ent[(pass & 1) * U + i];
+            t16_rowblock<G16>(wv[pass & 1][i], e, magic, xrow + rbc * 16 + rsub * 4, c);
         }
     }
     // all passes; the loads of pass 0 must already be in flight (issued ahead of the block's prologue).  Software
@@ -201,7 +251,8 @@ __device__ __forceinline__ void t16_unit_entries(const T16Matrix& m, const T16Un
 #pragma unroll
     for (int h = 0; h < NSLOT; ++h) {
         const int rb = min(u.rb0 + 4 * h + rsub, m.RB - 1);
-        ent[h] = (u.rb0 + 4 * h < u.rb1) ? t16_load_entry(m, t16_group_of_row(m, rb * 16), u.n) : 0u;
+        const uint32_t e = t16_load_entry(m, t16_group_of_row(m, rb * 16), u.n);
+        ent[h] = (u.rb0 + 4 * h + rsub < u.rb1) ? e : 0u;               // rows past the range: scale 0 -> contribute nothing
     }
 }
 
@@ -213,7 +264,10 @@ __device__ __forceinline__ void t16_unit_issue(const T16Matrix& m, const T16Unit
     for (int i = 0; i < U; ++i) {
         const int rb = u.rb0 + pass * U + i;
         const int rbc = rb < u.rb1 ? rb : u.rbsafe;
-        if constexpr (!G16) entp[i] = t16_load_entry(m, t16_group_of_row(m, rbc * 16 + rsub * 4), u.n);
+        if constexpr (!G16) {
+            const uint32_t e = t16_load_entry(m, t16_group_of_row(m, rbc * 16 + rsub * 4), u.n);
+            entp[i] = rb < u.rb1 ? e : 0u;
+        }
         wv[i] = nt_load16(u.base + (size_t) rbc * 64);
     }
 }
@@ -223,27 +277,16 @@ __device__ __forceinline__ void t16_unit_consume(const T16Unit& u, int pass, int
                                                  const uint32_t (&ent)[NSLOT], const uint32_t (&entp)[U], const uint4* xrow,
                                                  f32x4& c)
 {
-    const f16x2 c960 = {(f16) 960.f, (f16) 960.f};
+    const uint32_t magic = t16_magic();
     const int col = lane & 15, rsub = lane >> 4;
 #pragma unroll
     for (int i = 0; i < U; ++i) {
         const int li = pass * U + i;
         const int rb = u.rb0 + li;
-        if (rb < u.rb1) {                                               // wave-uniform
-            uint32_t e;
-            if constexpr (G16) e = (uint32_t) __shfl((int) ent[(li >> 2) < NSLOT ? (li >> 2) : 0], ((li & 3) << 4) | col, 64);
-            else e = entp[i];
-            const f16 sc = __builtin_bit_cast(f16, (uint16_t) (e & 0xFFFFu));
-            const f16 za = (f16) (float) (-(1024 + (int) (e >> 16)));
-            const f16x2 s2 = {sc, sc};
-            const f16x2 zc0 = {za, za};
-            const f16x2 zc1 = zc0 + c960;
-            const int r = rb * 16 + rsub * 4;
-            const uint4 x0 = xrow[r], x1 = xrow[r + 1], x2 = xrow[r + 2], x3 = xrow[r + 3];
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x0), t16_dequant(wv[i].x, zc0, zc1, s2), c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x1), t16_dequant(wv[i].y, zc0, zc1, s2), c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x2), t16_dequant(wv[i].z, zc0, zc1, s2), c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x3), t16_dequant(wv[i].w, zc0, zc1, s2), c, 0, 0, 0);
-        }
+        const int rbc = rb < u.rb1 ? rb : u.rbsafe;                     // branch-free: out-of-range row-blocks carry scale 0
+        uint32_t e;
+        if constexpr (G16) e = (uint32_t) __shfl((int) ent[(li >> 2) < NSLOT ? (li >> 2) : 0], ((li & 3) << 4) | col, 64);
+        else e = entp[i];
+        t16_rowblock<G16>(wv[i], e, magic, xrow + rbc * 16 + rsub * 4, c);
     }
 }
