@@ -233,8 +233,13 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// K2: RoPE + cache append + split-KV attention (head_dim 128, 16 lanes per key row)
+// K2: RoPE + cache append + split-KV attention (head_dim 128, 16 lanes per key row, 16 key rows per step)
+//
+// One block = (head, split).  The first DEC_ATT_UN * 16 keys of the split -- the whole split up to context 2560 with 16
+// splits -- are requested for K AND V before anything else happens, so the kernel pays ONE memory latency, not two
+// (scores -> softmax -> PV with the V rows already in registers).  Longer splits loop over further chunks.
 // ---------------------------------------------------------------------------------------------------------------
+#define DEC_ATT_UN 10
 __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q, const f16* __restrict__ k_new,
                                                        const f16* __restrict__ v_new, f16* __restrict__ kc,
                                                        f16* __restrict__ vc, const f16* __restrict__ sin,
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
                                                        const int32_t* __restrict__ pos_dev, int heads, int kv_heads,
                                                        int max_seq, int nsplit, float scale)
 {
-    constexpr int HD = 128, LPK = 16, KPI = 16;
+    constexpr int HD = 128, LPK = 16, KPI = 16, UN = DEC_ATT_UN;
     __shared__ float sc[DEC_ATT_MAX_KEYS];
     __shared__ float red[KPI][HD + 1];
     __shared__ float stat[8];
@@ -257,10 +262,30 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
     const int s0 = min(vis, split * L), s1 = min(vis, s0 + L);
     const int nkeys = s1 - s0;
     const int kvh = h / (heads / kv_heads);
+    f16* kbase = kc + (size_t) kvh * max_seq * HD + d8 * 8;
+    f16* vbase = vc + (size_t) kvh * max_seq * HD + d8 * 8;
 
-    // RoPE on q and on the new key: element d pairs with d +- 64, i.e. lane d8 with lane d8 ^ 8
+    // ---- every load of the first chunk up front: small ones first, then K rows, then V rows -------------------------
     const f16x8 sn = *(const f16x8*) (sin + (size_t) past * HD + d8 * 8);
     const f16x8 cs = *(const f16x8*) (cos + (size_t) past * HD + d8 * 8);
+    const f16x8 qraw = *(const f16x8*) (q + (size_t) h * HD + d8 * 8);
+    const f16x8 kraw = *(const f16x8*) (k_new + (size_t) kvh * HD + d8 * 8);
+    const f16x8 vn = *(const f16x8*) (v_new + (size_t) kvh * HD + d8 * 8);
+    f16x8 kv0[UN], vv0[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        const int j = u * KPI + ks;
+        kv0[u] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (j < nkeys) kv0[u] = *(const f16x8*) (kbase + (size_t) (s0 + j) * HD);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        const int j = u * KPI + ks;
+        vv0[u] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (j < nkeys) vv0[u] = *(const f16x8*) (vbase + (size_t) (s0 + j) * HD);
+    }
+
+    // RoPE on q and on the new key: element d pairs with d +- 64, i.e. lane d8 with lane d8 ^ 8
     const bool left = d8 < 8;
     auto rope8 = [&](f16x8 own) {
         const uint4 oi = __builtin_bit_cast(uint4, own);
@@ -277,11 +302,8 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
         }
         return r;
     };
-    const f16x8 qr = rope8(*(const f16x8*) (q + (size_t) h * HD + d8 * 8));
-    const f16x8 kr = rope8(*(const f16x8*) (k_new + (size_t) kvh * HD + d8 * 8));
-    const f16x8 vn = *(const f16x8*) (v_new + (size_t) kvh * HD + d8 * 8);
-    f16* kbase = kc + (size_t) kvh * max_seq * HD + d8 * 8;
-    f16* vbase = vc + (size_t) kvh * max_seq * HD + d8 * 8;
+    const f16x8 qr = rope8(qraw);
+    const f16x8 kr = rope8(kraw);
     if (split == 0 && (h % (heads / kv_heads)) == 0 && ks == 0) {
         *(f16x8*) (kbase + (size_t) past * HD) = kr;
         *(f16x8*) (vbase + (size_t) past * HD) = vn;
@@ -290,23 +312,16 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
 #pragma unroll
     for (int j = 0; j < 8; ++j) qf[j] = (float) qr[j] * scale;
 
-    constexpr int UN = 8;                                       // key rows in flight per thread
+    // ---- scores ---------------------------------------------------------------------------------------------------
     float mx = -INFINITY;
-    for (int j0 = 0; j0 < nkeys; j0 += KPI * UN) {
-        f16x8 kv[UN];
+    auto score_chunk = [&](int j0, const f16x8 (&kv)[UN]) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int j = j0 + u * KPI + ks;
-            const int key = s0 + (j < nkeys ? j : 0);           // clamped: always a valid row
-            kv[u] = *(const f16x8*) (kbase + (size_t) key * HD);
-            if (key == past) kv[u] = kr;                        // the new key never comes from memory
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int j = j0 + u * KPI + ks;
+            const f16x8 kk = (s0 + j == past) ? kr : kv[u];            // the new key never comes from memory
             float dot = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dot = fmaf(qf[e], (float) kv[u][e], dot);
+            for (int e = 0; e < 8; ++e) dot = fmaf(qf[e], (float) kk[e], dot);
 #pragma unroll
             for (int off = 1; off < LPK; off <<= 1) dot += __shfl_xor(dot, off, 64);
             if (j < nkeys) {
@@ -314,6 +329,16 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
                 mx = fmaxf(mx, dot);
             }
         }
+    };
+    score_chunk(0, kv0);
+    for (int j0 = KPI * UN; j0 < nkeys; j0 += KPI * UN) {
+        f16x8 kv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int j = j0 + u * KPI + ks;
+            kv[u] = *(const f16x8*) (kbase + (size_t) (s0 + (j < nkeys ? j : 0)) * HD);
+        }
+        score_chunk(j0, kv);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
@@ -333,25 +358,29 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
     __syncthreads();
     lsum = stat[4] + stat[5] + stat[6] + stat[7];
 
+    // ---- P V ------------------------------------------------------------------------------------------------------
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
-    for (int j0 = 0; j0 < nkeys; j0 += KPI * UN) {
-        f16x8 vv[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int j = j0 + u * KPI + ks;
-            const int key = s0 + (j < nkeys ? j : 0);
-            vv[u] = *(const f16x8*) (vbase + (size_t) key * HD);
-            if (key == past) vv[u] = vn;
-        }
+    auto pv_chunk = [&](int j0, const f16x8 (&vv)[UN]) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int j = j0 + u * KPI + ks;
             const float p = j < nkeys ? sc[j] : 0.f;
+            const f16x8 v8 = (s0 + j == past) ? vn : vv[u];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = fmaf(p, (float) vv[u][e], o[e]);
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(p, (float) v8[e], o[e]);
         }
+    };
+    pv_chunk(0, vv0);
+    for (int j0 = KPI * UN; j0 < nkeys; j0 += KPI * UN) {
+        f16x8 vv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int j = j0 + u * KPI + ks;
+            vv[u] = *(const f16x8*) (vbase + (size_t) (s0 + (j < nkeys ? j : 0)) * HD);
+        }
+        pv_chunk(j0, vv);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[ks][d8 * 8 + e] = o[e];
@@ -373,7 +402,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
 // K2b: merge the split-KV partials of one head -> fp16 attention output (the value the reference's ATen attention
 // rounds to fp16 before o_proj, model.py:407-409)
 // ---------------------------------------------------------------------------------------------------------------
-#define DEC_MAX_NSPLIT 8
+#define DEC_MAX_NSPLIT 16
 __global__ __launch_bounds__(128) void dec_attn_merge_kernel(const float* __restrict__ partial, f16* __restrict__ out, int nsplit)
 {
     const int h = blockIdx.x, d = threadIdx.x;
@@ -501,7 +530,7 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     d->sin = (const f16*) sin; d->cos = (const f16*) cos;
     d->layers.resize(n_layers);
     for (auto& l : d->layers) l.set = false;
-    int ns = 256 / heads;
+    int ns = (max_seq_len > 1280 ? 512 : 256) / heads;             // long contexts: 2 blocks per CU, <= 160 keys each
     if (ns < 1) ns = 1;
     if (ns > DEC_MAX_NSPLIT) ns = DEC_MAX_NSPLIT;
     while ((max_seq_len + ns - 1) / ns + 16 > DEC_ATT_MAX_KEYS) ++ns;
