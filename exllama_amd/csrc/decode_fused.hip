@@ -173,16 +173,15 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
         }
     }
     __syncthreads();
-    if (gather) {                                                    // act-order: one image per distinct x_map
-        if (a.xs_images > 1) {                                       // EMODE 2: gate image built by waves 0-3, up image by 4-7
+    if (gather) {                                                    // act-order: one image per matrix (each has its own x_map)
+        if constexpr (EMODE == 2) {                                  // gate image built by waves 0-3, up image by waves 4-7
             const int mi = wave / WPT;
             t16_stage_from_lds(xlin, a.mat[mi].x_map, R, xs + (size_t) mi * R, tid % (WPT * 64), WPT * 64);
         } else {
-            t16_stage_from_lds(xlin, a.mat[0].x_map, R, xs, tid, DEC_THREADS);
+            for (int k = 0; k < a.xs_images; ++k) t16_stage_from_lds(xlin, a.mat[k].x_map, R, xs + (size_t) k * R, tid, DEC_THREADS);
         }
         __syncthreads();
     }
-    // EMODE 0 with several act-order matrices (q, k, v) shares ONE image only if they share the map; the host checks it.
 
     // ---- 4. walk the tiles ----------------------------------------------------------------------------------
 #define DEC_BUF(k) (((k) & 1) ? wv1 : wv0)
@@ -612,13 +611,20 @@ extern "C" int exl_decoder_free(void* dec)
 template <int PNORM, int EMODE, int NV>
 static int launch_dec_gemv_cfg(bool g16, int rbw, dim3 grid, size_t smem, hipStream_t s, const DecGemvArgs& a)
 {
-#define DEC_LAUNCH(U, NP) do { if (g16) hipLaunchKernelGGL((dec_stream_kernel<U, NP, true, PNORM, EMODE, NV>), grid, dim3(DEC_THREADS), smem, s, a); \
-                               else     hipLaunchKernelGGL((dec_stream_kernel<U, NP, false, PNORM, EMODE, NV>), grid, dim3(DEC_THREADS), smem, s, a); } while (0)
+#define DEC_LAUNCH1(U, NP, G) do { auto kfn = dec_stream_kernel<U, NP, G, PNORM, EMODE, NV>;                                   \
+        static bool big = false;                                                                                              \
+        if (smem > 64 * 1024 && !big) {               /* more than the default dynamic-LDS limit: opt in once */              \
+            EXL_HIP(hipFuncSetAttribute((const void*) kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));          \
+            big = true;                                                                                                       \
+        }                                                                                                                     \
+        hipLaunchKernelGGL(kfn, grid, dim3(DEC_THREADS), smem, s, a); } while (0)
+#define DEC_LAUNCH(U, NP) do { if (g16) DEC_LAUNCH1(U, NP, true); else DEC_LAUNCH1(U, NP, false); } while (0)
     if (rbw <= 4)       DEC_LAUNCH(4, 1);
     else if (rbw <= 8)  DEC_LAUNCH(4, 2);
     else if (rbw <= 12) DEC_LAUNCH(6, 2);
     else                DEC_LAUNCH(6, 4);
 #undef DEC_LAUNCH
+#undef DEC_LAUNCH1
     EXL_LAUNCH_CHECK();
     return 0;
 }
@@ -651,16 +657,15 @@ static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec,
     const bool g16 = mats[0]->groupsize % 128 == 0;
     for (int i = 1; i < nmat; ++i)
         EXL_REQUIRE((mats[i]->groupsize % 128 == 0) == g16 && mats[i]->height == K, EXL_E_UNSUPPORTED, "decoder: fused matrices must share K and group-size class");
-    a.xs_images = (emode == 2 && any_map) ? 2 : 1;
+    a.xs_images = any_map ? nmat : 1;                                // act-order: every matrix gathers x through its own map
     static const int ablate = getenv("EXL_DEC_ABLATE") ? atoi(getenv("EXL_DEC_ABLATE")) : 0;
     a.ablate = ablate;
     const size_t smem = (size_t) a.xs_images * (K / 8) * 16 + (2 * DEC_WAVES * 16 + DEC_WAVES) * sizeof(float) + (any_map ? (size_t) K * 2 : 0);
-    EXL_REQUIRE(smem <= 64 * 1024, EXL_E_UNSUPPORTED, "decoder: activation stage (%zu bytes of LDS) exceeds 64 KiB", smem);
+    EXL_REQUIRE(smem <= 160 * 1024, EXL_E_UNSUPPORTED, "decoder: activation stage (%zu bytes of LDS) exceeds the 160 KiB of a CU", smem);
     const int nv = (K / 8 + DEC_THREADS - 1) / DEC_THREADS;
-    if (emode != 2)
-        for (int i = 1; i < nmat; ++i)
-            EXL_REQUIRE(mats[i]->x_map == nullptr && mats[0]->x_map == nullptr, EXL_E_UNSUPPORTED,
-                        "decoder: act-order matrices cannot share one launch (each needs its own activation gather)");
+    for (int i = 1; i < nmat; ++i)
+        EXL_REQUIRE((mats[i]->x_map == nullptr) == (mats[0]->x_map == nullptr), EXL_E_UNSUPPORTED,
+                    "decoder: matrices fused into one launch must agree on act-order");
     dim3 grid(tiles < max_blocks ? tiles : max_blocks);
 #define DEC_NV(P, E) (nv <= 1 ? launch_dec_gemv_cfg<P, E, 1>(g16, rbw, grid, smem, s, a) : nv <= 2 ? launch_dec_gemv_cfg<P, E, 2>(g16, rbw, grid, smem, s, a) \
                       : nv <= 3 ? launch_dec_gemv_cfg<P, E, 3>(g16, rbw, grid, smem, s, a) : launch_dec_gemv_cfg<P, E, 6>(g16, rbw, grid, smem, s, a))
@@ -683,11 +688,7 @@ static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int3
         const f16* xin = i == 0 ? d->embed : d->hid;
         const int64_t* tk = i == 0 ? token_dev : nullptr;
         f16* hc = i == 0 ? d->hid : nullptr;
-        if (!l.q->x_map && !l.k->x_map && !l.v->x_map)
-            return launch_dec_gemv(d->max_blocks, 1, 0, xin, tk, l.in_norm, d->eps, hc, 3, qkv, qkv_out, nullptr, s);
-        for (int k = 0; k < 3; ++k)                                  // act-order: every matrix gathers x through its own map
-            EXL_TRY(launch_dec_gemv(d->max_blocks, 1, 0, xin, tk, l.in_norm, d->eps, k == 0 ? hc : nullptr, 1, qkv + k, qkv_out + k, nullptr, s));
-        return 0;
+        return launch_dec_gemv(d->max_blocks, 1, 0, xin, tk, l.in_norm, d->eps, hc, 3, qkv, qkv_out, nullptr, s);
     }
     case EXL_DEC_ATTN:
         hipLaunchKernelGGL(dec_attn_kernel, dim3(d->nsplit, d->heads), dim3(256), 0, s, d->qbuf, d->kbuf, d->vbuf, l.kc, l.vc,
