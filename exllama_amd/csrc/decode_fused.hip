@@ -169,7 +169,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
         const int idx = tid + i * DEC_THREADS;
         if (idx < nvec) {
             if (gather) *(f16x8*) (xlin + idx * 8) = xv[i];
-            else        xs[idx] = t16_permute(__builtin_bit_cast(uint4, xv[i]));
+            else        xs[idx] = __builtin_bit_cast(uint4, xv[i]);
         }
     }
     __syncthreads();

@@ -3,7 +3,9 @@
 // T16 layout ("16-column tiles, 4-row pieces").  With R = K/8 packed rows and RB = R/16 row-blocks, the GPTQ word
 // (packed row r, column n) lives in the 16-byte piece
 //     piece(n, r) = (t * RB + rb) * 64 + rsub * 16 + col        t = n / 16, col = n % 16, rb = r / 16, rsub = (r % 16) / 4
-// as dword j = r % 4.  So one piece = 4 consecutive packed rows (32 k) of ONE column, one wave64 load instruction
+// as dword j = r % 4, with the 8 nibbles of the word INTERLEAVED: weight k of the row sits at nibble (k >> 1) + 4 * (k & 1),
+// so that the two-at-a-time magic-number expansion (mask 0x000F000F picks nibbles 0 and 4, ...) yields the weights in
+// natural k order (k0,k1),(k2,k3),... and neither the weights nor the activations need a shuffle at run time.  So one piece = 4 consecutive packed rows (32 k) of ONE column, one wave64 load instruction
 // (lane = rsub * 16 + col) = 16 packed rows x 16 columns = 1 KiB of contiguous memory, and a 16-column tile is one
 // contiguous run of K * 8 bytes that a block streams front to back with full K: no split-K, no partial-sum slabs, no
 // cross-block reduction on the decode path.
@@ -26,17 +28,6 @@
 
 __device__ __forceinline__ f16x2 t16_h2(uint32_t v) { return __builtin_bit_cast(f16x2, v); }
 
-// (h0..h7) -> (h0,h4),(h1,h5),(h2,h6),(h3,h7): the order in which nibble pairs fall out of a GPTQ word
-__device__ __forceinline__ uint4 t16_permute(uint4 d)
-{
-    uint4 o;
-    o.x = (d.x & 0xFFFFu) | (d.z << 16);
-    o.y = (d.x >> 16) | (d.z & 0xFFFF0000u);
-    o.z = (d.y & 0xFFFFu) | (d.w << 16);
-    o.w = (d.y >> 16) | (d.w & 0xFFFF0000u);
-    return o;
-}
-
 // The magic constant lives in a VGPR the compiler cannot fold: (w & mask) | magic then becomes ONE v_and_or_b32
 // (gfx9-family VALU instructions take a single literal / scalar operand: with two constants hipcc emits v_and + v_or).
 __device__ __forceinline__ uint32_t t16_magic()
@@ -46,7 +37,7 @@ __device__ __forceinline__ uint32_t t16_magic()
     return m;
 }
 
-// 8 weights of one word as EXACT fp16 integers (q - z), order (q0,q4,q1,q5,q2,q6,q3,q7): 4 shifts/and_or + 4 packed ops
+// 8 weights of one (nibble-interleaved) word as EXACT fp16 integers (q - z), natural k order: 1 shift, 4 and_or, 4 packed ops
 __device__ __forceinline__ f16x8 t16_dequant_exact(uint32_t w, uint32_t magic, f16x2 zc0, f16x2 zc1)
 {
     const f16x2 sixteenth = {(f16) 0.0625f, (f16) 0.0625f};
@@ -60,7 +51,7 @@ __device__ __forceinline__ f16x8 t16_dequant_exact(uint32_t w, uint32_t magic, f
     return __builtin_bit_cast(f16x8, u);
 }
 
-// 8 weights of one word as fp16, order (q0,q4,q1,q5,q2,q6,q3,q7), each h( h(q - z) * s )
+// 8 weights of one (nibble-interleaved) word as fp16, natural k order, each h( h(q - z) * s )
 __device__ __forceinline__ f16x8 t16_dequant(uint32_t w, f16x2 zc0, f16x2 zc1, f16x2 s2)
 {
     const f16x2 sixteenth = {(f16) 0.0625f, (f16) 0.0625f};
@@ -175,7 +166,7 @@ struct T16Wave {
             wv[pass & 1][i] = nt_load16(base + (size_t) rbc * 64);
         }
     }
-    // xrow: LDS activation image (permuted 8-half groups per packed row) of the activation row this lane feeds to the
+    // xrow: LDS activation image (8 halves per packed row, natural order) of the activation row this lane feeds to the
     // A operand (row m = lane & 15; with a single activation row every lane passes the same pointer).
     __device__ __forceinline__ void consume(int pass, const uint4* xrow, f32x4& c)
     {
@@ -203,7 +194,7 @@ struct T16Wave {
     }
 };
 
-// Build the permuted (and x_map-gathered) LDS image of an activation row from a linear fp16 copy in LDS.
+// Build the (x_map-gathered) LDS image of an activation row from a linear fp16 copy in LDS.
 __device__ __forceinline__ void t16_stage_from_lds(const f16* xlin, const uint32_t* x_map, int R, uint4* xs, int tid,
                                                    int nthreads)
 {
@@ -220,7 +211,7 @@ __device__ __forceinline__ void t16_stage_from_lds(const f16* xlin, const uint32
         } else {
             v = *(const uint4*) (xlin + k);
         }
-        xs[idx] = t16_permute(v);
+        xs[idx] = v;
     }
 }
 

@@ -17,7 +17,7 @@
 //     once per XCD L2 rather than once per m-tile.
 // Act-order weights: x is gathered through x_map by column_remap into the borrowed temp_state buffer first
 // (same as the reference, q4_matmul.cu:320-325); folding the gather into the A-tile load is future work.
-#include "common.h"
+#include "gemv_t16.h"
 #include <stdlib.h>
 
 #define MAGIC_1024 0x64006400u
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void q4_gemm_kernel(const f16* __restrict__ x,
     auto store_a = [&](int buf, const uint4 (&ar)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            *(uint4*) (lds + buf * (BM * BK * 2) + a_lds_off(a_row[i], a_c8[i])) = permute_x8(ar[i]);
+            *(uint4*) (lds + buf * (BM * BK * 2) + a_lds_off(a_row[i], a_c8[i])) = T16 ? ar[i] : permute_x8(ar[i]);   // T16 words are nibble-interleaved: natural k order
     };
     // B operand of MFMA step kk, lane half g = the 8 k of ONE packed row.  GPTQ layout: row 2*kk + g of the K tile (one
     // uint2 = columns n, n+1).  T16 layout: the lane's two pieces hold rows 4*g .. 4*g+3 of the K tile for columns n and
@@ -230,38 +230,42 @@ __global__ __launch_bounds__(256) void q4_gemm_kernel(const f16* __restrict__ x,
 // ---------------------------------------------------------------------------------------------------------------
 // T16 layout, LDS-staged B: the prefill kernel of the product path.
 //
-//   * block tile 128(M) x 128(N), K step 64, 256 threads = 4 waves as 2(M) x 2(N), each wave 64 x 64 =
-//     4 x 4 tiles of v_mfma_f32_16x16x32_f16, fp32 accumulate (64 accumulator registers);
+//   * block tile BM(M) x 128(N), K step 64; BM = 256 with 8 waves (4 x 2) for large M, 128 with 4 waves (2 x 2) otherwise;
+//     each wave 64 x 64 = 4 x 4 tiles of v_mfma_f32_16x16x32_f16, fp32 accumulate (64 accumulator registers);
 //   * activations: global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip), 128-byte rows XOR-swizzled
 //     through the per-lane SOURCE address (the LDS image of a DMA is lane-linear), so the fragment reads
-//     (ds_read_b128, 16 rows x 4 k-chunks per wave) are bank-conflict free;
-//   * weights: each thread loads ONE 16-byte T16 piece per K step (4 packed rows = 32 k of one column; 32 lanes read
-//     512 contiguous bytes), expands it ONCE per block to 32 fp16 values h(h(q - z) * s) -- bit-identical to the
-//     reference's reconstruct (q4_matrix.cu:207) -- un-permutes the nibble-pair order with 4 v_perm per word and writes
-//     64 bytes of the swizzled [n][k] LDS tile.  The dequantisation cost is paid once per 128 rows of M instead of once
-//     per wave as in the register-B kernel above;
-//   * double-buffered LDS (64 KiB per block, 2 blocks per CU): tile t+1 is staged while tile t feeds the MFMAs, one
-//     barrier per K step;
+//     (ds_read_b128, 16 rows x 4 k-chunks per wave) are bank-conflict free (SQ_LDS_BANK_CONFLICT = 0 measured);
+//   * weights: each thread loads one T16 piece (or half of one at 512 threads) per K step -- 32 lanes read 512
+//     contiguous bytes --, expands it ONCE per block to fp16 values h(h(q - z) * s), bit-identical to the reference's
+//     reconstruct (q4_matrix.cu:207), already in natural k order (the T16 words are nibble-interleaved), and writes
+//     them to the swizzled [n][k] LDS tile.  The dequantisation cost is paid once per BM rows of M instead of once per
+//     wave as in the register-B kernel above; at BM = 256 it is 1/4 of the VALU work of the 128-row tile per MFMA;
+//   * double-buffered LDS, tile t+1 is staged while tile t feeds the MFMAs, one barrier per K step;
 //   * MFMA roles are swapped (A operand = weights, B operand = activations) so that a lane ends up with 4 CONSECUTIVE
 //     output columns of one row: 8-byte stores instead of 2-byte ones;
 //   * blocks of one XCD walk the m-tiles of the same weight column tile first (weights are pulled from HBM once per
 //     XCD L2, not once per m-tile).
 // ---------------------------------------------------------------------------------------------------------------
-#define GT_BM 128
 #define GT_BN 128
 #define GT_BK 64
-#define GT_TILE_BYTES (128 * 64 * 2)
+#define GT_BTILE_BYTES (128 * 64 * 2)
 
-// byte offset of the 16-byte chunk c (8 halves) of row r in a swizzled [128][64] fp16 tile
+// byte offset of the 16-byte chunk c (8 halves) of row r in a swizzled [rows][64] fp16 tile
 __device__ __forceinline__ int gt_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
 
-__global__ __launch_bounds__(256, 2) void q4_gemm_t16_kernel(const f16* __restrict__ x, const uint4* __restrict__ qw,
-                                                             const uint32_t* __restrict__ qzeros,
-                                                             const f16* __restrict__ scales, f16* __restrict__ out, int M,
-                                                             int K, int N, int gshift, int groupsize, int no_zero, int mtiles,
-                                                             int ntiles)
+template <int WM>          // waves along M: block = WM x 2 waves, BM = 64 * WM rows
+__global__ __launch_bounds__(WM * 128) void q4_gemm_t16_kernel(const f16* __restrict__ x, const uint4* __restrict__ qw,
+                                                              const uint32_t* __restrict__ qzeros,
+                                                              const f16* __restrict__ scales, f16* __restrict__ out, int M,
+                                                              int K, int N, int gshift, int groupsize, int no_zero, int mtiles,
+                                                              int ntiles)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * GT_TILE_BYTES];       // [buf][A | B]
+    constexpr int TBM = 64 * WM;
+    constexpr int NTH = WM * 128;
+    constexpr int A_BYTES = TBM * 128;
+    constexpr int STAGE = A_BYTES + GT_BTILE_BYTES;
+    constexpr int PW = 4 * 256 / NTH;                                 // words of a piece per thread (4 or 2)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [2][A | B]
 
     const int b = blockIdx.x;
     const int xcd = b & 7;
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void q4_gemm_t16_kernel(const f16* __restri
     const int mt = idx - nl * mtiles;
     const int nt = nl * 8 + xcd;
     if (nt >= ntiles) return;
-    const int m0 = mt * GT_BM;
+    const int m0 = mt * TBM;
     const int n0 = nt * GT_BN;
 
     const int tid = threadIdx.x;
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void q4_gemm_t16_kernel(const f16* __restri
     const int RB = K >> 7;
     const int nk = K / GT_BK;
 
-    // ---- A staging (LDS-DMA): 16 pieces of 1 KiB per tile, 4 per wave; piece c = rows 8c .. 8c+7 ---------------------
+    // ---- A staging (LDS-DMA): BM / 8 pieces of 1 KiB per tile, 4 per wave; piece c = rows 8c .. 8c+7 ---------------
     const f16* a_src[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -294,25 +298,30 @@ __global__ __launch_bounds__(256, 2) void q4_gemm_t16_kernel(const f16* __restri
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             __attribute__((address_space(3))) unsigned char* dst =
-                (__attribute__((address_space(3))) unsigned char*) (lds + (size_t) buf * 2 * GT_TILE_BYTES + (wave * 4 + i) * 1024);
+                (__attribute__((address_space(3))) unsigned char*) (lds + (size_t) buf * STAGE + (wave * 4 + i) * 1024);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (a_src[i] + k0), dst, 16, 0, 0);
         }
     };
 
-    // ---- B staging: thread -> one T16 piece per K step --------------------------------------------------------------
-    const int b_tile = tid >> 5;                                      // 16-column tile within the block (0..7)
-    const int b_rs = (tid >> 4) & 1;                                  // which 32-k half of the K step
-    const int b_col = tid & 15;
+    // ---- B staging: thread -> PW words of one T16 piece per K step -----------------------------------------------------
+    const int pid = PW == 4 ? tid : tid >> 1;                         // piece within the K step (0..255)
+    const int ph = PW == 4 ? 0 : tid & 1;                             // which half of the piece
+    const int b_tile = pid >> 5;                                      // 16-column tile within the block (0..7)
+    const int b_rs = (pid >> 4) & 1;                                  // which 32-k half of the K step
+    const int b_col = pid & 15;
     const int b_nloc = b_tile * 16 + b_col;                           // row of the LDS B tile
     const int b_n = min(n0 + b_nloc, N - 1);                          // clamped column (a partial last n-tile is never stored)
-    const uint4* b_src = qw + ((size_t) (b_n >> 4) * RB) * 64 + (b_n & 15);
+    const uint32_t* b_src = (const uint32_t*) (qw + ((size_t) (b_n >> 4) * RB) * 64 + (b_n & 15)) + ph * PW;
     const int b_zsh = (b_n & 7) * 4;
-    uint4 breg;
+    const uint32_t magic = t16_magic();
+    uint32_t breg[PW];
     uint32_t bzw;
     f16 bsc;
     auto issue_b = [&](int it) {
         const int rb = it >> 1, rsub = (it & 1) * 2 + b_rs;
-        breg = b_src[(size_t) rb * 64 + rsub * 16];
+        const uint32_t* p = b_src + ((size_t) rb * 64 + rsub * 16) * 4;
+        if constexpr (PW == 4) { const uint4 v = *(const uint4*) p; breg[0] = v.x; breg[1] = v.y; breg[2] = v.z; breg[3] = v.w; }
+        else                   { const uint2 v = *(const uint2*) p; breg[0] = v.x; breg[1] = v.y; }
         const int k = it * GT_BK + b_rs * 32;
         const int grp = gshift >= 0 ? (k >> gshift) : (k / groupsize);
         bzw = qzeros[(size_t) grp * (N >> 3) + (b_n >> 3)];
@@ -323,18 +332,15 @@ __global__ __launch_bounds__(256, 2) void q4_gemm_t16_kernel(const f16* __restri
         const f16 za = (f16) (float) (-(1024 + z));
         const f16 zb = (f16) (float) (-(64 + z));
         const f16x2 zc0 = {za, za}, zc1 = {zb, zb}, s2 = {bsc, bsc};
-        unsigned char* base = lds + (size_t) buf * 2 * GT_TILE_BYTES + GT_TILE_BYTES;
-        const uint32_t words[4] = {breg.x, breg.y, breg.z, breg.w};
+        unsigned char* base = lds + (size_t) buf * STAGE + A_BYTES;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f16x8 d = dequant_word(words[j], zc0, zc1, s2);       // (q0,q4,q1,q5,q2,q6,q3,q7)
+        for (int j = 0; j < PW; ++j) {
+            const f16x8 d = t16_dequant_exact(breg[j], magic, zc0, zc1);                // natural k order
             const uint4 u = __builtin_bit_cast(uint4, d);
-            uint4 o;                                                    // -> natural k order (q0..q7)
-            o.x = __builtin_amdgcn_perm(u.y, u.x, 0x05040100u);         // (q0, q1)
-            o.y = __builtin_amdgcn_perm(u.w, u.z, 0x05040100u);         // (q2, q3)
-            o.z = __builtin_amdgcn_perm(u.y, u.x, 0x07060302u);         // (q4, q5)
-            o.w = __builtin_amdgcn_perm(u.w, u.z, 0x07060302u);         // (q6, q7)
-            *(uint4*) (base + gt_off(b_nloc, b_rs * 4 + j)) = o;
+            uint4 o;
+            o.x = __builtin_bit_cast(uint32_t, as_h2(u.x) * s2); o.y = __builtin_bit_cast(uint32_t, as_h2(u.y) * s2);
+            o.z = __builtin_bit_cast(uint32_t, as_h2(u.z) * s2); o.w = __builtin_bit_cast(uint32_t, as_h2(u.w) * s2);
+            *(uint4*) (base + gt_off(b_nloc, b_rs * 4 + ph * PW + j)) = o;
         }
     };
 
@@ -357,8 +363,8 @@ __global__ __launch_bounds__(256, 2) void q4_gemm_t16_kernel(const f16* __restri
             stage_a(cur ^ 1, (it + 1) * GT_BK);
             issue_b(it + 1);
         }
-        const unsigned char* at = lds + (size_t) cur * 2 * GT_TILE_BYTES;
-        const unsigned char* bt = at + GT_TILE_BYTES;
+        const unsigned char* at = lds + (size_t) cur * STAGE;
+        const unsigned char* bt = at + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             f16x8 xf[4], wf[4];
@@ -400,6 +406,26 @@ __global__ __launch_bounds__(256, 2) void q4_gemm_t16_kernel(const f16* __restri
     }
 }
 
+template <int WM>
+static int launch_gemm_t16(const Q4Matrix* w, const f16* xin, int rows, f16* out, int no_zero, int gshift, hipStream_t s)
+{
+    constexpr int TBM = 64 * WM;
+    const int K = w->height, N = w->width;
+    const int mtiles = (rows + TBM - 1) / TBM;
+    const int ntiles = (N + GT_BN - 1) / GT_BN;
+    const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
+    const size_t smem = 2 * ((size_t) TBM * 128 + GT_BTILE_BYTES);
+    static bool big = false;
+    if (smem > 64 * 1024 && !big) {
+        EXL_HIP(hipFuncSetAttribute((const void*) q4_gemm_t16_kernel<WM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        big = true;
+    }
+    hipLaunchKernelGGL(q4_gemm_t16_kernel<WM>, dim3(grid), dim3(WM * 128), smem, s, xin, (const uint4*) w->qweight, w->qzeros,
+                       w->scales, out, rows, K, N, gshift, w->groupsize, no_zero, mtiles, ntiles);
+    EXL_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_zero, f16* remap_tmp,
                    size_t remap_tmp_numel, hipStream_t s)
 {
@@ -421,10 +447,12 @@ int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
     const int ntiles = (N + BN - 1) / BN;
     const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
     static const bool use_reg_b = getenv("EXL_GEMM_REGISTER_B") != nullptr;     // A/B switch for measurements
-    if (w->layout == EXL_LAYOUT_T16 && !use_reg_b)
-        hipLaunchKernelGGL(q4_gemm_t16_kernel, dim3(grid), dim3(256), 0, s, xin, (const uint4*) w->qweight, w->qzeros, w->scales, out,
-                           rows, K, N, gshift, w->groupsize, no_zero, mtiles, ntiles);
-    else if (w->layout == EXL_LAYOUT_T16)
+    static const int force_wm = getenv("EXL_GEMM_WM") ? atoi(getenv("EXL_GEMM_WM")) : 0;
+    if (w->layout == EXL_LAYOUT_T16 && !use_reg_b) {
+        const bool big_tile = force_wm ? force_wm == 4 : rows > 512;      // 256-row tiles once there are enough rows to fill the chip
+        return big_tile ? launch_gemm_t16<4>(w, xin, rows, out, no_zero, gshift, s) : launch_gemm_t16<2>(w, xin, rows, out, no_zero, gshift, s);
+    }
+    if (w->layout == EXL_LAYOUT_T16)
         hipLaunchKernelGGL(q4_gemm_kernel<true>, dim3(grid), dim3(256), 0, s, xin, w->qweight, w->qzeros, w->scales, out, rows, K,
                            N, gshift, w->groupsize, no_zero, mtiles, ntiles);
     else

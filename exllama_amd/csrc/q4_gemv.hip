@@ -271,7 +271,7 @@ __global__ __launch_bounds__(T16_WAVES * 64) void q4_gemv_t16_kernel(const T16Ma
     w.init(m, t, lane, rb0, min(m.RB, rb0 + rb_per_wave));
     w.load_entries(m);
     w.issue(m, 0);
-    // activation rows -> LDS (permuted; gathered through x_map for act-order weights)
+    // activation rows -> LDS (gathered through x_map for act-order weights)
     for (int idx = tid; idx < rows * m.R; idx += NTH) {
         const int mm = idx / m.R, r = idx - mm * m.R;
         const f16* xr = x + (size_t) mm * m.K;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(T16_WAVES * 64) void q4_gemv_t16_kernel(const T16Ma
         } else {
             v = *(const uint4*) (xr + r * 8);
         }
-        xs[(size_t) mm * xstride + r] = t16_permute(v);
+        xs[(size_t) mm * xstride + r] = v;
     }
     __syncthreads();
     f32x4 c = {0.f, 0.f, 0.f, 0.f};

@@ -99,9 +99,18 @@ __global__ __launch_bounds__(256) void reconstruct_t16_kernel(const uint4* __res
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int q = (int) ((words[j] >> (4 * i)) & 0xFu);
+            const int q = (int) ((words[j] >> (4 * ((i >> 1) + 4 * (i & 1)))) & 0xFu);      // interleaved nibble of weight i
             out[(size_t) ((r0 + j) * 8 + i) * width + n] = (f16) (q - z) * sc;
         }
+}
+
+// nibble k of a GPTQ word -> nibble (k >> 1) + 4 * (k & 1): even weights in the low half-word, odd ones in the high one
+__device__ __forceinline__ uint32_t t16_interleave(uint32_t w)
+{
+    const uint32_t e = w & 0x0F0F0F0Fu, o = (w >> 4) & 0x0F0F0F0Fu;
+    const uint32_t ep = (e & 0xFu) | ((e >> 4) & 0xF0u) | ((e >> 8) & 0xF00u) | ((e >> 12) & 0xF000u);
+    const uint32_t op = (o & 0xFu) | ((o >> 4) & 0xF0u) | ((o >> 8) & 0xF00u) | ((o >> 12) & 0xF000u);
+    return ep | (op << 16);
 }
 
 // GPTQ [R][N] words -> T16 pieces.  One thread = one destination piece.
@@ -116,10 +125,10 @@ __global__ __launch_bounds__(256) void retile_t16_kernel(const uint32_t* __restr
     const int n = t * 16 + (lane & 15);
     const int r0 = rb * 16 + (lane >> 4) * 4;
     uint4 v;
-    v.x = src[(size_t) (r0 + 0) * width + n];
-    v.y = src[(size_t) (r0 + 1) * width + n];
-    v.z = src[(size_t) (r0 + 2) * width + n];
-    v.w = src[(size_t) (r0 + 3) * width + n];
+    v.x = t16_interleave(src[(size_t) (r0 + 0) * width + n]);
+    v.y = t16_interleave(src[(size_t) (r0 + 1) * width + n]);
+    v.z = t16_interleave(src[(size_t) (r0 + 2) * width + n]);
+    v.w = t16_interleave(src[(size_t) (r0 + 3) * width + n]);
     dst[p] = v;
 }
 
