@@ -406,6 +406,234 @@ __global__ __launch_bounds__(WM * 128) void q4_gemm_t16_kernel(const f16* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Same tile, deeper pipeline: activation tiles run TWO K steps ahead through a 3-slot LDS ring, the packed weight piece
+// (+ its zero word and scale) of step t+2 is in flight in registers while step t feeds the MFMAs and step t+1 is being
+// dequantised.  hipcc cannot count LDS-DMA next to ordinary loads (it drains with vmcnt(0)), so the register loads are
+// issued from inline asm and waited for with a hand-counted s_waitcnt: every K step issues exactly GP_BATCH VMEM
+// operations (4 DMA pieces + 3 loads), so "vmcnt(GP_BATCH)" = "everything of the previous step's batch has landed".
+// Barriers are raw s_barrier (a __syncthreads() would drain the DMA queue as well).
+// ---------------------------------------------------------------------------------------------------------------
+#define GP_BATCH 7
+
+template <int WM>
+__global__ __launch_bounds__(WM * 128) void q4_gemm_t16p_kernel(const f16* __restrict__ x, const uint4* __restrict__ qw,
+                                                               const uint32_t* __restrict__ qzeros,
+                                                               const f16* __restrict__ scales, f16* __restrict__ out, int M,
+                                                               int K, int N, int gshift, int groupsize, int no_zero, int mtiles,
+                                                               int ntiles)
+{
+    constexpr int TBM = 64 * WM;
+    constexpr int NTH = WM * 128;
+    constexpr int A_BYTES = TBM * 128;
+    constexpr int PW = 4 * 256 / NTH;                                 // words of a piece per thread (4 or 2)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [3][A] then [2][B]
+    unsigned char* const ldsB = lds + 3 * A_BYTES;
+
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int idx = b >> 3;
+    const int nl = idx / mtiles;
+    const int mt = idx - nl * mtiles;
+    const int nt = nl * 8 + xcd;
+    if (nt >= ntiles) return;
+    const int m0 = mt * TBM;
+    const int n0 = nt * GT_BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int RB = K >> 7;
+    const int nk = K / GT_BK;                                         // even (K % 128 == 0)
+
+    const f16* a_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = wave * 4 + i;
+        const int row = c * 8 + (lane >> 3);
+        const int slot = lane & 7;
+        const int grow = min(m0 + row, M - 1);
+        a_src[i] = x + (size_t) grow * K + ((slot ^ (row & 7)) << 3);
+    }
+    auto stage_a = [&](int slot3, int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __attribute__((address_space(3))) unsigned char* dst =
+                (__attribute__((address_space(3))) unsigned char*) (lds + (size_t) slot3 * A_BYTES + (wave * 4 + i) * 1024);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (a_src[i] + k0), dst, 16, 0, 0);
+        }
+    };
+
+    const int pid = PW == 4 ? tid : tid >> 1;
+    const int ph = PW == 4 ? 0 : tid & 1;
+    const int b_tile = pid >> 5;
+    const int b_rs = (pid >> 4) & 1;
+    const int b_col = pid & 15;
+    const int b_nloc = b_tile * 16 + b_col;
+    const int b_n = min(n0 + b_nloc, N - 1);
+    const uint32_t* b_src = (const uint32_t*) (qw + ((size_t) (b_n >> 4) * RB) * 64 + (b_n & 15)) + ph * PW;
+    const int b_zsh = (b_n & 7) * 4;
+    const uint32_t magic = t16_magic();
+
+    // register set of one K step: packed words, zero word, scale -- loaded by inline asm (3 VMEM operations)
+    struct BRegs { u32x4 w4; u32x2 w2; uint32_t zw, sc; };            // w4 (256 threads) or w2 (512 threads) holds the packed words
+    auto issue_b = [&](int it, BRegs& r) {
+        const int rb = it >> 1, rsub = (it & 1) * 2 + b_rs;
+        const uint32_t* p = b_src + ((size_t) rb * 64 + rsub * 16) * 4;
+        const int k = it * GT_BK + b_rs * 32;
+        const int grp = gshift >= 0 ? (k >> gshift) : (k / groupsize);
+        const uint32_t* zp = qzeros + (size_t) grp * (N >> 3) + (b_n >> 3);
+        const f16* sp = scales + (size_t) grp * N + b_n;
+        if constexpr (PW == 4) {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.w4) : "v"(p) : "memory");
+        } else {
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r.w2) : "v"(p) : "memory");
+        }
+        asm volatile("global_load_dword %0, %1, off" : "=v"(r.zw) : "v"(zp) : "memory");
+        asm volatile("global_load_ushort %0, %1, off" : "=v"(r.sc) : "v"(sp) : "memory");
+    };
+    // wait until at most `N` VMEM operations are outstanding, and tie the registers of `r` to the wait
+#define GP_WAIT(NSTR, r)                                                                                              \
+    do {                                                                                                              \
+        if constexpr (PW == 4) asm volatile("s_waitcnt vmcnt(" NSTR ")" : "+v"(r.w4), "+v"(r.zw), "+v"(r.sc) :: "memory"); \
+        else                   asm volatile("s_waitcnt vmcnt(" NSTR ")" : "+v"(r.w2), "+v"(r.zw), "+v"(r.sc) :: "memory"); \
+    } while (0)
+    auto store_b = [&](int slot2, const BRegs& r) {
+        const int z = (int) ((r.zw >> b_zsh) & 0xFu) + 1;
+        const f16 za = (f16) (float) (-(1024 + z));
+        const f16 zb = (f16) (float) (-(64 + z));
+        const f16 bsc = __builtin_bit_cast(f16, (uint16_t) (r.sc & 0xFFFFu));
+        const f16x2 zc0 = {za, za}, zc1 = {zb, zb}, s2 = {bsc, bsc};
+        // LDS byte address of this thread's first chunk; the stores go through inline asm: hipcc would otherwise drain
+        // the whole VMEM queue (vmcnt(0)) before an LDS store it can see while LDS-DMA writes are in flight
+        const uint32_t lbase = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned char*) (ldsB + (size_t) slot2 * GT_BTILE_BYTES);
+        const uint32_t words[4] = {PW == 4 ? r.w4[0] : r.w2[0], PW == 4 ? r.w4[1] : r.w2[1], PW == 4 ? r.w4[2] : 0u, PW == 4 ? r.w4[3] : 0u};
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            const f16x8 d = t16_dequant_exact(words[j], magic, zc0, zc1);
+            const uint4 u = __builtin_bit_cast(uint4, d);
+            uint4 o;
+            o.x = __builtin_bit_cast(uint32_t, as_h2(u.x) * s2); o.y = __builtin_bit_cast(uint32_t, as_h2(u.y) * s2);
+            o.z = __builtin_bit_cast(uint32_t, as_h2(u.z) * s2); o.w = __builtin_bit_cast(uint32_t, as_h2(u.w) * s2);
+            const u32x4 ov = {o.x, o.y, o.z, o.w};
+            asm volatile("ds_write_b128 %0, %1" :: "v"(lbase + (uint32_t) gt_off(b_nloc, b_rs * 4 + ph * PW + j)), "v"(ov) : "memory");
+        }
+    };
+    auto block_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wave's ds_writes are in LDS
+        __builtin_amdgcn_s_barrier();
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fk = lane >> 4;
+    auto compute = [&](int slot3, int slot2) {
+        const unsigned char* at = lds + (size_t) slot3 * A_BYTES;
+        const unsigned char* bt = ldsB + (size_t) slot2 * GT_BTILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f16x8 xf[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xf[i] = *(const f16x8*) (at + gt_off(wm * 64 + i * 16 + fr, kk * 4 + fk));
+                wf[i] = *(const f16x8*) (bt + gt_off(wn * 64 + i * 16 + fr, kk * 4 + fk));
+            }
+#pragma unroll
+            for (int in = 0; in < 4; ++in)
+#pragma unroll
+                for (int im = 0; im < 4; ++im)
+                    acc[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[in], xf[im], acc[in][im], 0, 0, 0);
+        }
+    };
+
+    // ---- prologue: batches 0 and 1 in flight, B(0) dequantised --------------------------------------------------------
+    BRegs rX, rY;
+    stage_a(0, 0);
+    issue_b(0, rX);
+    stage_a(1, GT_BK);                                                    // nk >= 2 always
+    issue_b(1, rY);
+    GP_WAIT("7", rX);                                                     // batch 0 landed (batch 1 may still fly)
+    store_b(0, rX);
+    block_barrier();
+
+    // ---- main loop, two K steps per trip (register sets X / Y swap roles); straight-line: every wait is unconditional ----
+    int a_slot = 0;                                                       // LDS ring slot of tile `it`
+    auto ring = [](int s, int d) { const int v = s + d; return v >= 3 ? v - 3 : v; };
+    int it = 0;
+    for (; it + 3 < nk; it += 2) {
+        // step it: tile it computes, B(it+1) waits in rY, batch it+2 is fetched into (ring slot + 2, rX)
+        stage_a(ring(a_slot, 2), (it + 2) * GT_BK);
+        issue_b(it + 2, rX);
+        compute(a_slot, 0);
+        GP_WAIT("7", rY);                                                 // batch it+1 landed
+        store_b(1, rY);
+        block_barrier();
+        a_slot = ring(a_slot, 1);
+        // step it+1: tile it+1 computes, B(it+2) waits in rX, batch it+3 is fetched into rY
+        stage_a(ring(a_slot, 2), (it + 3) * GT_BK);
+        issue_b(it + 3, rY);
+        compute(a_slot, 1);
+        GP_WAIT("7", rX);                                                 // batch it+2 landed
+        store_b(0, rX);
+        block_barrier();
+        a_slot = ring(a_slot, 1);
+    }
+    // ---- last two K steps: nothing left to fetch ----------------------------------------------------------------------
+    compute(a_slot, 0);
+    GP_WAIT("0", rY);
+    store_b(1, rY);
+    block_barrier();
+    a_slot = ring(a_slot, 1);
+    compute(a_slot, 1);
+#undef GP_WAIT
+
+#pragma unroll
+    for (int im = 0; im < 4; ++im) {
+        const int row = m0 + wm * 64 + im * 16 + fr;
+        if (row < M) {
+#pragma unroll
+            for (int in = 0; in < 4; ++in) {
+                const int n = n0 + wn * 64 + in * 16 + fk * 4;
+                if (n < N) {
+                    f16* op = out + (size_t) row * N + n;
+                    float v[4] = {acc[in][im][0], acc[in][im][1], acc[in][im][2], acc[in][im][3]};
+                    if (no_zero) {
+                        const f16x4 prev = *(const f16x4*) op;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += (float) prev[j];
+                    }
+                    *(f16x4*) op = (f16x4){(f16) v[0], (f16) v[1], (f16) v[2], (f16) v[3]};
+                }
+            }
+        }
+    }
+}
+
+template <int WM>
+static int launch_gemm_t16p(const Q4Matrix* w, const f16* xin, int rows, f16* out, int no_zero, int gshift, hipStream_t s)
+{
+    constexpr int TBM = 64 * WM;
+    const int K = w->height, N = w->width;
+    const int mtiles = (rows + TBM - 1) / TBM;
+    const int ntiles = (N + GT_BN - 1) / GT_BN;
+    const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
+    const size_t smem = 3 * (size_t) TBM * 128 + 2 * GT_BTILE_BYTES;
+    static bool big = false;
+    if (smem > 64 * 1024 && !big) {
+        EXL_HIP(hipFuncSetAttribute((const void*) q4_gemm_t16p_kernel<WM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        big = true;
+    }
+    hipLaunchKernelGGL(q4_gemm_t16p_kernel<WM>, dim3(grid), dim3(WM * 128), smem, s, xin, (const uint4*) w->qweight, w->qzeros,
+                       w->scales, out, rows, K, N, gshift, w->groupsize, no_zero, mtiles, ntiles);
+    EXL_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int WM>
 static int launch_gemm_t16(const Q4Matrix* w, const f16* xin, int rows, f16* out, int no_zero, int gshift, hipStream_t s)
 {
@@ -450,7 +678,9 @@ int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
     static const int force_wm = getenv("EXL_GEMM_WM") ? atoi(getenv("EXL_GEMM_WM")) : 0;
     if (w->layout == EXL_LAYOUT_T16 && !use_reg_b) {
         const bool big_tile = force_wm ? force_wm == 4 : rows > 512;      // 256-row tiles once there are enough rows to fill the chip
-        return big_tile ? launch_gemm_t16<4>(w, xin, rows, out, no_zero, gshift, s) : launch_gemm_t16<2>(w, xin, rows, out, no_zero, gshift, s);
+        static const bool two_stage = getenv("EXL_GEMM_TWO_STAGE") != nullptr;          // A/B switch: the simpler double-buffered kernel
+        if (two_stage) return big_tile ? launch_gemm_t16<4>(w, xin, rows, out, no_zero, gshift, s) : launch_gemm_t16<2>(w, xin, rows, out, no_zero, gshift, s);
+        return big_tile ? launch_gemm_t16p<4>(w, xin, rows, out, no_zero, gshift, s) : launch_gemm_t16p<2>(w, xin, rows, out, no_zero, gshift, s);
     }
     if (w->layout == EXL_LAYOUT_T16)
         hipLaunchKernelGGL(q4_gemm_kernel<true>, dim3(grid), dim3(256), 0, s, xin, w->qweight, w->qzeros, w->scales, out, rows, K,
