@@ -416,15 +416,21 @@ __global__ __launch_bounds__(WM * 128) void q4_gemm_t16_kernel(const f16* __rest
 // ---------------------------------------------------------------------------------------------------------------
 #define GP_BATCH 7
 
-template <int WM>
-__global__ __launch_bounds__(WM * 128) void q4_gemm_t16p_kernel(const f16* __restrict__ x, const uint4* __restrict__ qw,
+// WAVES_M x WAVES_N waves, each TM x TN tiles of 16 x 16: block = (WAVES_M * TM * 16) rows x 128 columns (WAVES_N * TN == 8).
+// Fewer, fatter waves read fewer LDS fragments per MFMA ((TM + TN) / (TM * TN)): the kernel is LDS-bandwidth bound.
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void q4_gemm_t16p_kernel(const f16* __restrict__ x, const uint4* __restrict__ qw,
                                                                const uint32_t* __restrict__ qzeros,
                                                                const f16* __restrict__ scales, f16* __restrict__ out, int M,
                                                                int K, int N, int gshift, int groupsize, int no_zero, int mtiles,
                                                                int ntiles)
 {
-    constexpr int TBM = 64 * WM;
-    constexpr int NTH = WM * 128;
+    static_assert(WAVES_N * TN == 8, "block is 128 columns wide");
+    constexpr int TBM = WAVES_M * TM * 16;
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int NTH = NW * 64;
+    constexpr int APW = (TBM / 8) / NW;                               // 1 KiB activation pieces per wave per K step
+    static_assert(APW * NW * 8 == TBM, "activation pieces must divide evenly");
     constexpr int A_BYTES = TBM * 128;
     constexpr int PW = 4 * 256 / NTH;                                 // words of a piece per thread (4 or 2)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [3][A] then [2][B]
@@ -443,14 +449,14 @@ __global__ __launch_bounds__(WM * 128) void q4_gemm_t16p_kernel(const f16* __res
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int RB = K >> 7;
     const int nk = K / GT_BK;                                         // even (K % 128 == 0)
 
-    const f16* a_src[4];
+    const f16* a_src[APW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = wave * 4 + i;
+    for (int i = 0; i < APW; ++i) {
+        const int c = wave * APW + i;
         const int row = c * 8 + (lane >> 3);
         const int slot = lane & 7;
         const int grow = min(m0 + row, M - 1);
@@ -458,14 +464,14 @@ __global__ __launch_bounds__(WM * 128) void q4_gemm_t16p_kernel(const f16* __res
     }
     auto stage_a = [&](int slot3, int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < APW; ++i) {
             __attribute__((address_space(3))) unsigned char* dst =
-                (__attribute__((address_space(3))) unsigned char*) (lds + (size_t) slot3 * A_BYTES + (wave * 4 + i) * 1024);
+                (__attribute__((address_space(3))) unsigned char*) (lds + (size_t) slot3 * A_BYTES + (wave * APW + i) * 1024);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (a_src[i] + k0), dst, 16, 0, 0);
         }
     };
 
-    const int pid = PW == 4 ? tid : tid >> 1;
+    const int pid = PW == 4 ? tid : tid >> 1;                          // 256 or 512 threads
     const int ph = PW == 4 ? 0 : tid & 1;
     const int b_tile = pid >> 5;
     const int b_rs = (pid >> 4) & 1;
@@ -499,6 +505,9 @@ __global__ __launch_bounds__(WM * 128) void q4_gemm_t16p_kernel(const f16* __res
         if constexpr (PW == 4) asm volatile("s_waitcnt vmcnt(" NSTR ")" : "+v"(r.w4), "+v"(r.zw), "+v"(r.sc) :: "memory"); \
         else                   asm volatile("s_waitcnt vmcnt(" NSTR ")" : "+v"(r.w2), "+v"(r.zw), "+v"(r.sc) :: "memory"); \
     } while (0)
+    // one K step's batch = APW DMA pieces + 3 loads: "at most one batch outstanding" = the previous batch has landed
+#define GP_WAITB(r) do { if constexpr (APW == 4) GP_WAIT("7", r); else if constexpr (APW == 8) GP_WAIT("11", r); else GP_WAIT("5", r); } while (0)
+    static_assert(APW == 2 || APW == 4 || APW == 8, "unsupported activation piece count");
     auto store_b = [&](int slot2, const BRegs& r) {
         const int z = (int) ((r.zw >> b_zsh) & 0xFu) + 1;
         const f16 za = (f16) (float) (-(1024 + z));
@@ -525,11 +534,11 @@ __global__ __launch_bounds__(WM * 128) void q4_gemm_t16p_kernel(const f16* __res
         __builtin_amdgcn_s_barrier();
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[TN][TM];                                                   // [n-tile][m-tile]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fk = lane >> 4;
     auto compute = [&](int slot3, int slot2) {
@@ -537,16 +546,15 @@ __global__ __launch_bounds__(WM * 128) void q4_gemm_t16p_kernel(const f16* __res
         const unsigned char* bt = ldsB + (size_t) slot2 * GT_BTILE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            f16x8 xf[4], wf[4];
+            f16x8 xf[TM], wf[TN];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                xf[i] = *(const f16x8*) (at + gt_off(wm * 64 + i * 16 + fr, kk * 4 + fk));
-                wf[i] = *(const f16x8*) (bt + gt_off(wn * 64 + i * 16 + fr, kk * 4 + fk));
-            }
+            for (int i = 0; i < TM; ++i) xf[i] = *(const f16x8*) (at + gt_off((wm * TM + i) * 16 + fr, kk * 4 + fk));
 #pragma unroll
-            for (int in = 0; in < 4; ++in)
+            for (int i = 0; i < TN; ++i) wf[i] = *(const f16x8*) (bt + gt_off((wn * TN + i) * 16 + fr, kk * 4 + fk));
 #pragma unroll
-                for (int im = 0; im < 4; ++im)
+            for (int in = 0; in < TN; ++in)
+#pragma unroll
+                for (int im = 0; im < TM; ++im)
                     acc[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[in], xf[im], acc[in][im], 0, 0, 0);
         }
     };
@@ -557,7 +565,7 @@ __global__ __launch_bounds__(WM * 128) void q4_gemm_t16p_kernel(const f16* __res
     issue_b(0, rX);
     stage_a(1, GT_BK);                                                    // nk >= 2 always
     issue_b(1, rY);
-    GP_WAIT("7", rX);                                                     // batch 0 landed (batch 1 may still fly)
+    GP_WAITB(rX);                                                         // batch 0 landed (batch 1 may still fly)
     store_b(0, rX);
     block_barrier();
 
@@ -570,7 +578,7 @@ __global__ __launch_bounds__(WM * 128) void q4_gemm_t16p_kernel(const f16* __res
         stage_a(ring(a_slot, 2), (it + 2) * GT_BK);
         issue_b(it + 2, rX);
         compute(a_slot, 0);
-        GP_WAIT("7", rY);                                                 // batch it+1 landed
+        GP_WAITB(rY);                                                     // batch it+1 landed
         store_b(1, rY);
         block_barrier();
         a_slot = ring(a_slot, 1);
@@ -578,7 +586,7 @@ __global__ __launch_bounds__(WM * 128) void q4_gemm_t16p_kernel(const f16* __res
         stage_a(ring(a_slot, 2), (it + 3) * GT_BK);
         issue_b(it + 3, rY);
         compute(a_slot, 1);
-        GP_WAIT("7", rX);                                                 // batch it+2 landed
+        GP_WAITB(rX);                                                     // batch it+2 landed
         store_b(0, rX);
         block_barrier();
         a_slot = ring(a_slot, 1);
@@ -590,15 +598,16 @@ __global__ __launch_bounds__(WM * 128) void q4_gemm_t16p_kernel(const f16* __res
     block_barrier();
     a_slot = ring(a_slot, 1);
     compute(a_slot, 1);
+#undef GP_WAITB
 #undef GP_WAIT
 
 #pragma unroll
-    for (int im = 0; im < 4; ++im) {
-        const int row = m0 + wm * 64 + im * 16 + fr;
+    for (int im = 0; im < TM; ++im) {
+        const int row = m0 + (wm * TM + im) * 16 + fr;
         if (row < M) {
 #pragma unroll
-            for (int in = 0; in < 4; ++in) {
-                const int n = n0 + wn * 64 + in * 16 + fk * 4;
+            for (int in = 0; in < TN; ++in) {
+                const int n = n0 + (wn * TN + in) * 16 + fk * 4;
                 if (n < N) {
                     f16* op = out + (size_t) row * N + n;
                     float v[4] = {acc[in][im][0], acc[in][im][1], acc[in][im][2], acc[in][im][3]};
@@ -614,21 +623,22 @@ __global__ __launch_bounds__(WM * 128) void q4_gemm_t16p_kernel(const f16* __res
     }
 }
 
-template <int WM>
+template <int WAVES_M, int WAVES_N, int TM, int TN>
 static int launch_gemm_t16p(const Q4Matrix* w, const f16* xin, int rows, f16* out, int no_zero, int gshift, hipStream_t s)
 {
-    constexpr int TBM = 64 * WM;
+    constexpr int TBM = WAVES_M * TM * 16;
     const int K = w->height, N = w->width;
     const int mtiles = (rows + TBM - 1) / TBM;
     const int ntiles = (N + GT_BN - 1) / GT_BN;
     const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
     const size_t smem = 3 * (size_t) TBM * 128 + 2 * GT_BTILE_BYTES;
+    auto kfn = q4_gemm_t16p_kernel<WAVES_M, WAVES_N, TM, TN>;
     static bool big = false;
     if (smem > 64 * 1024 && !big) {
-        EXL_HIP(hipFuncSetAttribute((const void*) q4_gemm_t16p_kernel<WM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EXL_HIP(hipFuncSetAttribute((const void*) kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         big = true;
     }
-    hipLaunchKernelGGL(q4_gemm_t16p_kernel<WM>, dim3(grid), dim3(WM * 128), smem, s, xin, (const uint4*) w->qweight, w->qzeros,
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(WAVES_M * WAVES_N * 64), smem, s, xin, (const uint4*) w->qweight, w->qzeros,
                        w->scales, out, rows, K, N, gshift, w->groupsize, no_zero, mtiles, ntiles);
     EXL_LAUNCH_CHECK();
     return 0;
@@ -680,7 +690,13 @@ int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
         const bool big_tile = force_wm ? force_wm == 4 : rows > 512;      // 256-row tiles once there are enough rows to fill the chip
         static const bool two_stage = getenv("EXL_GEMM_TWO_STAGE") != nullptr;          // A/B switch: the simpler double-buffered kernel
         if (two_stage) return big_tile ? launch_gemm_t16<4>(w, xin, rows, out, no_zero, gshift, s) : launch_gemm_t16<2>(w, xin, rows, out, no_zero, gshift, s);
-        return big_tile ? launch_gemm_t16p<4>(w, xin, rows, out, no_zero, gshift, s) : launch_gemm_t16p<2>(w, xin, rows, out, no_zero, gshift, s);
+        static const int variant = getenv("EXL_GEMM_VARIANT") ? atoi(getenv("EXL_GEMM_VARIANT")) : 0;
+        if (!big_tile) return launch_gemm_t16p<2, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s);        // 128 x 128, 4 waves
+        switch (variant) {                                               // measured at M = 2048 (7B layer): 812-827 / 735 / 738 TFLOP/s
+        case 2:  return launch_gemm_t16p<4, 1, 4, 8>(w, xin, rows, out, no_zero, gshift, s);               // 256 x 128, 4 waves of 64 x 128
+        case 3:  return launch_gemm_t16p<2, 2, 8, 4>(w, xin, rows, out, no_zero, gshift, s);               // 256 x 128, 4 waves of 128 x 64
+        default: return launch_gemm_t16p<4, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s);               // 256 x 128, 8 waves of 64 x 64
+        }
     }
     if (w->layout == EXL_LAYOUT_T16)
         hipLaunchKernelGGL(q4_gemm_kernel<true>, dim3(grid), dim3(256), 0, s, xin, w->qweight, w->qzeros, w->scales, out, rows, K,
