@@ -244,14 +244,24 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
                                                        f16* __restrict__ vc, const f16* __restrict__ sin,
                                                        const f16* __restrict__ cos, float* __restrict__ partial,
                                                        const int32_t* __restrict__ pos_dev, int heads, int kv_heads,
-                                                       int max_seq, int nsplit, float scale)
+                                                       int max_seq, int nsplit, float scale, f16* __restrict__ direct_out)
 {
     constexpr int HD = 128, LPK = 16, KPI = 16, UN = DEC_ATT_UN;
     __shared__ float sc[DEC_ATT_MAX_KEYS];
     __shared__ float red[KPI][HD + 1];
     __shared__ float stat[8];
 
-    const int split = blockIdx.x, h = blockIdx.y;
+    // 1-D grid; block id -> (head, split) such that every split of head h runs on XCD h % 8 (block b runs on XCD b % 8,
+    // observed, speed only): the merge block of head h (XCD h % 8 as well) then finds the partials in its own L2.
+    int h, split;
+    if ((heads & 7) == 0) {
+        const int r = blockIdx.x & 7, j = blockIdx.x >> 3;
+        h = r + 8 * (j / nsplit);
+        split = j % nsplit;
+    } else {
+        h = blockIdx.x / nsplit;
+        split = blockIdx.x % nsplit;
+    }
     const int tid = threadIdx.x;
     const int d8 = tid & 15, ks = tid >> 4;
     const int past = *pos_dev;
@@ -389,9 +399,10 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
         float v = 0.f;
 #pragma unroll
         for (int s = 0; s < KPI; ++s) v += red[s][tid];
-        pp[tid] = v;
+        if (direct_out) direct_out[h * HD + tid] = (f16) (v / lsum);   // a single split: this IS the attention output
+        else pp[tid] = v;
     }
-    if (tid == 0) {
+    if (tid == 0 && !direct_out) {
         pp[HD] = nkeys > 0 ? mx : -INFINITY;
         pp[HD + 1] = nkeys > 0 ? lsum : 0.f;
     }
@@ -503,7 +514,8 @@ struct Decoder {
     std::vector<DecLayer> layers;
     f16 *hid, *qbuf, *kbuf, *vbuf, *attn_out, *act;
     float* partial;
-    int nsplit;
+    int nsplit;                   // KV splits of the attention kernel in use (<= nsplit_max)
+    int nsplit_max;
     int max_blocks;               // persistent GEMV grid: blocks per CU x CUs
     void* block;                  // one hipMalloc
 };
@@ -535,6 +547,7 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     while ((max_seq_len + ns - 1) / ns + 16 > DEC_ATT_MAX_KEYS) ++ns;
     if (ns > DEC_MAX_NSPLIT) { delete d; EXL_FAIL(EXL_E_UNSUPPORTED, "decoder: max_seq_len %d too long (max %d)", max_seq_len, DEC_MAX_NSPLIT * (DEC_ATT_MAX_KEYS - 16)); }
     d->nsplit = ns;
+    d->nsplit_max = ns;
     const int kvd = kv_heads * head_dim;
     size_t bytes = 0;
     auto carve = [&](size_t n) { const size_t off = bytes; bytes += (n + 255) & ~(size_t) 255; return off; };
@@ -593,6 +606,20 @@ extern "C" int exl_decoder_set_layer(void* dec, int index, void* q, void* k, voi
     l.in_norm = (const f16*) in_norm; l.post_norm = (const f16*) post_norm;
     l.kc = (f16*) key_cache; l.vc = (f16*) value_cache;
     l.set = true;
+    return 0;
+}
+
+extern "C" int exl_decoder_set_kv_splits(void* dec, int nsplit, int* max_context)
+{
+    Decoder* d = dec_from(dec);
+    EXL_REQUIRE(d, EXL_E_INVALID, "decoder_set_kv_splits: invalid decoder");
+    if (nsplit <= 0) nsplit = d->nsplit_max;
+    EXL_REQUIRE(nsplit <= d->nsplit_max, EXL_E_INVALID, "decoder_set_kv_splits: %d splits requested, at most %d", nsplit, d->nsplit_max);
+    d->nsplit = nsplit;
+    if (max_context) {                                               // keys visible = context + 1 must fit nsplit * (MAX_KEYS - 16)
+        const long cap = (long) nsplit * (DEC_ATT_MAX_KEYS - 16) - 1;
+        *max_context = (int) (cap < d->max_seq - 1 ? cap : d->max_seq - 1);
+    }
     return 0;
 }
 
@@ -691,12 +718,13 @@ static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int3
         return launch_dec_gemv(d->max_blocks, 1, 0, xin, tk, l.in_norm, d->eps, hc, 3, qkv, qkv_out, nullptr, s);
     }
     case EXL_DEC_ATTN:
-        hipLaunchKernelGGL(dec_attn_kernel, dim3(d->nsplit, d->heads), dim3(256), 0, s, d->qbuf, d->kbuf, d->vbuf, l.kc, l.vc,
+        hipLaunchKernelGGL(dec_attn_kernel, dim3(d->nsplit * d->heads), dim3(256), 0, s, d->qbuf, d->kbuf, d->vbuf, l.kc, l.vc,
                            d->sin, d->cos, d->partial, pos_dev, d->heads, d->kv_heads, d->max_seq, d->nsplit,
-                           1.0f / sqrtf((float) d->hd));
+                           1.0f / sqrtf((float) d->hd), d->nsplit == 1 ? d->attn_out : (f16*) nullptr);
         EXL_LAUNCH_CHECK();
         return 0;
     case EXL_DEC_MERGE:
+        if (d->nsplit == 1) return 0;                                // the attention kernel wrote the output itself
         hipLaunchKernelGGL(dec_attn_merge_kernel, dim3(d->heads), dim3(128), 0, s, d->partial, d->attn_out, d->nsplit);
         EXL_LAUNCH_CHECK();
         return 0;

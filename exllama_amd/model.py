@@ -627,7 +627,7 @@ class ExLlama:
                                                          cache.key_states[i].data_ptr(), cache.value_states[i].data_ptr()),
                                "decoder_set_layer")
         st = {
-            "handle": handle, "cache": cache, "dev": dev, "graph": None,
+            "handle": handle, "cache": cache, "dev": dev, "graph": None, "graphs": [],
             "tok": torch.zeros((1, 1), dtype=torch.int64, device=dev),
             "pos": torch.zeros((1,), dtype=torch.int32, device=dev),
             "logits": torch.zeros((1, 1, cfg.vocab_size), dtype=torch.float32, device=dev),
@@ -635,14 +635,27 @@ class ExLlama:
         }
         self._decoder = st
         if use_graph:
-            st["pos"].fill_(cache.current_seq_len)
-            self._decoder_launch(st, advance=0)                 # eager dry run (K/V written at the current slot are
-            torch.cuda.synchronize(dev)                          # overwritten by the real token later)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._decoder_launch(st, advance=1)
-            st["graph"] = g
-            st["dev_pos"] = cache.current_seq_len
+            # one captured graph per context bucket: short contexts use fewer KV splits (1 split = no merge kernel)
+            st["graphs"] = []
+            start = cache.current_seq_len
+            st["pos"].fill_(start)
+            self._decoder_launch(st, advance=0)                 # eager dry run with the full split count (the K/V written
+            torch.cuda.synchronize(dev)                          # at the current slot are overwritten by the real token later)
+            for ns in (1, 4, 0):                                # 0 = the decoder's maximum
+                lim = C.c_int()
+                rc = lib.exl_decoder_set_kv_splits(handle, ns, C.byref(lim))
+                if rc != 0:
+                    continue                                    # more splits than this decoder has: covered by the last bucket
+                limit = min(lim.value, {1: 160, 4: 640}.get(ns, lim.value))
+                if st["graphs"] and limit <= st["graphs"][-1][0]:
+                    continue
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):                        # capture only records: nothing runs at this position
+                    self._decoder_launch(st, advance=1)
+                st["graphs"].append((limit, g))
+            st["graph"] = st["graphs"][-1][1]
+            st["pos"].fill_(start)
+            st["dev_pos"] = start
 
     def _decoder_launch(self, st, advance):
         with cuda_ext._Guard(st["dev"]):
@@ -658,7 +671,12 @@ class ExLlama:
         if st["dev_pos"] != cache.current_seq_len:              # host rewound / advanced the cache outside the executor
             st["pos"].fill_(cache.current_seq_len)
         if st["graph"] is not None:
-            st["graph"].replay()
+            for limit, g in st["graphs"]:                        # first bucket whose context limit covers this position
+                if cache.current_seq_len <= limit:
+                    g.replay()
+                    break
+            else:
+                raise RuntimeError(f"position {cache.current_seq_len} beyond the decoder's context limit")
         else:
             self._decoder_launch(st, advance=1)
         cache.current_seq_len += 1

@@ -174,6 +174,11 @@ int exl_decoder_set_layer(void* decoder, int index, void* q, void* k, void* v, v
  * 6 kernels per layer + 1, no allocation, no synchronisation: capturable in a hipGraph. */
 int exl_decoder_step(void* decoder, const int64_t* token_dev, int32_t* pos_dev, float* logits_out, int advance,
                      void* stream);
+/* Number of KV splits the attention kernel of subsequent steps uses (1 .. the value chosen at creation; 0 = that value).
+ * One split skips the merge kernel (5 kernels per layer).  *max_context (may be NULL) receives the longest context
+ * (position) a step with this setting can serve.  A captured graph keeps the setting it was captured with, so a caller
+ * can hold one graph per context bucket and pick by position (exllama_amd/model.py does). */
+int exl_decoder_set_kv_splits(void* decoder, int nsplit, int* max_context);
 /* Measurement aid (bench.py): for each kernel class, `reps` passes over all layers' launches of that class back to
  * back between two hipEvents on `stream` (the weights stream from HBM as in a real step); class_ms_host[c] (HOST memory,
  * EXL_DEC_NCLASS floats) = mean time of one pass = that class' share of one token.  Overwrites the K/V slot at *pos_dev,

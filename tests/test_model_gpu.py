@@ -181,7 +181,11 @@ def test_native_decode_executor_matches_op_path_and_oracle(name, gs, act):
     top2 = prev.topk(2, dim=-1).values
     clear = (top2[:, 0] - top2[:, 1]) > 4e-2 * scale
     assert all(a == b for a, b, ok in zip(toks_eager, toks_ops, clear.tolist()) if ok)
-    assert torch.equal(graph, eager) and toks_graph == toks_eager          # replayed graph == eager launches, bit for bit
+    # the replayed graphs pick their KV-split count by context bucket (1 split here), the eager launches use the decoder's
+    # maximum: same arithmetic, different summation order of the attention partials
+    assert (graph - eager).abs().max().item() <= 2e-3 * scale
+    graph2, toks_graph2, _ = run("graph", forced=toks_ops)
+    assert torch.equal(graph, graph2) and toks_graph == toks_graph2         # bit-reproducible run to run
     for l in range(len(c_ops.key_states)):
         ka, kb = c_ops.key_states[l][:, :, :32].float(), c_graph.key_states[l][:, :, :32].float()
         assert (ka - kb).abs().max().item() <= 2e-2 * ka.abs().max().item()
