@@ -252,9 +252,19 @@ def decoder_roofline_probe(model, cache, dims, g, ctx, steps=6):
         classes[k] = {"us_per_launch": round(us, 3), "GBps": round(per_launch[k] / us / 1e3, 1) if per_launch[k] else None}
     dom = "gate_up"
     achieved = per_launch[dom] / (ms[dom] / L / 1e3) / 1e9
+    # HBM traffic of the same kernel from the PMC counters: collected OFFLINE in separate rocprofv3 --pmc passes
+    # (scripts/pmc_traffic.sh -> profiles/r01_pmc_traffic.json); only valid for the shapes it was measured on
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        if (h, I, g) == (4096, 11008, 128):
+            traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     return {"bound": "hbm", "kernel": "dec_stream_kernel<PNORM=1, EMODE=2> (fused RMSNorm + gate/up projections + SiLU*mul, one launch per layer)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None, "launches": L * steps, "avg_launch_us": round(ms[dom] * 1e3 / L, 3),
+            "traffic": traffic, "launches": L * steps, "avg_launch_us": round(ms[dom] * 1e3 / L, 3),
             "algorithmic_bytes_per_launch": int(per_launch[dom]), "classes": classes,
             "token_ms_sum_of_classes": round(sum(ms.values()), 4),
             "note": "per class: %d passes over all %d layers' launches of that kernel, back to back between two HIP events on the "
