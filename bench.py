@@ -69,6 +69,21 @@ def prefill_flops(dims, S):
     return linear + attn + 2 * h * V
 
 
+def reduce_over_ranks(local_values, dist, device):
+    """The contract's timing rule: every rank contributes its own timings, the job's timing is the MAX over ranks.
+    `dist` is torch.distributed (initialised) or None for a single process."""
+    t = torch.tensor(list(local_values), dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.tolist()
+
+
+def whole_job_rates(world, S, G, prefill_ms, worst_ms, best_ms):
+    """Replicas are independent (one model copy and one prompt per GPU, no data-path collective): the job's throughput
+    is the sum over ranks of tokens / the slowest rank's time."""
+    return {"prefill": world * S / (prefill_ms / 1e3), "worst": world * G / (worst_ms / 1e3), "best": world * G / (best_ms / 1e3)}
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -154,15 +169,10 @@ def main():
         phase_ms["worst"].append(e[1].elapsed_time(e[2]))
         phase_ms["best"].append(e[3].elapsed_time(e[4]))
     mean = lambda v: sum(v) / len(v)
-    local = torch.tensor([elapsed, mean(phase_ms["prefill"]), mean(phase_ms["worst"]), mean(phase_ms["best"])],
-                         dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(local, op=dist.ReduceOp.MAX)             # contract: MAX over ranks
-    elapsed, prefill_ms, worst_ms, best_ms = local.tolist()
-
-    decode_tps = world * G / (worst_ms / 1e3)
-    best_tps = world * G / (best_ms / 1e3)
-    prefill_tps = world * S / (prefill_ms / 1e3)
+    elapsed, prefill_ms, worst_ms, best_ms = reduce_over_ranks(
+        [elapsed, mean(phase_ms["prefill"]), mean(phase_ms["worst"]), mean(phase_ms["best"])], dist, dev)   # MAX over ranks
+    rates = whole_job_rates(world, S, G, prefill_ms, worst_ms, best_ms)
+    decode_tps, best_tps, prefill_tps = rates["worst"], rates["best"], rates["prefill"]
 
     result = {
         "metric": "single-token decode tokens/s at full context (prefill tokens/s alongside), Llama GPTQ 4-bit",
