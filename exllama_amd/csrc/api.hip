@@ -258,8 +258,9 @@ static int q4_dispatch(Q4Matrix* m, const void* x, int rows, void* out, int no_z
 #define Q4_PROLOGUE(name)                                                                      \
     Q4Matrix* m = q4_from_handle(w);                                                           \
     EXL_REQUIRE(m, EXL_E_INVALID, name ": invalid q4 handle");                                 \
-    EXL_REQUIRE(x && out, EXL_E_INVALID, name ": null tensor pointer");                        \
     EXL_REQUIRE(x_height >= 0, EXL_E_INVALID, name ": negative row count");                    \
+    if (x_height == 0) return 0;                              /* empty activations: nothing to do */ \
+    EXL_REQUIRE(x && out, EXL_E_INVALID, name ": null tensor pointer");                        \
     DeviceGuard guard(m->device);                                                              \
     EXL_REQUIRE(guard.ok, EXL_E_INVALID, name ": cannot select device %d", m->device);         \
     DeviceBuffers* bufs = exl_buffers(m->device);

@@ -38,9 +38,17 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const f16* __restric
     unsigned char* k_lds = lds;
     unsigned char* vt_lds = lds + FA_BKV * FA_HD * 2;
 
-    const int qb = blockIdx.x;
-    const int h = blockIdx.y;
-    const int b = blockIdx.z;
+    // 1-D grid.  Causal work grows with the query block (block qb walks qb + 1 key tiles of 128), and the blocks that
+    // end up co-resident on a CU are `half` apart in launch order (two 256-thread blocks per CU when the grid is 2 x CUs):
+    // the second half of the grid walks the query blocks in REVERSE, so a CU gets qb and nqb-1-qb -- equal work per CU.
+    const int nqb = (q_len + FA_BQ - 1) / FA_BQ;
+    const int total = gridDim.x;
+    const int L = blockIdx.x;
+    const int qi = L % nqb;
+    const int hb = L / nqb;
+    const int qb = (2 * L >= total) ? nqb - 1 - qi : qi;
+    const int h = hb % heads;
+    const int b = hb / heads;
     const int kvh = h / (heads / kv_heads);
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -143,15 +151,22 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const f16* __restric
         // ---- causal mask + online softmax (this lane: query qrow, keys kv0 + kt*32 + (r&3)+8*(r>>2)+4*g) ----
         const int limit = past_len + qrow;                     // last visible key
         float mx = -INFINITY;
+        if (kv0 + FA_BKV - 1 <= past_len + q0 + wave * 32) {    // wave-uniform: the whole tile is visible to every row of this wave
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                const float v = key <= limit ? s[kt][r] : -INFINITY;
-                s[kt][r] = v;
-                mx = fmaxf(mx, v);
-            }
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    const float v = key <= limit ? s[kt][r] : -INFINITY;
+                    s[kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);                  // finite from tile 0 on (key 0 is always visible)
         const float alpha = exp2f((m_run - m_new) * c1);
@@ -168,10 +183,12 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const f16* __restric
             }
         l_run = fmaf(l_run, alpha, psum);
         m_run = m_new;
+        if (!__all(alpha == 1.0f)) {                           // wave-uniform: no row's running maximum moved -> nothing to rescale
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc_o[dt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) acc_o[dt][r] *= alpha;
+        }
 
         // ---- O^T += V^T P^T ---------------------------------------------------------------------------------
 #pragma unroll
@@ -203,9 +220,8 @@ int launch_flash_prefill(const f16* q, const f16* kc, const f16* vc, f16* out, i
                          int kv_heads, int hd, int max_seq, int past_len, hipStream_t s)
 {
     EXL_REQUIRE(hd == FA_HD, EXL_E_UNSUPPORTED, "flash prefill: head_dim must be 128 (got %d)", hd);
-    EXL_REQUIRE(bsz <= 65535 && heads <= 65535, EXL_E_UNSUPPORTED, "flash prefill: grid too large");
     const float c1 = (1.0f / sqrtf((float) hd)) * 1.4426950408889634f;
-    dim3 grid((q_len + FA_BQ - 1) / FA_BQ, heads, bsz);
+    dim3 grid(((q_len + FA_BQ - 1) / FA_BQ) * heads * bsz);
     hipLaunchKernelGGL(flash_prefill_kernel, grid, dim3(256), 0, s, q, kc, vc, out, q_len, heads, kv_heads, max_seq,
                        past_len, c1);
     EXL_LAUNCH_CHECK();

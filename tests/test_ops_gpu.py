@@ -170,7 +170,9 @@ def test_q4_gemv_is_deterministic(ce):
 
 GEMM_SHAPES = [(256, 128, 64, True, 16), (512, 96, 128, False, 33), (704, 256, 64, True, 130), (256, 64, 32, True, 8),
                (4096, 4096, 128, False, 128), (4096, 11008, 128, False, 96), (11008, 4096, 128, True, 200),
-               (6656, 6656, 32, True, 64)]
+               (6656, 6656, 32, True, 64),
+               # > 512 rows: the 256-row pipelined tile, ragged last m-tile
+               (4096, 4096, 128, False, 600), (1408, 512, 64, True, 530), (512, 11008, 32, False, 777)]
 
 
 @pytest.mark.parametrize("K,N,gs,act,rows", GEMM_SHAPES)
@@ -190,6 +192,16 @@ def test_q4_gemm_vs_oracle(ce, K, N, gs, act, rows):
     out2 = res.to(DEV).clone()
     ce.exllama_ext.q4_matmul_gemm(x.to(DEV), h, out2, no_zero=True)
     _close(out2.cpu().numpy(), O.q4_matmul_recons(x.numpy(), out=res.numpy(), **ow), ulps=1.5)
+
+
+def test_q4_matmul_zero_rows_is_a_no_op(ce):
+    lin, gen = _lin(512, 256, 128, False, seed=5)
+    h, d = _handle(ce, lin)
+    x = torch.empty((0, 512), dtype=torch.float16, device=DEV)
+    for fn in (ce.exllama_ext.q4_matmul, ce.exllama_ext.q4_matmul_gemv, ce.exllama_ext.q4_matmul_gemm):
+        out = torch.empty((0, 256), dtype=torch.float16, device=DEV)
+        fn(x, h, out)
+    torch.cuda.synchronize()
 
 
 def test_q4_matmul_threshold_dispatch(ce):
