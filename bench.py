@@ -44,6 +44,9 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true", help="decode eagerly instead of replaying the captured hipGraph")
     p.add_argument("--no-roofline-probe", action="store_true")
+    p.add_argument("--layer-split", action="store_true",
+                   help="ONE model split by layers across the ranks (hidden states handed off by RCCL send/recv, exllama_amd/pipeline.py) "
+                        "instead of one replica per rank; capacity mode: the stages run one after the other at batch 1")
     return p.parse_args()
 
 
@@ -67,6 +70,86 @@ def prefill_flops(dims, S):
     linear = 2 * S * L * (2 * h * h + 2 * h * kvd + 3 * h * I)
     attn = 4 * S * S * h * L
     return linear + attn + 2 * h * V
+
+
+def layer_split_main(args, dims, L, S, G, rank, world, dev, dist):
+    """--layer-split: rank r builds ONLY its contiguous run of layers (synthetic weights, own seed), the prompt and every
+    decoded token travel through the ranks once per forward pass.  Same protocol and timing rules as the replica mode;
+    the job's rate is the single pipeline's rate."""
+    from exllama_amd import synth
+    from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
+    from exllama_amd.pipeline import LayerSplitRunner, split_layers
+
+    class _Solo:                                                  # world == 1: same code path without a process group
+        def get_rank(self): return 0
+        def get_world_size(self): return 1
+        def broadcast(self, t, src): return None
+    d = dist if dist is not None else _Solo()
+    first, last = split_layers(L, world)[rank]
+    n_local = last - first
+    tensors = synth.make_checkpoint(dims, groupsize=args.groupsize, act_order=args.act_order, seed=100 + rank, device=dev,
+                                    zeros="sym", num_layers=n_local)
+    cfg = ExLlamaConfig(synth.config_dict(dims, n_local))
+    cfg.max_seq_len = S + G
+    cfg.max_input_len = S
+    cfg.device_map.layers = [dev] * n_local
+    cfg.device_map.embed_tokens = cfg.device_map.norm = cfg.device_map.lm_head = dev
+    model = ExLlama(cfg, tensors=tensors)
+    del tensors
+    cache = ExLlamaCache(model)
+    runner = LayerSplitRunner(model, cache, d, dims.hidden_size, dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)                                         # every rank needs the same prompt SHAPE; values matter on rank 0
+    ids = torch.randint(0, min(31999, dims.vocab_size - 1), (1, S), device=dev, generator=gen)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+
+    def step(record):
+        e = [ev() for _ in range(3)]
+        cache.current_seq_len = 0
+        e[0].record()
+        logits = runner.forward(ids)
+        e[1].record()
+        for _ in range(G):
+            tok = runner.next_token(logits)
+            logits = runner.forward(tok)
+        e[2].record()
+        if record is not None:
+            record.append(e)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(None)
+    barrier()
+    events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(events)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    mean = lambda v: sum(v) / len(v)
+    pre = mean([e[0].elapsed_time(e[1]) for e in events])
+    dec = mean([e[1].elapsed_time(e[2]) for e in events])
+    elapsed, pre, dec = reduce_over_ranks([elapsed, pre, dec], dist, dev)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "single-token decode tokens/s at full context (prefill tokens/s alongside), Llama GPTQ 4-bit",
+            "value": round(G / (dec / 1e3), 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "int4 weights (GPTQ) x fp16 activations, fp32 accumulate",
+            "data": "synthetic (seeded random GPTQ weights of the named architecture, random token ids)",
+            "config": {"workload": f"Llama-{args.model.upper()} 4-bit GPTQ g{args.groupsize}, {S}-token prefill + {G}-token greedy decode, "
+                                   f"ONE model split by layers over {world} rank(s)", "layers": L, "prompt_tokens": S, "gen_tokens": G,
+                       "parallelism": f"layer split x{world} (sequential stages, P2P hidden-state hand-off, op-by-op decode path)"},
+            "prefill_tokens_per_s": round(S / (pre / 1e3), 1), "decode_worst_tokens_per_s": round(G / (dec / 1e3), 2),
+            "prefill_ms": round(pre, 3), "decode_worst_ms_per_token": round(dec / G, 4)}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def reduce_over_ranks(local_values, dist, device):
@@ -106,6 +189,8 @@ def main():
     dims = synth.PRESETS[args.model]
     L = dims.num_hidden_layers if args.layers is None else args.layers
     S, G = args.prompt, args.gen
+    if args.layer_split:
+        return layer_split_main(args, dims, L, S, G, rank, world, dev, dist)
     tensors = synth.make_checkpoint(dims, groupsize=args.groupsize, act_order=args.act_order, seed=0, device=dev,
                                     zeros="sym", num_layers=L)
     cfg = ExLlamaConfig(synth.config_dict(dims, L))

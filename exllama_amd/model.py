@@ -571,17 +571,37 @@ class ExLlama:
         for d in devs[1:]:
             buffers[d] = buffer.to(d)
 
-        ids = _move_tensor(input_ids, cfg.device_map.embed_tokens, "input_ids", cfg)
-        hidden = torch.nn.functional.embedding(ids, self.embed_weight).contiguous()
+        hidden = self.embed(input_ids)
+        hidden = self.forward_layers(hidden, cache, buffers, lora)
+        cache.current_seq_len += seq_len
+        if preprocess_only:
+            return None
+        return _move_tensor(self.head(hidden, last_id_only), output_device, "logits", cfg)
 
+    # The three stages of a forward pass, also used one stage per process by exllama_amd/pipeline.py (layer split
+    # across processes: rank 0 embeds, every rank runs its own layers, the last rank applies norm + lm_head).
+    def embed(self, input_ids):
+        cfg = self.config
+        ids = _move_tensor(input_ids, cfg.device_map.embed_tokens, "input_ids", cfg)
+        return torch.nn.functional.embedding(ids, self.embed_weight).contiguous()
+
+    def forward_layers(self, hidden, cache, buffers=None, lora=None):
+        """Runs every layer this model holds on `hidden` [bsz, q_len, hidden]; does NOT advance cache.current_seq_len."""
+        cfg = self.config
+        if buffers is None:
+            devs = cfg.device_map.get_layers_devs()
+            first = ExLlamaBuffer(cfg)
+            buffers = {devs[0]: first}
+            for d in devs[1:]:
+                buffers[d] = first.to(d)
         for i, layer in enumerate(self.layers):
             device = cfg.device_map.layers[i]
             hidden = _move_tensor(hidden, device, "hidden_states", cfg)
             hidden = layer.forward(hidden, cache, buffers[device], lora)
-        cache.current_seq_len += seq_len
-        if preprocess_only:
-            return None
+        return hidden
 
+    def head(self, hidden, last_id_only=True):
+        cfg = self.config
         hidden = _move_tensor(hidden, cfg.device_map.norm, "hidden_states", cfg)
         if last_id_only:
             hidden = hidden[:, -1:, :].contiguous()
@@ -589,8 +609,7 @@ class ExLlama:
         if cfg.device_map.lm_head == "cpu":
             hidden = hidden.float()
         hidden = _move_tensor(hidden, cfg.device_map.lm_head, "hidden_states", cfg)
-        logits = torch.matmul(hidden, self.lm_head_weight.t()).float()
-        return _move_tensor(logits, output_device, "logits", cfg)
+        return torch.matmul(hidden, self.lm_head_weight.t()).float()
 
     # ---- native decode executor + hipGraph ---------------------------------------------------------------
     def enable_decode_graph(self, cache, use_graph=True):

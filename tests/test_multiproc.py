@@ -54,3 +54,81 @@ def test_single_process_reduction_is_identity():
 
 
 PORT = _free_port()
+
+
+# ---- layer split across processes (exllama_amd/pipeline.py): plumbing test with a torch-only stage on CPU ------------
+class _ToyStage:
+    """embed / forward_layers / head with plain torch ops, deterministic weights (seeded per GLOBAL layer index)."""
+
+    def __init__(self, first, last, hidden=32, vocab=50):
+        g = torch.Generator().manual_seed(123)
+        self.emb = torch.randn(vocab, hidden, generator=g).half()
+        self.out = torch.randn(vocab, hidden, generator=g).half()
+        self.ws = []
+        for i in range(8):
+            w = (torch.randn(hidden, hidden, generator=g) * 0.1).half()
+            if first <= i < last:
+                self.ws.append(w)
+
+    def embed(self, ids):
+        return self.emb[ids]
+
+    def forward_layers(self, hidden, cache):
+        for w in self.ws:
+            hidden = (hidden.float() + torch.tanh(hidden.float() @ w.float())).half()
+        return hidden
+
+    def head(self, hidden, last_id_only=True):
+        if last_id_only:
+            hidden = hidden[:, -1:, :]
+        return hidden.float() @ self.out.float().t()
+
+
+def _pipe_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from exllama_amd.pipeline import LayerSplitRunner, split_layers
+    first, last = split_layers(8, world)[rank]
+    runner = LayerSplitRunner(_ToyStage(first, last), None, dist, 32, "cpu")
+    ids = torch.tensor([[3, 7, 11, 13]])
+    logits = runner.forward(ids)
+    toks = []
+    for _ in range(3):
+        tok = runner.next_token(logits)
+        toks.append(int(tok))
+        logits = runner.forward(tok)
+    if rank == world - 1:
+        out.put((toks, logits))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_layer_split_matches_single_process():
+    from exllama_amd.pipeline import split_layers, stage_tensors
+    assert split_layers(32, 8) == [(4 * i, 4 * i + 4) for i in range(8)]
+    assert split_layers(7, 3) == [(0, 3), (3, 5), (5, 7)]
+    t = {"model.embed_tokens.weight": 1, "model.layers.0.a": 2, "model.layers.5.b.qweight": 3, "model.layers.6.c": 4, "lm_head.weight": 5}
+    assert stage_tensors(t, 5, 7) == {"model.embed_tokens.weight": 1, "model.layers.0.b.qweight": 3, "model.layers.1.c": 4, "lm_head.weight": 5}
+    # reference run: all 8 layers in one process
+    full = _ToyStage(0, 8)
+    ids = torch.tensor([[3, 7, 11, 13]])
+    logits = full.head(full.forward_layers(full.embed(ids), None))
+    toks = []
+    for _ in range(3):
+        tok = logits[0, -1].argmax().view(1, 1)
+        toks.append(int(tok))
+        logits = full.head(full.forward_layers(full.embed(tok), None))
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got_toks, got_logits = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got_toks == toks
+    assert torch.equal(got_logits, logits)
