@@ -284,6 +284,25 @@ extern "C" int exl_q4_matmul_gemm(void* w, const void* x, int x_height, void* ou
     return q4_gemm(m, x, x_height, out, no_zero, bufs->temp_state, bufs->temp_state_numel, (hipStream_t) stream);
 }
 
+extern "C" int exl_q4_matmul_dual(void* w1, void* w2, const void* x, int x_height, void* out1, void* out2, int silu,
+                                  void* stream, int* launched)
+{
+    EXL_REQUIRE(launched, EXL_E_INVALID, "q4_matmul_dual: launched is null");
+    *launched = 0;
+    Q4Matrix* m1 = q4_from_handle(w1);
+    Q4Matrix* m2 = q4_from_handle(w2);
+    EXL_REQUIRE(m1 && m2, EXL_E_INVALID, "q4_matmul_dual: invalid q4 handle");
+    EXL_REQUIRE(x_height >= 0, EXL_E_INVALID, "q4_matmul_dual: negative row count");
+    if (x_height == 0) { *launched = 1; return 0; }
+    EXL_REQUIRE(x && out1 && (silu || out2), EXL_E_INVALID, "q4_matmul_dual: null tensor pointer");
+    DeviceGuard guard(m1->device);
+    EXL_REQUIRE(guard.ok, EXL_E_INVALID, "q4_matmul_dual: cannot select device %d", m1->device);
+    const int r = launch_q4_gemm_dual(m1, m2, (const f16*) x, x_height, (f16*) out1, (f16*) out2, silu, (hipStream_t) stream);
+    if (r == 1) return 0;                                    // not eligible: the caller runs the two products itself
+    if (r == 0) *launched = 1;
+    return r;
+}
+
 extern "C" int exl_q4_matmul_lora(void* w, const void* x, int x_height, void* out, const void* lora_a,
                                   const void* lora_b, int rank, void* lora_temp, void* stream)
 {

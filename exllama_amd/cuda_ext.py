@@ -169,6 +169,18 @@ class _ExllamaExt:
         with _Guard(x.device):
             check(self._lib.exl_q4_matmul_gemm(w, x.data_ptr(), x.size(0), out.data_ptr(), int(no_zero), _stream(x)), "q4_matmul_gemm")
 
+    def q4_matmul_dual(self, x, w1, w2, out1, out2=None, silu=True):
+        """out1 = silu(x @ W1) * (x @ W2) (silu) or out1, out2 = x @ W1, x @ W2 in one kernel (include/exl_amd.h:
+        exl_q4_matmul_dual).  Returns False when the pair / row count is not eligible: nothing was launched."""
+        self._check_mm(x, w1, out1)
+        if out2 is not None:
+            self._check_mm(x, w2, out2)
+        done = C.c_int()
+        with _Guard(x.device):
+            check(self._lib.exl_q4_matmul_dual(w1, w2, x.data_ptr(), x.size(0), out1.data_ptr(), _ptr(out2), int(silu), _stream(x),
+                                               C.byref(done)), "q4_matmul_dual")
+        return bool(done.value)
+
     def q4_reconstruct(self, w, out):
         _req_dtype(out, torch.float16, "out")
         _req_cuda(out, "out")

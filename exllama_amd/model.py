@@ -210,19 +210,24 @@ class ExLlamaMLP:
         ext.q4_mlp(x.view(-1, x.shape[-1]), post_attention_layernorm.weight, self.config.rms_norm_eps,
                    self.gate_proj.q4, self.up_proj.q4, self.down_proj.q4, ga, gb, ua, ub, da, db, lora_temp)
 
-    def forward_residual(self, normed, hidden, lora):
-        """hidden += down(silu(gate(normed)) * up(normed)); residual fused in the down_proj epilogue."""
-        g = self.gate_proj.forward(normed, lora)
-        u = self.up_proj.forward(normed, lora)
-        ext.silu_mul(g, u)
-        self.down_proj.forward(g, lora, out=hidden, accumulate=True)
-
-    def forward(self, x, buffer=None, lora=None):
-        """Non-residual form of the reference (model.py:266-273)."""
+    def _activation(self, x, lora):
+        """silu(gate(x)) * up(x): one fused kernel for long prompts (exl_q4_matmul_dual), else the reference's three calls."""
+        if not (self.gate_proj.lora_applies(lora) or self.up_proj.lora_applies(lora)):
+            g = torch.empty(x.shape[:-1] + (self.gate_proj.out_features,), dtype=torch.float16, device=x.device)
+            if ext.q4_matmul_dual(x.view(-1, x.shape[-1]), self.gate_proj.q4, self.up_proj.q4, g.view(-1, g.shape[-1]), None, True):
+                return g
         g = self.gate_proj.forward(x, lora)
         u = self.up_proj.forward(x, lora)
         ext.silu_mul(g, u)
-        return self.down_proj.forward(g, lora)
+        return g
+
+    def forward_residual(self, normed, hidden, lora):
+        """hidden += down(silu(gate(normed)) * up(normed)); residual fused in the down_proj epilogue."""
+        self.down_proj.forward(self._activation(normed, lora), lora, out=hidden, accumulate=True)
+
+    def forward(self, x, buffer=None, lora=None):
+        """Non-residual form of the reference (model.py:266-273)."""
+        return self.down_proj.forward(self._activation(x, lora), lora)
 
 
 class ExLlamaAttention:

@@ -98,6 +98,13 @@ int exl_q4_matmul(void* w, const void* x, int x_height, void* out, int no_zero, 
 /* The two kernels individually (reference: q4_matmul.cu:239-299 q4_matmul_cuda, :301-344 q4_matmul_recons_cuda). */
 int exl_q4_matmul_gemv(void* w, const void* x, int x_height, void* out, int no_zero, void* stream);
 int exl_q4_matmul_gemm(void* w, const void* x, int x_height, void* out, int no_zero, void* stream);
+/* Prompt-pass fusion with no counterpart in the reference (it runs gate_proj, up_proj and the SiLU kernel one after the
+ * other, model.py:266-273): out1 = silu(x @ W1) * (x @ W2) when silu != 0, else out1 = x @ W1 and out2 = x @ W2, in ONE
+ * kernel that shares the activation tile between the two products.  Only for two T16 matrices of identical shape and
+ * group size without act-order and more than 512 rows: otherwise nothing is launched and *launched = 0 -- the caller then
+ * issues the separate calls (exl_q4_matmul twice + exl_silu_mul). */
+int exl_q4_matmul_dual(void* w1, void* w2, const void* x, int x_height, void* out1, void* out2, int silu, void* stream,
+                       int* launched);
 /* out = x @ W + (x @ lora_A) @ lora_B   (reference: exllama_ext.cpp:245-324 q4_matmul_lora) */
 int exl_q4_matmul_lora(void* w, const void* x, int x_height, void* out, const void* lora_a, const void* lora_b,
                        int rank, void* lora_temp, void* stream);

@@ -245,6 +245,48 @@ def test_full_size_prefill_property_gemm_equals_reconstruct_times_blas(ce):
     assert nbad == 0, f"{nbad} of {out.numel()} elements break exact linearity"
 
 
+@pytest.mark.parametrize("K,N,gs,rows", [(512, 256, 128, 513), (4096, 11008, 128, 2048), (1024, 1408, 32, 700), (256, 128, 64, 1000)])
+def test_q4_matmul_dual_equals_separate_products(ce, K, N, gs, rows):
+    """exl_q4_matmul_dual (long-prompt gate/up fusion) against the three separate ops the reference issues
+    (model.py:266-273) and against the oracle: same tile order and the same fp16 roundings, so bit-identical."""
+    lin1, gen = _lin(K, N, gs, False, seed=K + N + rows, std=0.02 * (4096 / K) ** 0.5)
+    lin2, _ = _lin(K, N, gs, False, seed=K + N + rows + 1, std=0.02 * (4096 / K) ** 0.5)
+    h1, d1 = _handle(ce, lin1)
+    h2, d2 = _handle(ce, lin2)
+    x = torch.randn(rows, K, generator=gen).half().to(DEV)
+    g = torch.empty((rows, N), dtype=torch.float16, device=DEV)
+    u = torch.empty_like(g)
+    ce.exllama_ext.q4_matmul_gemm(x, h1, g)
+    ce.exllama_ext.q4_matmul_gemm(x, h2, u)
+    dg = torch.full_like(g, float("nan"))
+    du = torch.full_like(g, float("nan"))
+    assert ce.exllama_ext.q4_matmul_dual(x, h1, h2, dg, du, silu=False)
+    assert torch.equal(dg, g) and torch.equal(du, u)
+    act = torch.full_like(g, float("nan"))
+    assert ce.exllama_ext.q4_matmul_dual(x, h1, h2, act, None, silu=True)
+    ce.exllama_ext.silu_mul(g, u)
+    assert torch.equal(act, g)
+    if K * N <= 1 << 21:
+        ref = O.silu_mul(O.q4_matmul_recons(x.cpu().numpy(), **_oracle_w(lin1)), O.q4_matmul_recons(x.cpu().numpy(), **_oracle_w(lin2)))
+        _close(act.cpu().numpy(), ref, ulps=4.0)
+
+
+def test_q4_matmul_dual_declines_what_it_does_not_cover(ce):
+    """Short prompts, act-order and mismatched shapes are left to the separate kernels: nothing launched, False returned."""
+    lin1, gen = _lin(512, 256, 128, False, seed=1)
+    lin2, _ = _lin(512, 256, 128, True, seed=2)
+    lin3, _ = _lin(512, 128, 128, False, seed=3)
+    h1, _d1 = _handle(ce, lin1)
+    h2, _d2 = _handle(ce, lin2)
+    h3, _d3 = _handle(ce, lin3)
+    x = torch.randn(600, 512, generator=gen).half().to(DEV)
+    out = torch.zeros((600, 256), dtype=torch.float16, device=DEV)
+    assert not ce.exllama_ext.q4_matmul_dual(x[:100].contiguous(), h1, h1, out[:100], None, silu=True)
+    assert not ce.exllama_ext.q4_matmul_dual(x, h1, h2, out, None, silu=True)
+    assert not ce.exllama_ext.q4_matmul_dual(x, h1, h3, out, None, silu=True)
+    assert float(out.abs().max()) == 0.0
+
+
 def test_q4_matmul_lora(ce):
     lin, gen = _lin(512, 256, 128, False, seed=21)
     h, d = _handle(ce, lin)
