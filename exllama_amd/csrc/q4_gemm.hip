@@ -416,6 +416,17 @@ __global__ __launch_bounds__(WM * 128) void q4_gemm_t16_kernel(const f16* __rest
 // ---------------------------------------------------------------------------------------------------------------
 #define GP_BATCH 7
 
+// Stall attribution for scripts/probe_gemm.hip (compiled only there): cycles a wave spends in the VMEM wait, the dequant +
+// LDS store, and the barrier of each K step; [block][wave][4] = {total, wait, store, barrier}.
+#ifdef EXL_GEMM_PROBE
+__device__ unsigned long long g_gemm_probe[1024 * 8 * 4];
+#define GP_CLK(v) const unsigned long long v = __builtin_readcyclecounter()
+#define GP_ACC(dst, a, b) dst += (b) - (a)
+#else
+#define GP_CLK(v) do { } while (0)
+#define GP_ACC(dst, a, b) do { } while (0)
+#endif
+
 // WAVES_M x WAVES_N waves, each TM x TN tiles of 16 x 16: block = (WAVES_M * TM * 16) rows x 128 columns (WAVES_N * TN == 8).
 // Fewer, fatter waves read fewer LDS fragments per MFMA ((TM + TN) / (TM * TN)): the kernel is LDS-bandwidth bound.
 template <int WAVES_M, int WAVES_N, int TM, int TN>
@@ -560,6 +571,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void q4_gemm_t16p_kernel(co
     };
 
     // ---- prologue: batches 0 and 1 in flight, B(0) dequantised --------------------------------------------------------
+#ifdef EXL_GEMM_PROBE
+    unsigned long long p_wait = 0, p_store = 0, p_bar = 0;
+    const unsigned long long p_t0 = __builtin_readcyclecounter();
+#endif
     BRegs rX, rY;
     stage_a(0, 0);
     issue_b(0, rX);
@@ -578,17 +593,27 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void q4_gemm_t16p_kernel(co
         stage_a(ring(a_slot, 2), (it + 2) * GT_BK);
         issue_b(it + 2, rX);
         compute(a_slot, 0);
+        GP_CLK(c0);
         GP_WAITB(rY);                                                     // batch it+1 landed
+        GP_CLK(c1);
         store_b(1, rY);
+        GP_CLK(c2);
         block_barrier();
+        GP_CLK(c3);
+        GP_ACC(p_wait, c0, c1); GP_ACC(p_store, c1, c2); GP_ACC(p_bar, c2, c3);
         a_slot = ring(a_slot, 1);
         // step it+1: tile it+1 computes, B(it+2) waits in rX, batch it+3 is fetched into rY
         stage_a(ring(a_slot, 2), (it + 3) * GT_BK);
         issue_b(it + 3, rY);
         compute(a_slot, 1);
+        GP_CLK(d0);
         GP_WAITB(rX);                                                     // batch it+2 landed
+        GP_CLK(d1);
         store_b(0, rX);
+        GP_CLK(d2);
         block_barrier();
+        GP_CLK(d3);
+        GP_ACC(p_wait, d0, d1); GP_ACC(p_store, d1, d2); GP_ACC(p_bar, d2, d3);
         a_slot = ring(a_slot, 1);
     }
     // ---- last two K steps: nothing left to fetch ----------------------------------------------------------------------
@@ -600,6 +625,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void q4_gemm_t16p_kernel(co
     compute(a_slot, 1);
 #undef GP_WAITB
 #undef GP_WAIT
+#ifdef EXL_GEMM_PROBE
+    if (lane == 0 && b < 1024) {
+        unsigned long long* pp = g_gemm_probe + ((size_t) b * 8 + wave) * 4;
+        pp[0] = __builtin_readcyclecounter() - p_t0; pp[1] = p_wait; pp[2] = p_store; pp[3] = p_bar;
+    }
+#endif
 
 #pragma unroll
     for (int im = 0; im < TM; ++im) {
@@ -621,6 +652,531 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void q4_gemm_t16p_kernel(co
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Mid-step barrier schedule of the same tile (the default).  Stall attribution of the kernel above
+// (scripts/probe_gemm.hip): of ~2100 cycles per K step only ~1000 are MFMA issue; after every barrier both waves of a
+// SIMD wait for their first fragments, and the dequant + LDS store (300 cycles) and the barrier (150-500) run with an
+// idle matrix pipe.  Here a K step is cut into two halves of 16 MFMAs and the barrier sits between the SECOND half of
+// tile t-1 and the FIRST half of tile t:
+//
+//     barrier(t-1) | read Q <- frags(t, k 0..31) | 16 MFMAs on P = frags(t-1, k 32..63), DMA A(t+2) + loads B(t+2) between them
+//                  | read P <- frags(t, k 32..63)| 16 MFMAs on Q, wait batch t+1 + dequant/store B(t+1) between them | barrier(t)
+//
+// so every MFMA group runs on fragments requested 16 MFMAs earlier and all VMEM / VALU / LDS-store work is issued in the
+// shadow of MFMAs.  __builtin_amdgcn_sched_barrier(0) pins the groups in source order.  The first half-step runs on
+// zero fragments (P starts as 0), the last two steps re-fetch the last tile instead of branching (straight-line loop:
+// every hand-counted wait stays unconditional).
+// ---------------------------------------------------------------------------------------------------------------
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void q4_gemm_t16m_kernel(const f16* __restrict__ x, const uint4* __restrict__ qw,
+                                                               const uint32_t* __restrict__ qzeros,
+                                                               const f16* __restrict__ scales, f16* __restrict__ out, int M,
+                                                               int K, int N, int gshift, int groupsize, int no_zero, int mtiles,
+                                                               int ntiles)
+{
+    static_assert(WAVES_N * TN == 8, "block is 128 columns wide");
+    static_assert(TM == 4 && TN == 4, "the MFMA groups below are written for 4 x 4 tiles per wave");
+    constexpr int TBM = WAVES_M * TM * 16;
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int NTH = NW * 64;
+    constexpr int APW = (TBM / 8) / NW;                               // 1 KiB activation pieces per wave per K step
+    static_assert(APW == 4, "4 activation pieces per wave per K step");
+    constexpr int A_BYTES = TBM * 128;
+    constexpr int PW = 4 * 256 / NTH;                                 // words of a piece per thread (4 or 2)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [3][A] then [2][B]
+    unsigned char* const ldsB = lds + 3 * A_BYTES;
+
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int idx = b >> 3;
+    const int nl = idx / mtiles;
+    const int mt = idx - nl * mtiles;
+    const int nt = nl * 8 + xcd;
+    if (nt >= ntiles) return;
+    const int m0 = mt * TBM;
+    const int n0 = nt * GT_BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int RB = K >> 7;
+    const int nk = K / GT_BK;                                         // even (K % 128 == 0)
+
+    uint32_t a_off[APW];                                               // element offsets from x (M * K < 2^32 checked on the host)
+#pragma unroll
+    for (int i = 0; i < APW; ++i) {
+        const int c = wave * APW + i;
+        const int row = c * 8 + (lane >> 3);
+        const int slot = lane & 7;
+        const int grow = min(m0 + row, M - 1);
+        a_off[i] = (uint32_t) grow * (uint32_t) K + ((slot ^ (row & 7)) << 3);
+    }
+    auto stage_a = [&](int i, int slot3, int k0) {                      // one 1 KiB piece
+        __attribute__((address_space(3))) unsigned char* dst =
+            (__attribute__((address_space(3))) unsigned char*) (lds + (size_t) slot3 * A_BYTES + (wave * APW + i) * 1024);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (x + (size_t) (a_off[i] + (uint32_t) k0)), dst, 16, 0, 0);
+    };
+
+    const int pid = PW == 4 ? tid : tid >> 1;                          // 256 or 512 threads
+    const int ph = PW == 4 ? 0 : tid & 1;
+    const int b_tile = pid >> 5;
+    const int b_rs = (pid >> 4) & 1;
+    const int b_col = pid & 15;
+    const int b_nloc = b_tile * 16 + b_col;
+    const int b_n = min(n0 + b_nloc, N - 1);
+    const uint32_t* b_src = (const uint32_t*) (qw + ((size_t) (b_n >> 4) * RB) * 64 + (b_n & 15)) + ph * PW;
+    const int b_zsh = (b_n & 7) * 4;
+    const uint32_t magic = t16_magic();
+    const uint32_t ginv = (uint32_t) (((1ull << 32) + (uint32_t) groupsize - 1) / (uint32_t) groupsize);
+    const uint32_t b_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned char*) ldsB;
+    uint32_t b_dst[PW];                                                // LDS byte offsets of this thread's chunks inside a B tile
+#pragma unroll
+    for (int j = 0; j < PW; ++j) b_dst[j] = b_lds + (uint32_t) gt_off(b_nloc, b_rs * 4 + ph * PW + j);
+
+    struct BRegs { u32x4 w4; u32x2 w2; uint32_t zw, sc; };
+    auto issue_w = [&](int it, BRegs& r) {
+        const int rb = it >> 1, rsub = (it & 1) * 2 + b_rs;
+        const uint32_t* p = b_src + ((size_t) rb * 64 + rsub * 16) * 4;
+        if constexpr (PW == 4) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.w4) : "v"(p) : "memory");
+        else                   asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r.w2) : "v"(p) : "memory");
+    };
+    auto issue_zs = [&](int it, BRegs& r) {
+        const uint32_t k = (uint32_t) (it * GT_BK + b_rs * 32);
+        const uint32_t grp = __umulhi(k, ginv);                             // = k / groupsize (k < 2^16), no branch in the loop
+        const uint32_t* zp = qzeros + (size_t) grp * (N >> 3) + (b_n >> 3);
+        const f16* sp = scales + (size_t) grp * N + b_n;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(r.zw) : "v"(zp) : "memory");
+        asm volatile("global_load_ushort %0, %1, off" : "=v"(r.sc) : "v"(sp) : "memory");
+    };
+#define GM_WAIT(NSTR, r)                                                                                              \
+    do {                                                                                                              \
+        if constexpr (PW == 4) asm volatile("s_waitcnt vmcnt(" NSTR ")" : "+v"(r.w4), "+v"(r.zw), "+v"(r.sc) :: "memory"); \
+        else                   asm volatile("s_waitcnt vmcnt(" NSTR ")" : "+v"(r.w2), "+v"(r.zw), "+v"(r.sc) :: "memory"); \
+    } while (0)
+    // dequantise word j of the landed register set and store its 8 halves (one 16-byte chunk of the [n][k] tile)
+    auto store_word = [&](int slot2, const BRegs& r, int j) {
+        const int z = (int) ((r.zw >> b_zsh) & 0xFu) + 1;
+        const f16 za = (f16) (float) (-(1024 + z));
+        const f16 zb = (f16) (float) (-(64 + z));
+        const f16 bsc = __builtin_bit_cast(f16, (uint16_t) (r.sc & 0xFFFFu));
+        const f16x2 zc0 = {za, za}, zc1 = {zb, zb}, s2 = {bsc, bsc};
+        const uint32_t word = PW == 4 ? r.w4[j] : r.w2[j & 1];
+        const f16x8 d = t16_dequant_exact(word, magic, zc0, zc1);
+        const uint4 u = __builtin_bit_cast(uint4, d);
+        const u32x4 ov = {__builtin_bit_cast(uint32_t, as_h2(u.x) * s2), __builtin_bit_cast(uint32_t, as_h2(u.y) * s2),
+                          __builtin_bit_cast(uint32_t, as_h2(u.z) * s2), __builtin_bit_cast(uint32_t, as_h2(u.w) * s2)};
+        asm volatile("ds_write_b128 %0, %1" :: "v"(b_dst[j] + (uint32_t) (slot2 * GT_BTILE_BYTES)), "v"(ov) : "memory");
+    };
+    auto block_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wave's ds_writes are in LDS
+        __builtin_amdgcn_s_barrier();
+    };
+
+    f32x4 acc[TN][TM];                                                   // [n-tile][m-tile]
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fk = lane >> 4;
+    int fx_off[TM], fw_off[TN];                                           // fragment byte offsets for k-chunk (kk * 4 + fk) = fk; kk = 1 flips bit 6 of the swizzled chunk
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fx_off[i] = gt_off((wm * TM + i) * 16 + fr, fk);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) fw_off[i] = gt_off((wn * TN + i) * 16 + fr, fk);
+    struct Frags { f16x8 x[TM], w[TN]; };
+    auto read_frags = [&](int slot3, int slot2, int kk, Frags& f) {
+        const unsigned char* at = lds + (size_t) slot3 * A_BYTES;
+        const unsigned char* bt = ldsB + (size_t) slot2 * GT_BTILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) f.x[i] = *(const f16x8*) (at + (fx_off[i] ^ (kk << 6)));
+#pragma unroll
+        for (int i = 0; i < TN; ++i) f.w[i] = *(const f16x8*) (bt + (fw_off[i] ^ (kk << 6)));
+    };
+#define GM_MFMA(f, i) acc[(i) / TM][(i) % TM] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[(i) / TM], f.x[(i) % TM], acc[(i) / TM][(i) % TM], 0, 0, 0)
+#define GM_MFMA2(f, i) do { GM_MFMA(f, i); GM_MFMA(f, (i) + 1); } while (0)
+#define GM_MFMA4(f, i) do { GM_MFMA2(f, i); GM_MFMA2(f, (i) + 2); } while (0)
+#define GM_SB() __builtin_amdgcn_sched_barrier(0)
+
+    Frags P, Q;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) P.x[i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < TN; ++i) P.w[i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+
+    // ---- prologue: batches 0 and 1 in flight, B(0) dequantised --------------------------------------------------------
+    BRegs rX, rY;
+#pragma unroll
+    for (int i = 0; i < APW; ++i) stage_a(i, 0, 0);
+    issue_w(0, rX); issue_zs(0, rX);
+#pragma unroll
+    for (int i = 0; i < APW; ++i) stage_a(i, 1, GT_BK);                  // nk >= 2 always
+    issue_w(1, rY); issue_zs(1, rY);
+    GM_WAIT("7", rX);                                                     // batch 0 landed (batch 1 may still fly)
+#pragma unroll
+    for (int j = 0; j < PW; ++j) store_word(0, rX, j);
+    block_barrier();
+
+#ifdef EXL_GEMM_PROBE
+    unsigned long long p_wait = 0, p_store = 0, p_bar = 0;                // here: first half / second half / barrier
+    const unsigned long long p_t0 = __builtin_readcyclecounter();
+#endif
+    int a_slot = 0;                                                       // LDS ring slot of tile t
+    auto ring = [](int s, int d) { const int v = s + d; return v >= 3 ? v - 3 : v; };
+    // one K step; rI receives the packed weights of tile t+2, rW holds tile t+1 (landing), bcur = LDS slot of B(t)
+    auto step = [&](int t, BRegs& rI, BRegs& rW, int bcur) {
+        const int tf = min(t + 2, nk - 1);                                // the last two steps re-fetch the last tile (never read)
+        const int adma = ring(a_slot, 2);
+        GP_CLK(c0);
+        GM_MFMA2(P, 0);   stage_a(0, adma, tf * GT_BK);  GM_SB();
+        read_frags(a_slot, bcur, 0, Q);                  GM_SB();          // behind the first MFMAs: hipcc waits with lgkmcnt(0)
+        GM_MFMA2(P, 2);   stage_a(1, adma, tf * GT_BK);  GM_SB();
+        GM_MFMA2(P, 4);   stage_a(2, adma, tf * GT_BK);  GM_SB();
+        GM_MFMA2(P, 6);   stage_a(3, adma, tf * GT_BK);  GM_SB();
+        GM_MFMA2(P, 8);   issue_w(tf, rI);               GM_SB();
+        GM_MFMA4(P, 10);  issue_zs(tf, rI);              GM_SB();
+        GM_MFMA2(P, 14);                                 GM_SB();
+        GP_CLK(c1);
+        GM_MFMA4(Q, 0);   GM_WAIT("7", rW);              GM_SB();
+        read_frags(a_slot, bcur, 1, P);                  GM_SB();
+        if constexpr (PW == 2) {
+            GM_MFMA4(Q, 4);   store_word(bcur ^ 1, rW, 0);   GM_SB();
+            GM_MFMA4(Q, 8);   store_word(bcur ^ 1, rW, 1);   GM_SB();
+            GM_MFMA4(Q, 12);                                 GM_SB();
+        } else {
+            GM_MFMA2(Q, 4);   store_word(bcur ^ 1, rW, 0);   GM_SB();
+            GM_MFMA2(Q, 6);   store_word(bcur ^ 1, rW, 1);   GM_SB();
+            GM_MFMA2(Q, 8);   store_word(bcur ^ 1, rW, 2);   GM_SB();
+            GM_MFMA2(Q, 10);  store_word(bcur ^ 1, rW, 3);   GM_SB();
+            GM_MFMA4(Q, 12);                                 GM_SB();
+        }
+        GP_CLK(c2);
+        block_barrier();
+        GP_CLK(c3);
+        GP_ACC(p_wait, c0, c1); GP_ACC(p_store, c1, c2); GP_ACC(p_bar, c2, c3);
+        a_slot = ring(a_slot, 1);
+    };
+    for (int t = 0; t < nk; t += 2) {
+        step(t, rX, rY, 0);
+        step(t + 1, rY, rX, 1);
+    }
+    GM_MFMA4(P, 0); GM_MFMA4(P, 4); GM_MFMA4(P, 8); GM_MFMA4(P, 12);      // second half of the last tile
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the two redundant fetches
+#ifdef EXL_GEMM_PROBE
+    if (lane == 0 && b < 1024) {
+        unsigned long long* pp = g_gemm_probe + ((size_t) b * 8 + wave) * 4;
+        pp[0] = __builtin_readcyclecounter() - p_t0; pp[1] = p_wait; pp[2] = p_store; pp[3] = p_bar;
+    }
+#endif
+#undef GM_WAIT
+#undef GM_MFMA
+#undef GM_MFMA2
+#undef GM_MFMA4
+#undef GM_SB
+
+#pragma unroll
+    for (int im = 0; im < TM; ++im) {
+        const int row = m0 + (wm * TM + im) * 16 + fr;
+        if (row < M) {
+#pragma unroll
+            for (int in = 0; in < TN; ++in) {
+                const int n = n0 + (wn * TN + in) * 16 + fk * 4;
+                if (n < N) {
+                    f16* op = out + (size_t) row * N + n;
+                    float v[4] = {acc[in][im][0], acc[in][im][1], acc[in][im][2], acc[in][im][3]};
+                    if (no_zero) {
+                        const f16x4 prev = *(const f16x4*) op;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += (float) prev[j];
+                    }
+                    *(f16x4*) op = (f16x4){(f16) v[0], (f16) v[1], (f16) v[2], (f16) v[3]};
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-specialised version of the same 256 x 128 x 64 tile (the default for > 512 rows).  Stall attribution of the
+// kernels above (scripts/probe_gemm.hip): the half step that carries the 4 LDS-DMA instructions + 3 loads of a wave takes
+// 640 cycles for the older and 1030 for the younger wave of a SIMD instead of 256 -- the CU's vector-memory pipe takes
+// ~16 cycles per wave instruction (32 KiB of activations per K step = 512 cycles) and a wave stalled on a VMEM issue
+// cannot issue the MFMAs behind it.  So the roles are split:
+//   * waves 0-7 (consumers, 64 x 64 each): nothing but fragment reads and MFMAs, software-pipelined over the barrier
+//     (first half of tile t runs on fragments requested before the second half of tile t-1 was issued);
+//   * waves 8-11 (producers, one per SIMD): per K step 8 LDS-DMA pieces of A(t+2), one 16-byte piece quarter of
+//     B(t+2) + zero word + scale into registers, then dequantise B(t+1) (landed a step ago) into the [n][k] LDS tile.
+// One s_barrier per K step over all 12 waves; same 3-slot A ring / 2-slot B ring, same hand-counted vmcnt.
+// ---------------------------------------------------------------------------------------------------------------
+#define GW_CONS 8
+#define GW_PROD 4
+__global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(const f16* __restrict__ x, const uint4* __restrict__ qw,
+                                                               const uint32_t* __restrict__ qzeros,
+                                                               const f16* __restrict__ scales, f16* __restrict__ out, int M,
+                                                               int K, int N, int gshift, int no_zero, int mtiles, int ntiles)
+{
+    constexpr int TM = 4, TN = 4, WAVES_N = 2;
+    constexpr int TBM = 256;
+    constexpr int A_BYTES = TBM * 128;
+    constexpr int APW = (TBM / 8) / GW_PROD;                          // 8 one-KiB activation pieces per producer wave per K step
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [3][A] then [2][B]
+    unsigned char* const ldsB = lds + 3 * A_BYTES;
+
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int idx = b >> 3;
+    const int nl = idx / mtiles;
+    const int mt = idx - nl * mtiles;
+    const int nt = nl * 8 + xcd;
+    if (nt >= ntiles) return;
+    const int m0 = mt * TBM;
+    const int n0 = nt * GT_BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = K / GT_BK;                                         // even (K % 128 == 0), >= 2
+    auto ring = [](int s, int d) { const int v = s + d; return v >= 3 ? v - 3 : v; };
+
+    if (wave >= GW_CONS) {
+        // ================================================= producer =================================================
+        // Every address is (uniform base, advanced by scalar adds per K step) + (fixed 32-bit byte offset per lane): the
+        // loads use the saddr form and cost no vector instruction -- a single wave issues only ~1 instruction per 5-6
+        // cycles, so the loader's instruction count per K step is what bounds it.
+        const int pw = wave - GW_CONS;
+        const int ptid = tid - GW_CONS * 64;                            // 0..255
+        const int RB = K >> 7;
+        uint32_t a_voff[APW];                                            // byte offsets from x (M * K * 2 < 2^32 checked on the host)
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            const int c = pw * APW + i;
+            const int row = c * 8 + (lane >> 3);
+            const int slot = lane & 7;
+            const int grow = min(m0 + row, M - 1);
+            a_voff[i] = ((uint32_t) grow * (uint32_t) K + ((slot ^ (row & 7)) << 3)) * 2u;
+        }
+        const uint32_t lds_a0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned char*) lds + (uint32_t) (pw * APW * 1024);
+        // pieces 2 * pair and 2 * pair + 1 of this wave's 8: M0 carries the LDS address of an LDS-DMA
+        auto stage_a2 = [&](int pair, int slot3, int k0) {
+            const f16* xk = x + k0;                                      // uniform
+            const uint32_t l = lds_a0 + (uint32_t) slot3 * A_BYTES + (uint32_t) pair * 2048;
+            asm volatile("s_mov_b32 m0, %[l]\n\t"
+                         "global_load_lds_dwordx4 %[v0], %[sb]\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\t"
+                         "global_load_lds_dwordx4 %[v1], %[sb]"
+                         :: [l] "s"(l), [sb] "s"(xk), [v0] "v"(a_voff[2 * pair]), [v1] "v"(a_voff[2 * pair + 1]) : "memory", "scc");
+        };
+        auto stage_a = [&](int slot3, int k0) {
+#pragma unroll
+            for (int pr = 0; pr < APW / 2; ++pr) stage_a2(pr, slot3, k0);
+        };
+        const int b_tile = ptid >> 5;
+        const int b_rs = (ptid >> 4) & 1;
+        const int b_col = ptid & 15;
+        const int b_nloc = b_tile * 16 + b_col;
+        const int b_n = min(n0 + b_nloc, N - 1);
+        // packed words of K step `it`: piece (n, rb = it / 2), sub-row (it & 1) * 2 + b_rs  ->  uniform it * 512 bytes + lane part
+        const uint32_t w_voff = (uint32_t) (((size_t) (b_n >> 4) * RB * 64 + (b_n & 15)) * 16 + (size_t) b_rs * 256);
+        // group of k = it * 64 + b_rs * 32 (groupsize a power of two >= 32): uniform (it * 64) >> gshift, + b_rs for groupsize 32
+        const int zs_lane_grp = gshift == 5 ? b_rs : 0;
+        const uint32_t z_voff = (uint32_t) ((zs_lane_grp * (N >> 3) + (b_n >> 3)) * 4);
+        const uint32_t s_voff = (uint32_t) ((zs_lane_grp * N + b_n) * 2);
+        const int b_zsh = (b_n & 7) * 4;
+        const uint32_t magic = t16_magic();
+        const uint32_t b_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned char*) ldsB;
+        uint32_t b_dst[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b_dst[j] = b_lds + (uint32_t) gt_off(b_nloc, b_rs * 4 + j);
+
+        struct BRegs { u32x4 w4; uint32_t zw, sc; };
+        auto issue_b = [&](int it, BRegs& r) {
+            const unsigned char* wp = (const unsigned char*) qw + (size_t) it * 512;                       // uniform
+            const int grp = (it * GT_BK) >> gshift;
+            const uint32_t* zp = qzeros + (size_t) grp * (N >> 3);
+            const f16* sp = scales + (size_t) grp * N;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r.w4) : "v"(w_voff), "s"(wp) : "memory");
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(r.zw) : "v"(z_voff), "s"(zp) : "memory");
+            asm volatile("global_load_ushort %0, %1, %2" : "=v"(r.sc) : "v"(s_voff), "s"(sp) : "memory");
+        };
+        // one batch = 3 loads + APW DMA pieces = 11 VMEM operations, in that order
+#define GW_WAIT(NSTR, r) asm volatile("s_waitcnt vmcnt(" NSTR ")" : "+v"(r.w4), "+v"(r.zw), "+v"(r.sc) :: "memory")
+        // -(1024 + z + 1) and -(64 + z + 1) as fp16 bit patterns: 0xE400 + n, 0xD400 + 16 n (exact integers below 2048 / 128)
+        auto store_word = [&](int slot2, const BRegs& r, int j) {
+            const uint32_t z1 = ((r.zw >> b_zsh) & 0xFu) + 1u;
+            const uint32_t z2 = z1 | (z1 << 16);
+            const f16x2 zc0 = as_h2(0xE400E400u + z2), zc1 = as_h2(0xD400D400u + (z2 << 4));
+            const uint32_t sb = r.sc & 0xFFFFu;
+            const f16x2 s2 = as_h2(sb | (sb << 16));
+            const f16x8 d = t16_dequant_exact(r.w4[j], magic, zc0, zc1);
+            const uint4 u = __builtin_bit_cast(uint4, d);
+            const u32x4 ov = {__builtin_bit_cast(uint32_t, as_h2(u.x) * s2), __builtin_bit_cast(uint32_t, as_h2(u.y) * s2),
+                              __builtin_bit_cast(uint32_t, as_h2(u.z) * s2), __builtin_bit_cast(uint32_t, as_h2(u.w) * s2)};
+            asm volatile("ds_write_b128 %0, %1" :: "v"(b_dst[j] + (uint32_t) (slot2 * GT_BTILE_BYTES)), "v"(ov) : "memory");
+        };
+        auto store_b = [&](int slot2, const BRegs& r) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) store_word(slot2, r, j);
+        };
+        auto publish = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this wave's ds_writes are in LDS
+            __builtin_amdgcn_s_barrier();
+        };
+        BRegs rX, rY;
+        issue_b(0, rX);  stage_a(0, 0);
+        issue_b(1, rY);  stage_a(1, GT_BK);
+        GW_WAIT("11", rX);                                               // batch 0 landed
+        store_b(0, rX);
+        publish();
+        int a_slot = 0;
+#ifdef EXL_GEMM_PROBE
+        unsigned long long p_wait = 0, p_store = 0, p_bar = 0, p_iss = 0;
+        const unsigned long long p_t0 = __builtin_readcyclecounter();
+#endif
+        auto half_step = [&](int adma, int tf, BRegs& rI, BRegs& rW, int bstore) {
+            GP_CLK(q0);
+            issue_b(tf, rI);
+            GP_CLK(q1);
+            GW_WAIT("3", rW);
+            GP_CLK(q2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                store_word(bstore, rW, j);
+                stage_a2(j, adma, tf * GT_BK);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            GP_CLK(q3);
+            publish();
+            GP_CLK(q4);
+            GP_ACC(p_iss, q0, q1); GP_ACC(p_wait, q1, q2); GP_ACC(p_store, q2, q3); GP_ACC(p_bar, q3, q4);
+        };
+        for (int t = 0; t < nk; t += 2) {                                // straight line: every wait is unconditional
+            const int t2 = min(t + 2, nk - 1), t3 = min(t + 3, nk - 1);   // the last two steps re-fetch the last tile (never read)
+            // B(t+2) first, then the wait ("only these 3 loads may still fly" = batch t+1 has landed), then the 8 DMA
+            // pieces of A(t+2) BETWEEN the dequantised words: the CU's vector-memory pipe takes ~16 cycles per 1 KiB piece
+            // whoever issues it, so DMA issue and the VALU work overlap instead of adding up
+            half_step(ring(a_slot, 2), t2, rX, rY, 1);
+            a_slot = ring(a_slot, 1);
+            half_step(ring(a_slot, 2), t3, rY, rX, 0);
+            a_slot = ring(a_slot, 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the redundant fetches must not outlive the block's LDS
+#ifdef EXL_GEMM_PROBE
+        if (lane == 0 && b < 1024) {                                    // producers report in slots 4..7 of the block: {issue, wait, store, barrier} of the even steps
+            unsigned long long* pp = g_gemm_probe + ((size_t) b * 8 + 4 + pw) * 4;
+            pp[0] = p_iss; pp[1] = p_wait; pp[2] = p_store; pp[3] = p_bar;
+        }
+#endif
+#undef GW_WAIT
+        return;
+    }
+
+    // ===================================================== consumer =====================================================
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    f32x4 acc[TN][TM];                                                   // [n-tile][m-tile]
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fk = lane >> 4;
+    int fx_off[TM], fw_off[TN];                                           // k-chunk fk; the second half (chunk 4 + fk) flips bit 6 of the swizzled offset
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fx_off[i] = gt_off((wm * TM + i) * 16 + fr, fk);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) fw_off[i] = gt_off((wn * TN + i) * 16 + fr, fk);
+    struct Frags { f16x8 x[TM], w[TN]; };
+    auto read_frags = [&](int slot3, int slot2, int kk, Frags& f) {
+        const unsigned char* at = lds + (size_t) slot3 * A_BYTES;
+        const unsigned char* bt = ldsB + (size_t) slot2 * GT_BTILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) f.x[i] = *(const f16x8*) (at + (fx_off[i] ^ (kk << 6)));
+#pragma unroll
+        for (int i = 0; i < TN; ++i) f.w[i] = *(const f16x8*) (bt + (fw_off[i] ^ (kk << 6)));
+    };
+#define GW_MFMA(f, i) acc[(i) / TM][(i) % TM] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[(i) / TM], f.x[(i) % TM], acc[(i) / TM][(i) % TM], 0, 0, 0)
+#define GW_MFMA2(f, i) do { GW_MFMA(f, i); GW_MFMA(f, (i) + 1); } while (0)
+#define GW_MFMA4(f, i) do { GW_MFMA2(f, i); GW_MFMA2(f, (i) + 2); } while (0)
+#define GW_SB() __builtin_amdgcn_sched_barrier(0)
+    Frags P, Q;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) P.x[i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < TN; ++i) P.w[i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    __builtin_amdgcn_s_barrier();                                        // A(0), B(0) published
+    int a_slot = 0;
+#ifdef EXL_GEMM_PROBE
+    unsigned long long p_wait = 0, p_store = 0, p_bar = 0;
+    const unsigned long long p_t0 = __builtin_readcyclecounter();
+    const unsigned long long p_r0 = __builtin_amdgcn_s_memrealtime();      // constant 100 MHz
+#endif
+    auto step = [&](int bcur) {
+        GP_CLK(c0);
+        GW_MFMA4(P, 0);                       GW_SB();                    // second half of tile t-1 (zeros at t = 0)
+        read_frags(a_slot, bcur, 0, Q);       GW_SB();
+        GW_MFMA4(P, 4); GW_MFMA4(P, 8); GW_MFMA4(P, 12);  GW_SB();
+        GW_MFMA4(Q, 0);                       GW_SB();
+        read_frags(a_slot, bcur, 1, P);       GW_SB();
+        GW_MFMA4(Q, 4); GW_MFMA4(Q, 8); GW_MFMA4(Q, 12);  GW_SB();
+        GP_CLK(c1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wave's reads of tile t are done before the slots are recycled
+        __builtin_amdgcn_s_barrier();
+        GP_CLK(c2);
+        GP_ACC(p_wait, c0, c1); GP_ACC(p_bar, c1, c2);
+        a_slot = ring(a_slot, 1);
+    };
+    for (int t = 0; t < nk; t += 2) { step(0); step(1); }
+    GW_MFMA4(P, 0); GW_MFMA4(P, 4); GW_MFMA4(P, 8); GW_MFMA4(P, 12);      // second half of the last tile
+#ifdef EXL_GEMM_PROBE
+    if (lane == 0 && b < 1024 && wave < 4) {                            // consumers 0..3 report {total, mfma part, -, barrier}
+        unsigned long long* pp = g_gemm_probe + ((size_t) b * 8 + wave) * 4;
+        pp[0] = __builtin_readcyclecounter() - p_t0; pp[1] = p_wait; pp[2] = __builtin_amdgcn_s_memrealtime() - p_r0; pp[3] = p_bar;
+    }
+#endif
+#undef GW_MFMA
+#undef GW_MFMA2
+#undef GW_MFMA4
+#undef GW_SB
+
+#pragma unroll
+    for (int im = 0; im < TM; ++im) {
+        const int row = m0 + (wm * TM + im) * 16 + fr;
+        if (row < M) {
+#pragma unroll
+            for (int in = 0; in < TN; ++in) {
+                const int n = n0 + (wn * TN + in) * 16 + fk * 4;
+                if (n < N) {
+                    f16* op = out + (size_t) row * N + n;
+                    float v[4] = {acc[in][im][0], acc[in][im][1], acc[in][im][2], acc[in][im][3]};
+                    if (no_zero) {
+                        const f16x4 prev = *(const f16x4*) op;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += (float) prev[j];
+                    }
+                    *(f16x4*) op = (f16x4){(f16) v[0], (f16) v[1], (f16) v[2], (f16) v[3]};
+                }
+            }
+        }
+    }
+}
+
+static int launch_gemm_t16w(const Q4Matrix* w, const f16* xin, int rows, f16* out, int no_zero, int gshift, hipStream_t s)
+{
+    const int K = w->height, N = w->width;
+    const int mtiles = (rows + 255) / 256;
+    const int ntiles = (N + GT_BN - 1) / GT_BN;
+    const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
+    const size_t smem = 3 * (size_t) 256 * 128 + 2 * GT_BTILE_BYTES;
+    static bool big = false;
+    if (!big) {
+        EXL_HIP(hipFuncSetAttribute((const void*) q4_gemm_t16w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        big = true;
+    }
+    hipLaunchKernelGGL(q4_gemm_t16w_kernel, dim3(grid), dim3((GW_CONS + GW_PROD) * 64), smem, s, xin, (const uint4*) w->qweight, w->qzeros,
+                       w->scales, out, rows, K, N, gshift, no_zero, mtiles, ntiles);
+    EXL_LAUNCH_CHECK();
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -870,6 +1426,27 @@ static int launch_gemm_t16p(const Q4Matrix* w, const f16* xin, int rows, f16* ou
     return 0;
 }
 
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+static int launch_gemm_t16m(const Q4Matrix* w, const f16* xin, int rows, f16* out, int no_zero, int gshift, hipStream_t s)
+{
+    constexpr int TBM = WAVES_M * TM * 16;
+    const int K = w->height, N = w->width;
+    const int mtiles = (rows + TBM - 1) / TBM;
+    const int ntiles = (N + GT_BN - 1) / GT_BN;
+    const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
+    const size_t smem = 3 * (size_t) TBM * 128 + 2 * GT_BTILE_BYTES;
+    auto kfn = q4_gemm_t16m_kernel<WAVES_M, WAVES_N, TM, TN>;
+    static bool big = false;
+    if (smem > 64 * 1024 && !big) {
+        EXL_HIP(hipFuncSetAttribute((const void*) kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        big = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(WAVES_M * WAVES_N * 64), smem, s, xin, (const uint4*) w->qweight, w->qzeros,
+                       w->scales, out, rows, K, N, gshift, w->groupsize, no_zero, mtiles, ntiles);
+    EXL_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int WM>
 static int launch_gemm_t16(const Q4Matrix* w, const f16* xin, int rows, f16* out, int no_zero, int gshift, hipStream_t s)
 {
@@ -917,7 +1494,12 @@ int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
         static const bool two_stage = getenv("EXL_GEMM_TWO_STAGE") != nullptr;          // A/B switch: the simpler double-buffered kernel
         if (two_stage) return big_tile ? launch_gemm_t16<4>(w, xin, rows, out, no_zero, gshift, s) : launch_gemm_t16<2>(w, xin, rows, out, no_zero, gshift, s);
         static const int variant = getenv("EXL_GEMM_VARIANT") ? atoi(getenv("EXL_GEMM_VARIANT")) : 0;
-        if (!big_tile) return launch_gemm_t16p<2, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s);        // 128 x 128, 4 waves
+        const bool mid = variant == 0 && (uint64_t) rows * (uint64_t) K < (1ull << 31);          // 32-bit activation byte offsets
+        const bool spec = mid && gshift >= 5 && (uint64_t) K * (uint64_t) N < (1ull << 32);       // loader waves: power-of-two groups, 32-bit weight offsets
+        if (!big_tile) return mid ? launch_gemm_t16m<2, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s)
+                                  : launch_gemm_t16p<2, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s);        // 128 x 128, 4 waves
+        if (spec) return launch_gemm_t16w(w, xin, rows, out, no_zero, gshift, s);                 // 256 x 128, 8 MFMA waves + 4 loader waves
+        if (mid || (variant == 4 && (uint64_t) rows * (uint64_t) K < (1ull << 31))) return launch_gemm_t16m<4, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s);
         switch (variant) {                                               // measured at M = 2048 (7B layer): 812-827 / 735 / 738 TFLOP/s
         case 2:  return launch_gemm_t16p<4, 1, 4, 8>(w, xin, rows, out, no_zero, gshift, s);               // 256 x 128, 4 waves of 64 x 128
         case 3:  return launch_gemm_t16p<2, 2, 8, 4>(w, xin, rows, out, no_zero, gshift, s);               // 256 x 128, 4 waves of 128 x 64
