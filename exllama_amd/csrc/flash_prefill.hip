@@ -29,7 +29,7 @@ __device__ __forceinline__ int k_lds_off(int key, int slot) { return key * 256 +
 // V^T tile [128 d][64 key positions]: 128-byte rows, 8 slots of 16 B, slot ^= f(d)
 __device__ __forceinline__ int vt_lds_off(int d, int slot) { return d * 128 + ((slot ^ (((d >> 1) ^ (d >> 4)) & 7)) << 4); }
 
-__global__ __launch_bounds__(256) void flash_prefill_kernel(const f16* __restrict__ q, const f16* __restrict__ kc,
+__global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const f16* __restrict__ q, const f16* __restrict__ kc,
                                                             const f16* __restrict__ vc, f16* __restrict__ out,
                                                             int q_len, int heads, int kv_heads, int max_seq,
                                                             int past_len, float c1 /* scale * log2(e) */)
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const f16* __restric
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);                  // finite from tile 0 on (key 0 is always visible)
-        const float alpha = exp2f((m_run - m_new) * c1);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c1);
         const float mc = m_new * c1;
         float psum = 0.f;
         f16x8 pf[4];
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const f16* __restric
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(fmaf(s[kt][r], c1, -mc));
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c1, -mc));   // v_exp_f32: inputs <= 0, a flushed denormal is 0
                 psum += p;
                 pf[kt * 2 + (r >> 3)][r & 7] = (f16) p;
             }

@@ -911,8 +911,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void q4_gemm_t16m_kernel(co
 //     B(t+2) + zero word + scale into registers, then dequantise B(t+1) (landed a step ago) into the [n][k] LDS tile.
 // One s_barrier per K step over all 12 waves; same 3-slot A ring / 2-slot B ring, same hand-counted vmcnt.
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef GW_ABL
+#define GW_ABL 0                // scripts/probe_gemm.hip only: 1 = no activation DMA, 2 = no B-tile LDS stores, 8 = no fragment reads
+#endif
 #define GW_CONS 8
 #define GW_PROD 4
+#define GW_BATCH_STR "11"       // 3 loads + 8 DMA pieces
 __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(const f16* __restrict__ x, const uint4* __restrict__ qw,
                                                                const uint32_t* __restrict__ qzeros,
                                                                const f16* __restrict__ scales, f16* __restrict__ out, int M,
@@ -963,13 +967,14 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
         auto stage_a2 = [&](int pair, int slot3, int k0) {
             const f16* xk = x + k0;                                      // uniform
             const uint32_t l = lds_a0 + (uint32_t) slot3 * A_BYTES + (uint32_t) pair * 2048;
+            if (GW_ABL & 1) return;
             asm volatile("s_mov_b32 m0, %[l]\n\t"
                          "global_load_lds_dwordx4 %[v0], %[sb]\n\t"
                          "s_add_u32 m0, m0, 0x400\n\t"
                          "global_load_lds_dwordx4 %[v1], %[sb]"
                          :: [l] "s"(l), [sb] "s"(xk), [v0] "v"(a_voff[2 * pair]), [v1] "v"(a_voff[2 * pair + 1]) : "memory", "scc");
         };
-        auto stage_a = [&](int slot3, int k0) {
+        auto stage_a = [&](int slot3, int k0) {                         // all 8 pieces (prologue)
 #pragma unroll
             for (int pr = 0; pr < APW / 2; ++pr) stage_a2(pr, slot3, k0);
         };
@@ -1001,7 +1006,7 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
             asm volatile("global_load_dword %0, %1, %2" : "=v"(r.zw) : "v"(z_voff), "s"(zp) : "memory");
             asm volatile("global_load_ushort %0, %1, %2" : "=v"(r.sc) : "v"(s_voff), "s"(sp) : "memory");
         };
-        // one batch = 3 loads + APW DMA pieces = 11 VMEM operations, in that order
+        // one batch = 3 loads + 8 DMA pieces = 11 VMEM operations, in that order
 #define GW_WAIT(NSTR, r) asm volatile("s_waitcnt vmcnt(" NSTR ")" : "+v"(r.w4), "+v"(r.zw), "+v"(r.sc) :: "memory")
         // -(1024 + z + 1) and -(64 + z + 1) as fp16 bit patterns: 0xE400 + n, 0xD400 + 16 n (exact integers below 2048 / 128)
         auto store_word = [&](int slot2, const BRegs& r, int j) {
@@ -1014,7 +1019,8 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
             const uint4 u = __builtin_bit_cast(uint4, d);
             const u32x4 ov = {__builtin_bit_cast(uint32_t, as_h2(u.x) * s2), __builtin_bit_cast(uint32_t, as_h2(u.y) * s2),
                               __builtin_bit_cast(uint32_t, as_h2(u.z) * s2), __builtin_bit_cast(uint32_t, as_h2(u.w) * s2)};
-            asm volatile("ds_write_b128 %0, %1" :: "v"(b_dst[j] + (uint32_t) (slot2 * GT_BTILE_BYTES)), "v"(ov) : "memory");
+            if (GW_ABL & 2) asm volatile("; keep %0 %1" :: "v"(b_dst[j] + (uint32_t) (slot2 * GT_BTILE_BYTES)), "v"(ov));
+            else asm volatile("ds_write_b128 %0, %1" :: "v"(b_dst[j] + (uint32_t) (slot2 * GT_BTILE_BYTES)), "v"(ov) : "memory");
         };
         auto store_b = [&](int slot2, const BRegs& r) {
 #pragma unroll
@@ -1039,7 +1045,7 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
             GP_CLK(q0);
             issue_b(tf, rI);
             GP_CLK(q1);
-            GW_WAIT("3", rW);
+            GW_WAIT(GW_BATCH_STR, rW);                                   // B(t+1) in registers; its DMA pieces + the 3 new loads may still fly
             GP_CLK(q2);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1048,13 +1054,14 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
             GP_CLK(q3);
+            asm volatile("s_waitcnt vmcnt(" GW_BATCH_STR ")" ::: "memory");   // A(t+1) landed (B(t+2) + A(t+2) are the operations behind it)
             publish();
             GP_CLK(q4);
             GP_ACC(p_iss, q0, q1); GP_ACC(p_wait, q1, q2); GP_ACC(p_store, q2, q3); GP_ACC(p_bar, q3, q4);
         };
         for (int t = 0; t < nk; t += 2) {                                // straight line: every wait is unconditional
             const int t2 = min(t + 2, nk - 1), t3 = min(t + 3, nk - 1);   // the last two steps re-fetch the last tile (never read)
-            // B(t+2) first, then the wait ("only these 3 loads may still fly" = batch t+1 has landed), then the 8 DMA
+            // B(t+2) first, then the wait for B(t+1)'s registers, then the 8 DMA
             // pieces of A(t+2) BETWEEN the dequantised words: the CU's vector-memory pipe takes ~16 cycles per 1 KiB piece
             // whoever issues it, so DMA issue and the VALU work overlap instead of adding up
             half_step(ring(a_slot, 2), t2, rX, rY, 1);
@@ -1081,19 +1088,17 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fk = lane >> 4;
-    int fx_off[TM], fw_off[TN];                                           // k-chunk fk; the second half (chunk 4 + fk) flips bit 6 of the swizzled offset
-#pragma unroll
-    for (int i = 0; i < TM; ++i) fx_off[i] = gt_off((wm * TM + i) * 16 + fr, fk);
-#pragma unroll
-    for (int i = 0; i < TN; ++i) fw_off[i] = gt_off((wn * TN + i) * 16 + fr, fk);
+    // fragment byte offsets of tile 0, k-chunk fk; tile i is 16 rows = 2048 bytes further (same swizzle), the second
+    // half of the K step (chunk 4 + fk) flips bit 6 of the swizzled offset
+    const int fx0 = gt_off(wm * TM * 16 + fr, fk), fw0 = gt_off(wn * TN * 16 + fr, fk);
     struct Frags { f16x8 x[TM], w[TN]; };
     auto read_frags = [&](int slot3, int slot2, int kk, Frags& f) {
-        const unsigned char* at = lds + (size_t) slot3 * A_BYTES;
-        const unsigned char* bt = ldsB + (size_t) slot2 * GT_BTILE_BYTES;
+        const unsigned char* at = lds + (size_t) slot3 * A_BYTES + (fx0 ^ (kk << 6));
+        const unsigned char* bt = ldsB + (size_t) slot2 * GT_BTILE_BYTES + (fw0 ^ (kk << 6));
 #pragma unroll
-        for (int i = 0; i < TM; ++i) f.x[i] = *(const f16x8*) (at + (fx_off[i] ^ (kk << 6)));
+        for (int i = 0; i < TM; ++i) f.x[i] = *(const f16x8*) (at + i * 2048);
 #pragma unroll
-        for (int i = 0; i < TN; ++i) f.w[i] = *(const f16x8*) (bt + (fw_off[i] ^ (kk << 6)));
+        for (int i = 0; i < TN; ++i) f.w[i] = *(const f16x8*) (bt + i * 2048);
     };
 #define GW_MFMA(f, i) acc[(i) / TM][(i) % TM] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.w[(i) / TM], f.x[(i) % TM], acc[(i) / TM][(i) % TM], 0, 0, 0)
 #define GW_MFMA2(f, i) do { GW_MFMA(f, i); GW_MFMA(f, (i) + 1); } while (0)
@@ -1111,12 +1116,15 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
     const unsigned long long p_t0 = __builtin_readcyclecounter();
     const unsigned long long p_r0 = __builtin_amdgcn_s_memrealtime();      // constant 100 MHz
 #endif
-    auto step = [&](int bcur) {
+    auto step = [&](int t, int bcur) {
         GP_CLK(c0);
         GW_MFMA4(P, 0);                       GW_SB();                    // second half of tile t-1 (zeros at t = 0)
+        if ((GW_ABL & 4) && t > 1) { bcur = 0; }
+        if (!(GW_ABL & 8) || t < 2)
         read_frags(a_slot, bcur, 0, Q);       GW_SB();
         GW_MFMA4(P, 4); GW_MFMA4(P, 8); GW_MFMA4(P, 12);  GW_SB();
         GW_MFMA4(Q, 0);                       GW_SB();
+        if (!(GW_ABL & 8) || t < 2)
         read_frags(a_slot, bcur, 1, P);       GW_SB();
         GW_MFMA4(Q, 4); GW_MFMA4(Q, 8); GW_MFMA4(Q, 12);  GW_SB();
         GP_CLK(c1);
@@ -1126,7 +1134,7 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
         GP_ACC(p_wait, c0, c1); GP_ACC(p_bar, c1, c2);
         a_slot = ring(a_slot, 1);
     };
-    for (int t = 0; t < nk; t += 2) { step(0); step(1); }
+    for (int t = 0; t < nk; t += 2) { step(t, 0); step(t + 1, 1); }
     GW_MFMA4(P, 0); GW_MFMA4(P, 4); GW_MFMA4(P, 8); GW_MFMA4(P, 12);      // second half of the last tile
 #ifdef EXL_GEMM_PROBE
     if (lane == 0 && b < 1024 && wave < 4) {                            // consumers 0..3 report {total, mfma part, -, barrier}
