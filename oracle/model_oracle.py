@@ -51,6 +51,17 @@ class OracleLinear:
             return acc.astype(f16)
         return O.q4_matmul_recons(x, self.qweight, self.qzeros, self.scales, self.x_map, out=residual)
 
+    def with_lora(self, x, a, b, residual=None):
+        """x @ W + (x @ A) @ B in the reference's order (exllama_ext.cpp:245-324): the adapter product is formed first
+        (two fp16-rounded GEMMs), the quantised product accumulates onto it; a residual stream is added last."""
+        x = np.asarray(x).astype(f16)
+        t = (x.astype(f32) @ np.asarray(a).astype(f32)).astype(f16)
+        d = (t.astype(f32) @ np.asarray(b).astype(f32)).astype(f16)
+        y = self(x, residual=d)
+        if residual is not None:
+            y = (np.asarray(residual).astype(f32) + y.astype(f32)).astype(f16)
+        return y
+
 
 class OracleLlama:
     def __init__(self, cfg, tensors, max_seq_len=2048, num_layers=None):
@@ -81,7 +92,21 @@ class OracleLlama:
                 "up": OracleLinear(tensors, p + ".mlp.up_proj"),
                 "down": OracleLinear(tensors, p + ".mlp.down_proj"),
             })
+        self.lora = {}                     # "model.layers.i.<block>.<proj>" -> (A [in, r], B [r, out]) as exllama_amd.lora stores them
         self.reset()
+
+    def set_lora(self, tensors):
+        """tensors: the `.tensors` dict of an ExLlamaLora (or None to clear)."""
+        self.lora = {}
+        for k, v in (tensors or {}).items():
+            if k.endswith(".lora_A.weight"):
+                base = k[:-len(".lora_A.weight")]
+                self.lora[base] = (_np(v), _np(tensors[base + ".lora_B.weight"]))
+
+    def _lin(self, i, which, key, x, residual=None):
+        lin = self.layers[i][which]
+        ab = self.lora.get(f"model.layers.{i}.{key}")
+        return lin.with_lora(x, ab[0], ab[1], residual) if ab else lin(x, residual=residual)
 
     def prepare(self):
         for l in self.layers:
@@ -101,9 +126,9 @@ class OracleLlama:
         bsz, q_len, h = hidden.shape
         x2 = hidden.reshape(-1, h)
         xn = O.rms_norm(x2, l["in_norm"], self.eps)
-        q = l["q"](xn).reshape(bsz, -1)
-        k = l["k"](xn).reshape(bsz, -1)
-        v = l["v"](xn).reshape(bsz, q_len, -1)
+        q = self._lin(i, "q", "self_attn.q_proj", xn).reshape(bsz, -1)
+        k = self._lin(i, "k", "self_attn.k_proj", xn).reshape(bsz, -1)
+        v = self._lin(i, "v", "self_attn.v_proj", xn).reshape(bsz, q_len, -1)
         q = O.rope(q, self.sin, self.cos, self.past, self.heads, self.hd).reshape(bsz, q_len, self.heads, self.hd)
         k = O.rope(k, self.sin, self.cos, self.past, self.kv_heads, self.hd).reshape(bsz, q_len, -1)
         O.update_cache(k, v, self.kc[i], self.vc[i], self.past)
@@ -111,10 +136,10 @@ class OracleLlama:
         a = O.attention(q.transpose(0, 2, 1, 3), self.kc[i][:bsz, :, :kv_len], self.vc[i][:bsz, :, :kv_len],
                         causal_past_len=self.past)
         a = a.transpose(0, 2, 1, 3).reshape(-1, h)
-        x2 = l["o"](a, residual=x2)
+        x2 = self._lin(i, "o", "self_attn.o_proj", a, residual=x2)
         xn = O.rms_norm(x2, l["post_norm"], self.eps)
-        act = O.silu_mul(l["gate"](xn), l["up"](xn))
-        x2 = l["down"](act, residual=x2)
+        act = O.silu_mul(self._lin(i, "gate", "mlp.gate_proj", xn), self._lin(i, "up", "mlp.up_proj", xn))
+        x2 = self._lin(i, "down", "mlp.down_proj", act, residual=x2)
         return x2.reshape(bsz, q_len, h)
 
     def forward(self, input_ids, last_id_only=True):

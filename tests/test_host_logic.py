@@ -86,3 +86,191 @@ def test_synthetic_checkpoint_layout(tmp_path):
         assert set(f.keys()) == set(t.keys())
         assert torch.equal(f.get_tensor("model.layers.0.self_attn.q_proj.qweight"), t["model.layers.0.self_attn.q_proj.qweight"])
     assert ExLlamaConfig(cfg_path).num_key_value_heads == dims.num_key_value_heads
+
+
+# ---- model_init: the reference's command-line surface -> ExLlamaConfig (model_init.py) ---------------------------------
+def _parse(argv):
+    import argparse
+    from exllama_amd import model_init, perplexity
+    p = argparse.ArgumentParser()
+    model_init.add_args(p)
+    perplexity.add_args(p)
+    a = p.parse_args(argv)
+    model_init.post_parse(a)
+    perplexity.post_parse(a)
+    return a
+
+
+def test_model_init_flags_to_config(tmp_path):
+    from exllama_amd import model_init
+    dims = synth.PRESETS["tiny"]
+    cfg_path = tmp_path / "config.json"
+    cfg_path.write_text(json.dumps(synth.config_dict(dims)))
+    a = _parse(["-t", "tok.model", "-c", str(cfg_path), "-m", "w.safetensors", "-l", "4096", "-gs", "20,7.5", "-a", "2.0",
+                "-mmrt", "16", "-fmt", "0", "-nfa", "-mmfr", "-flash", "1024"])
+    model_init.get_model_files(a)                       # -t/-c/-m given: nothing to discover
+    c = model_init.make_config(a)
+    assert (c.max_seq_len, c.matmul_recons_thd, c.fused_mlp_thd, c.fused_attn, c.matmul_fused_remap) == (4096, 16, 0, False, True)
+    assert c.auto_map == [20.0, 7.5] and c.model_path == "w.safetensors"
+    assert c.use_flash_attn_2 and c.max_input_len == 1024
+    hd = dims.hidden_size // dims.num_attention_heads
+    assert c.rotary_embedding_base == pytest.approx(10000.0 * 2.0 ** (hd / (hd - 2)))       # NTK alpha (model.py:122-123)
+    assert c.rmsnorm_no_half2 and c.silu_no_half2      # ROCm default of the reference: half2 paths off unless -fh2
+    assert _parse(["-c", str(cfg_path), "-theta", "500000"]).theta == 500000.0
+    model_init.print_options(a)
+    # defaults are the reference's
+    d = _parse([])
+    assert (d.length, d.matmul_recons_thd, d.fused_mlp_thd, d.sdp_thd, d.compress_pos_emb, d.alpha) == (2048, 8, 2, 8, 1.0, 1.0)
+
+
+def test_model_init_directory_discovery(tmp_path):
+    from exllama_amd import model_init
+    (tmp_path / "config.json").write_text("{}")
+    for n in ("model-00001-of-00002.safetensors", "model-00002-of-00002.safetensors"):
+        (tmp_path / n).write_bytes(b"")
+    a = _parse(["-d", str(tmp_path)])
+    model_init.get_model_files(a)
+    assert a.config.endswith("config.json") and a.tokenizer.endswith("tokenizer.model") and len(a.model) == 2
+    assert model_init._wildcard_name([os.path.basename(m) for m in a.model]) == "model-0000*-of-00002.safetensors"
+    with pytest.raises(SystemExit):
+        model_init.get_model_files(_parse(["-t", "x"]))          # neither -d nor all of -t -c -m
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    with pytest.raises(SystemExit):
+        model_init.get_model_files(_parse(["-d", str(empty)]))
+
+
+# ---- perplexity: chunking and the NLL arithmetic (perplexity.py) -------------------------------------------------------
+class _FixedLogitsModel:
+    """forward() returns the same logits row for every position: ppl is then known in closed form."""
+    def __init__(self, row):
+        self.row = torch.as_tensor(row, dtype=torch.float32)
+        self.calls = []
+
+    def forward(self, ids, cache, last_id_only=True, lora=None):
+        self.calls.append((tuple(ids.shape), cache.current_seq_len))
+        cache.current_seq_len += ids.shape[1]
+        return self.row.expand(ids.shape[0], ids.shape[1], -1).clone()
+
+
+class _Cache:
+    current_seq_len = 0
+
+
+def test_perplexity_chunking_and_value():
+    from exllama_amd.perplexity import Perplexity
+    V = 7
+    m = _FixedLogitsModel(torch.zeros(V))
+    p = Perplexity(model=m, cache=_Cache())
+    p.add_tokens(torch.arange(25) % V, chunk_size=10, overlap=2)             # windows start every 8 tokens
+    assert [c.shape[1] for c in p.dataset_chunks] == [10, 10, 9, 1]
+    assert p.dataset_chunks[1][0, 0].item() == 8 % V
+    assert p.test(quiet=True) == pytest.approx(V)                            # uniform prediction: ppl = vocabulary size
+    assert [c for c, _ in m.calls] == [(1, 9), (1, 9), (1, 8)]               # 1-token tail chunk skipped; cache restarted per chunk
+    assert all(pos == 0 for _, pos in m.calls)
+    # token-by-token mode makes one call per input token and gives the same number
+    m2 = _FixedLogitsModel(torch.tensor([2.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]))
+    p2 = Perplexity(model=m2, cache=_Cache())
+    p2.add_tokens(torch.zeros(6, dtype=torch.long), chunk_size=6)
+    whole = p2.test(quiet=True)
+    assert whole == pytest.approx(1.0 / torch.softmax(m2.row, 0)[0].item())
+    n_whole = len(m2.calls)
+    assert p2.test(quiet=True, ppl_token=True) == pytest.approx(whole)
+    assert len(m2.calls) - n_whole == 5
+    # chunk_limit and truncation
+    p3 = Perplexity(model=m, cache=_Cache())
+    p3.add_tokens(torch.arange(40) % V, chunk_size=16, chunk_truncate=4, overlap=99)     # overlap clamped to chunk_size - 2
+    assert all(c.shape[1] <= 4 for c in p3.dataset_chunks) and len(p3.dataset_chunks) == 20
+    assert p3.test(chunk_limit=2, quiet=True) == pytest.approx(V)
+    with pytest.raises(SystemExit):
+        Perplexity(model=m, cache=_Cache()).test()
+
+
+def test_perplexity_presets_and_json_loader(tmp_path):
+    from exllama_amd.perplexity import Perplexity
+    a = _parse(["-ppl", "gptq-for-llama"])
+    assert (a.perplexity_dataset, a.perplexity_chunk_num, a.perplexity_chunk_min) == ("datasets/wikitext2.txt", 128, 0)
+    assert _parse(["-ppl"]).perplexity_dataset == "datasets/wikitext2_val_sample.jsonl"
+    assert _parse([]).perplexity is None
+
+    class Tok:
+        def encode(self, text):
+            return torch.tensor([[ord(ch) % 11 for ch in text]])
+    ds = tmp_path / "d.jsonl"
+    ds.write_text("\n".join(json.dumps({"text": t}) for t in ["short", "a much longer record of text", "another long enough record"]))
+    p = Perplexity(model=_FixedLogitsModel(torch.zeros(11)), cache=_Cache(), tokenizer=Tok())
+    p.load(str(ds), chunk_size=12, chunk_truncate=8, minlength=10)
+    assert [c.shape[1] for c in p.dataset_chunks] == [8, 8]
+    raw = tmp_path / "d.txt"
+    raw.write_text("x" * 30)
+    p.load(str(raw), chunk_size=12)
+    assert [c.shape[1] for c in p.dataset_chunks[2:]] == [12, 12, 6]
+    with pytest.raises(ValueError):
+        Perplexity(model=p.model, cache=_Cache()).load(str(raw), 8)
+
+
+# ---- lora: PEFT adapter -> transposed, pre-scaled fp16 halves keyed by target layer (lora.py) ---------------------------
+class _Lin:
+    def __init__(self, i, o):
+        self.in_features, self.out_features = i, o
+
+
+class _Blk:
+    pass
+
+
+def _stub_model(layers=2, h=16, inter=24):
+    class M:
+        pass
+    m = M()
+    m.config = type("C", (), {"device_map": ExLlamaDeviceMap(layers)})()
+    m.config.device_map.layers = ["cpu"] * layers
+    m.layers = []
+    for _ in range(layers):
+        l = _Blk()
+        l.self_attn, l.mlp = _Blk(), _Blk()
+        for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            setattr(l.self_attn, n, _Lin(h, h))
+        l.mlp.gate_proj, l.mlp.up_proj, l.mlp.down_proj = _Lin(h, inter), _Lin(h, inter), _Lin(inter, h)
+        m.layers.append(l)
+    return m
+
+
+def test_lora_loader(tmp_path):
+    from exllama_amd.lora import ExLlamaLora
+    m = _stub_model()
+    g = torch.Generator().manual_seed(0)
+    r = 4
+    pre = "base_model.model.model.layers."
+    sd = {pre + "0.self_attn.q_proj.lora_A.weight": torch.randn(r, 16, generator=g),
+          pre + "0.self_attn.q_proj.lora_B.weight": torch.randn(16, r, generator=g).to(torch.bfloat16),
+          pre + "1.mlp.down_proj.lora_A.weight": torch.randn(r, 24, generator=g).half(),
+          pre + "1.mlp.down_proj.lora_B.weight": torch.randn(16, r, generator=g),
+          pre + "1.mlp.down_proj.bias": torch.zeros(16)}
+    cfg = tmp_path / "adapter_config.json"
+    cfg.write_text(json.dumps({"r": r, "lora_alpha": 8, "fan_in_fan_out": False}))
+    lora = ExLlamaLora(m, str(cfg), "adapter.bin", tensors=sd)
+    assert (lora.lora_r, lora.lora_alpha, lora.lora_scaling, lora.bias_ignored) == (4, 8.0, 2.0, True)
+    assert sorted(lora.tensors) == ["model.layers.0.self_attn.q_proj.lora_A.weight", "model.layers.0.self_attn.q_proj.lora_B.weight",
+                                    "model.layers.1.mlp.down_proj.lora_A.weight", "model.layers.1.mlp.down_proj.lora_B.weight"]
+    a = lora.tensors["model.layers.0.self_attn.q_proj.lora_A.weight"]
+    b = lora.tensors["model.layers.0.self_attn.q_proj.lora_B.weight"]
+    assert a.shape == (16, r) and b.shape == (r, 16) and a.dtype == b.dtype == torch.float16 and a.is_contiguous()
+    assert torch.equal(a, sd[pre + "0.self_attn.q_proj.lora_A.weight"].T.half())
+    assert torch.equal(b, (sd[pre + "0.self_attn.q_proj.lora_B.weight"].T * 2.0).half())          # alpha / r folded into B
+    # through a real file too
+    from safetensors.torch import save_file
+    st = tmp_path / "adapter_model.safetensors"
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(st))
+    again = ExLlamaLora(m, str(cfg), str(st))
+    assert all(torch.equal(again.tensors[k], lora.tensors[k]) for k in lora.tensors)
+    # rejections (reference: lora.py:33-34, 51, 60-63, 94-95)
+    bad = [({"r": 4, "lora_alpha": 4, "fan_in_fan_out": True}, sd),
+           ({"r": 4, "lora_alpha": 4}, {"lm_head.lora_A.weight": torch.zeros(4, 16)}),
+           ({"r": 4, "lora_alpha": 4}, {pre + "0.self_attn.q_proj.lora_A.weight": torch.zeros(4, 17)}),
+           ({"r": 4, "lora_alpha": 4}, {pre + "0.mlp.q_proj.lora_A.weight": torch.zeros(4, 16)}),
+           ({"r": 4, "lora_alpha": 4}, {pre + "0.self_attn.q_proj.bias": torch.ones(16)}),
+           ({"r": 4, "lora_alpha": 4}, {pre + "0.self_attn.q_proj.lora_A.weight": torch.zeros(4, 16, dtype=torch.int32)})]
+    for c, tensors in bad:
+        with pytest.raises(ValueError):
+            ExLlamaLora(m, c, "x.bin", tensors=tensors)

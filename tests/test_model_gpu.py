@@ -203,3 +203,71 @@ def test_native_decode_executor_matches_op_path_and_oracle(name, gs, act):
     again = model.forward(torch.tensor([[toks_ops[0]]], device="cuda:0"), c_graph)[0, 0].float().cpu()
     assert torch.equal(again, graph[0])
     model.free_unmanaged()
+
+
+def test_perplexity_module_chunk_and_token_modes_and_oracle():
+    """exllama_amd.perplexity (the reference's -ppl leg, perplexity.py:93-138) on a seeded token stream: whole-chunk
+    (MFMA GEMM + flash prefill) and token-by-token (decode kernels) evaluation agree to the reference's own precision
+    (2 decimals relative), and both agree with the CPU oracle model."""
+    from exllama_amd.perplexity import Perplexity
+    model, cache, tensors, dims = _build("tiny_gqa", 64, True, seed=3, max_seq_len=48)
+    ids = torch.randint(1, dims.vocab_size, (1, 100), generator=torch.Generator().manual_seed(7))
+    p = Perplexity(model=model, cache=cache)
+    p.add_tokens(ids.to("cuda:0"), chunk_size=40, overlap=4)
+    assert [c.shape[1] for c in p.dataset_chunks] == [40, 40, 28]
+    whole = p.test(quiet=True)
+    token = p.test(quiet=True, ppl_token=True)
+    orc = OracleLlama(synth.config_dict(dims), tensors, max_seq_len=48)
+    lp_sum, n = 0.0, 0
+    for c in p.dataset_chunks:
+        c = c.cpu()
+        orc.reset()
+        lg = torch.from_numpy(np.asarray(orc.forward(c[:, :-1].numpy(), last_id_only=False), dtype=np.float32))
+        lp = torch.log_softmax(lg, dim=-1).gather(-1, c[:, 1:].unsqueeze(-1))
+        lp_sum += lp.sum().item()
+        n += c.shape[1] - 1
+    ref = math.exp(-lp_sum / n)
+    assert math.isfinite(whole) and whole > 1.0
+    assert abs(whole - token) < 5e-3 * whole, (whole, token)
+    assert abs(whole - ref) < 5e-3 * ref, (whole, ref)
+    model.free_unmanaged()
+
+
+@pytest.mark.parametrize("name,gs,act", [("tiny", 64, False), ("tiny_gqa", 128, True)])
+def test_lora_adapter_end_to_end(name, gs, act):
+    """exllama_amd.lora.ExLlamaLora (PEFT layout in, transposed + pre-scaled halves out) through every projection of the
+    model, prefill (q4_matmul_lora) and single-token decode (q4_attn / q4_mlp with LoRA operands), against the oracle
+    model with the same adapter; and the adapter must actually change the logits."""
+    from exllama_amd.lora import ExLlamaLora
+    from exllama_amd.model import ExLlamaCache
+    model, cache, tensors, dims = _build(name, gs, act, seed=9)
+    g = torch.Generator().manual_seed(21)
+    r, sd = 8, {}
+    kvd = dims.hidden_size // dims.num_attention_heads * dims.num_key_value_heads
+    shapes = {"self_attn.q_proj": (dims.hidden_size, dims.hidden_size), "self_attn.k_proj": (dims.hidden_size, kvd),
+              "self_attn.v_proj": (dims.hidden_size, kvd), "self_attn.o_proj": (dims.hidden_size, dims.hidden_size),
+              "mlp.gate_proj": (dims.hidden_size, dims.intermediate_size), "mlp.up_proj": (dims.hidden_size, dims.intermediate_size),
+              "mlp.down_proj": (dims.intermediate_size, dims.hidden_size)}
+    for i in range(dims.num_hidden_layers):
+        for key, (fin, fout) in shapes.items():
+            if i == 1 and key == "mlp.up_proj":
+                continue                                                     # a projection without an adapter stays on the plain path
+            sd[f"base_model.model.model.layers.{i}.{key}.lora_A.weight"] = torch.randn(r, fin, generator=g) * 0.05
+            sd[f"base_model.model.model.layers.{i}.{key}.lora_B.weight"] = torch.randn(fout, r, generator=g) * 0.05
+    lora = ExLlamaLora(model, {"r": r, "lora_alpha": 16}, "synthetic.bin", tensors=sd)
+    assert all(t.device.type == "cuda" and t.dtype == torch.float16 for t in lora.tensors.values())
+    ids = torch.randint(1, dims.vocab_size, (1, 12), generator=torch.Generator().manual_seed(2))
+    base = model.forward(ids.to("cuda:0"), cache, last_id_only=False).float().cpu()
+    cache2 = ExLlamaCache(model)
+    got = model.forward(ids.to("cuda:0"), cache2, last_id_only=False, lora=lora).float().cpu()
+    orc = OracleLlama(synth.config_dict(dims), tensors, max_seq_len=64)
+    orc.set_lora({k: v.cpu() for k, v in lora.tensors.items()})
+    ref = torch.from_numpy(np.asarray(orc.forward(ids.numpy(), last_id_only=False), dtype=np.float32))
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 2e-2 * scale, ((got - ref).abs().max().item(), scale)
+    assert (got - base).abs().max().item() > 5e-2 * scale                    # the adapter is not a no-op
+    tok = torch.tensor([[int(ref[0, -1].argmax())]])
+    step = model.forward(tok.to("cuda:0"), cache2, lora=lora).float().cpu()   # rows == 1: fused decode ops with LoRA operands
+    ref_step = torch.from_numpy(np.asarray(orc.forward(tok.numpy()), dtype=np.float32))
+    assert (step - ref_step).abs().max().item() <= 2e-2 * scale
+    model.free_unmanaged()
