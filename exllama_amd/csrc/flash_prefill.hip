@@ -16,6 +16,7 @@
 //   both LDS tiles are XOR-swizzled for ds_read_b128.
 // Causal: query i (global row q0+i) sees keys j <= past_len + q0 + i; tiles beyond the diagonal are skipped.
 #include "common.h"
+#include <stdlib.h>
 
 #define FA_BQ 128
 #define FA_BKV 64
@@ -28,6 +29,21 @@ __device__ __forceinline__ uint32_t pack_hi(uint32_t a, uint32_t b) { return (a 
 __device__ __forceinline__ int k_lds_off(int key, int slot) { return key * 256 + ((slot ^ (key & 15)) << 4); }
 // V^T tile [128 d][64 key positions]: 128-byte rows, 8 slots of 16 B, slot ^= f(d)
 __device__ __forceinline__ int vt_lds_off(int d, int slot) { return d * 128 + ((slot ^ (((d >> 1) ^ (d >> 4)) & 7)) << 4); }
+
+// Per-lane LDS offsets of the MFMA operand fragments, computed ONCE (the loop body is VALU-issue bound: every address
+// instruction saved per tile counts).  K: k_lds_off(32 * kt + c, 2 * kb + g) = kofs[kb] + kt * 8192 (the swizzle only sees
+// c & 15).  V^T: vt_lds_off(32 * dt + c, 2 * kb2 + g) = vofs[kb2 ^ dt] + dt * 4096: with d = 32 * dt + c the swizzle term
+// ((d >> 1) ^ (d >> 4)) & 7 is ((c >> 1) ^ (c >> 4)) & 7 xor 2 * dt, and xor-ing 2 * dt into slot 2 * kb2 + g permutes kb2.
+struct FaFragOffsets { int kofs[8]; int vofs[4]; };
+__device__ __forceinline__ FaFragOffsets fa_frag_offsets(int c, int g)
+{
+    FaFragOffsets o;
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) o.kofs[kb] = k_lds_off(c, 2 * kb + g);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o.vofs[t] = vt_lds_off(c, 2 * t + g);
+    return o;
+}
 
 __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const f16* __restrict__ q, const f16* __restrict__ kc,
                                                             const f16* __restrict__ vc, f16* __restrict__ out,
@@ -55,6 +71,7 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const f16* __rest
     const int lane = tid & 63;
     const int g = lane >> 5;
     const int c = lane & 31;
+    const FaFragOffsets fo = fa_frag_offsets(c, g);
 
     const int q0 = qb * FA_BQ;
     const int qrow = q0 + wave * 32 + c;                       // this lane's query (row inside q_len)
@@ -144,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const f16* __rest
             for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 8; ++kb) {
-                const f16x8 kf = *(const f16x8*) (k_lds + k_lds_off(kt * 32 + c, 2 * kb + g));
+                const f16x8 kf = *(const f16x8*) (k_lds + fo.kofs[kb] + kt * 8192);
                 s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kb], s[kt], 0, 0, 0);
             }
         }
@@ -195,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const f16* __rest
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
             for (int kb2 = 0; kb2 < 4; ++kb2) {
-                const f16x8 vf = *(const f16x8*) (vt_lds + vt_lds_off(dt * 32 + c, 2 * kb2 + g));
+                const f16x8 vf = *(const f16x8*) (vt_lds + fo.vofs[kb2 ^ dt] + dt * 4096);
                 acc_o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb2], acc_o[dt], 0, 0, 0);
             }
     }
@@ -222,6 +239,10 @@ int launch_flash_prefill(const f16* q, const f16* kc, const f16* vc, f16* out, i
     EXL_REQUIRE(hd == FA_HD, EXL_E_UNSUPPORTED, "flash prefill: head_dim must be 128 (got %d)", hd);
     const float c1 = (1.0f / sqrtf((float) hd)) * 1.4426950408889634f;
     dim3 grid(((q_len + FA_BQ - 1) / FA_BQ) * heads * bsz);
+    // Measured and dropped (round 1): an 8-wave block whose wave pairs split every tile's keys and merge at the end (one
+    // block per CU, heaviest-first dispatch) is balanced by construction but 79 us against 67 us for this kernel at
+    // S = 2048: the loop is bound by instruction issue (PMC: ~310 VALU instructions per 32 MFMAs, MFMA pipe 21 % busy),
+    // not by the causal imbalance.
     hipLaunchKernelGGL(flash_prefill_kernel, grid, dim3(256), 0, s, q, kc, vc, out, q_len, heads, kv_heads, max_seq,
                        past_len, c1);
     EXL_LAUNCH_CHECK();
