@@ -43,6 +43,7 @@ def parse_args():
     p.add_argument("--layers", type=int, default=None, help="debug: truncate the model (INVALID as a benchmark)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-graph", action="store_true", help="decode eagerly instead of replaying the captured hipGraph")
+    p.add_argument("--host-argmax", action="store_true", help="greedy argmax by torch between graph replays (the reference's loop) instead of inside the graph")
     p.add_argument("--no-roofline-probe", action="store_true")
     p.add_argument("--layer-split", action="store_true",
                    help="ONE model split by layers across the ranks (hidden states handed off by RCCL send/recv, exllama_amd/pipeline.py) "
@@ -212,8 +213,13 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)
     phase_ms = {"prefill": [], "worst": [], "best": []}
 
+    device_greedy = use_graph and not args.host_argmax and hasattr(model, "generate_greedy")
+
     def decode(n, logits):
-        for _ in range(n):
+        if device_greedy:                                         # n graph replays: decode kernels + argmax feeding the next step
+            model.generate_greedy(logits[0, -1].argmax().view(1, 1), cache, n)
+            return model.last_decoder_logits()
+        for _ in range(n):                                        # the reference's loop (test_benchmark_inference.py:188-191)
             tok = logits[0, -1].argmax().view(1, 1)               # stays on the device: no host sync per token
             logits = model.forward(tok, cache)
         return logits
@@ -277,7 +283,8 @@ def main():
                         f"{S}-token prefill + {G}-token greedy decode at context {S}..{S + G} (BASELINE configs[1]); "
                         f"plus {G} tokens from context 4",
             "layers": L, "prompt_tokens": S, "gen_tokens": G, "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
-            "decode_mode": "hipGraph replay" if use_graph else "eager launches",
+            "decode_mode": ("hipGraph replay, greedy argmax inside the graph" if device_greedy else
+                            "hipGraph replay, torch.argmax between replays" if use_graph else "eager launches"),
         },
         "prefill_tokens_per_s": round(prefill_tps, 1),
         "decode_worst_tokens_per_s": round(decode_tps, 2),

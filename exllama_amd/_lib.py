@@ -57,6 +57,7 @@ SIGNATURES = {
     "exl_decoder_set_layer": (c_int, [c_void_p, c_int] + [c_void_p] * 11),
     "exl_decoder_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "exl_decoder_set_kv_splits": (c_int, [c_void_p, c_int, C.POINTER(c_int)]),
+    "exl_decoder_step_greedy": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "exl_decoder_step_timed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, C.POINTER(c_float)]),
     "exl_decoder_free": (c_int, [c_void_p]),
     "exl_rep_penalty": (c_int, [c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int]),

@@ -497,6 +497,42 @@ __global__ __launch_bounds__(256) void dec_head_kernel(const f16* __restrict__ h
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// K7 (greedy generation only): argmax of the logits -> the next token, written where the next step reads its input and
+// into history[position of that token].  Lowest index wins ties; NaNs never win.  One block: 128 KB of logits.
+// Replaces the host-driven torch.argmax + two small copies per token of the reference's loop
+// (test_benchmark_inference.py:188-191).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void dec_argmax_kernel(const float* __restrict__ logits, int vocab, int64_t* __restrict__ token_io,
+                                                          int64_t* __restrict__ history, const int32_t* __restrict__ pos_dev)
+{
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const int tid = threadIdx.x;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = tid; i < vocab; i += 1024) {
+        const float v = logits[i];
+        if (v > best || (v == best && i < idx)) { best = v; idx = i; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(idx, off, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if ((tid & 63) == 0) { bv[tid >> 6] = best; bi[tid >> 6] = idx; }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int w = 1; w < 16; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        if (idx == 0x7fffffff) idx = 0;                                  // all NaN / -inf: token 0
+        *token_io = idx;
+        if (history) history[*pos_dev] = idx;                            // the head kernel has already advanced the position
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 struct DecLayer {
@@ -772,6 +808,23 @@ extern "C" int exl_decoder_step(void* dec, const int64_t* token_dev, int32_t* po
     if (rc == 0) rc = dec_launch(d, EXL_DEC_HEAD, 0, token_dev, pos_dev, logits_out, advance, s);
     if (prev != d->device) (void) hipSetDevice(prev);
     return rc;
+}
+
+extern "C" int exl_decoder_step_greedy(void* dec, int64_t* token_io_dev, int32_t* pos_dev, float* logits_out,
+                                       int64_t* history_dev, void* stream)
+{
+    Decoder* d = dec_from(dec);
+    EXL_REQUIRE(d, EXL_E_INVALID, "decoder_step_greedy: invalid decoder");
+    const int rc = exl_decoder_step(dec, token_io_dev, pos_dev, logits_out, 1, stream);
+    if (rc) return rc;
+    int prev = 0;
+    EXL_HIP(hipGetDevice(&prev));
+    if (prev != d->device) EXL_HIP(hipSetDevice(d->device));
+    hipLaunchKernelGGL(dec_argmax_kernel, dim3(1), dim3(1024), 0, (hipStream_t) stream, logits_out, d->vocab, token_io_dev, history_dev, pos_dev);
+    const hipError_t e = hipGetLastError();
+    if (prev != d->device) (void) hipSetDevice(prev);
+    if (e != hipSuccess) EXL_FAIL((int) e, "decoder_step_greedy: %s", hipGetErrorString(e));
+    return 0;
 }
 
 // Measurement aid: for each kernel class, `reps` passes over ALL layers' launches of that class back to back (so the

@@ -185,7 +185,10 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const f16* __rest
                 }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);                  // finite from tile 0 on (key 0 is always visible)
+        // Lazy reference maximum: softmax is invariant to the reference point as long as l and O share it, so the running
+        // maximum only moves when a row's maximum grew by more than 2^8 in the exp2 domain (p <= 256 stays exact-range in
+        // fp16, O and l accumulate in fp32).  After the first tiles almost no tile rescales O (64 multiplies per lane).
+        const float m_new = (mx - m_run) * c1 > 8.0f ? mx : m_run;     // m_run = -inf on the first tile: always taken
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c1);
         const float mc = m_new * c1;
         float psum = 0.f;
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const f16* __rest
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c1, -mc));   // v_exp_f32: inputs <= 0, a flushed denormal is 0
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c1, -mc));   // v_exp_f32: exponent <= 8, a flushed denormal is 0
                 psum += p;
                 pf[kt * 2 + (r >> 3)][r & 7] = (f16) p;
             }

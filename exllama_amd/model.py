@@ -661,6 +661,7 @@ class ExLlama:
         if use_graph:
             # one captured graph per context bucket: short contexts use fewer KV splits (1 split = no merge kernel)
             st["graphs"] = []
+            st["bucket_splits"] = []
             start = cache.current_seq_len
             st["pos"].fill_(start)
             self._decoder_launch(st, advance=0)                 # eager dry run with the full split count (the K/V written
@@ -677,6 +678,7 @@ class ExLlama:
                 with torch.cuda.graph(g):                        # capture only records: nothing runs at this position
                     self._decoder_launch(st, advance=1)
                 st["graphs"].append((limit, g))
+                st["bucket_splits"].append(ns)
             st["graph"] = st["graphs"][-1][1]
             st["pos"].fill_(start)
             st["dev_pos"] = start
@@ -706,6 +708,59 @@ class ExLlama:
         cache.current_seq_len += 1
         st["dev_pos"] = cache.current_seq_len
         return _move_tensor(st["logits"].clone(), output_device, "logits", self.config)
+
+    def generate_greedy(self, first_token, cache, num_tokens):
+        """num_tokens greedy steps entirely on the device: each replay of a captured hipGraph runs the decode kernels AND the
+        argmax that feeds the next step (exl_decoder_step_greedy), so there is no host work between tokens -- the reference's
+        loop does `torch.argmax(logits)` + forward per token (test_benchmark_inference.py:188-191).  `first_token` is the
+        token at position cache.current_seq_len; returns the num_tokens tokens that follow it (LongTensor on the device) and
+        leaves the last step's logits in the executor's buffer (self.last_decoder_logits()).  Needs
+        enable_decode_graph(cache, use_graph=True)."""
+        st = self._decoder
+        if st is None or st["cache"] is not cache or st["graph"] is None:
+            raise RuntimeError("generate_greedy needs enable_decode_graph(cache) with graph replay")
+        start = cache.current_seq_len
+        if start + num_tokens > cache.max_seq_len:
+            raise RuntimeError(f"sequence ({start} + {num_tokens}) exceeds the cache length {cache.max_seq_len}")
+        if "history" not in st:
+            import ctypes as C
+            st["history"] = torch.zeros((cache.max_seq_len + 1,), dtype=torch.int64, device=st["dev"])
+            st["ggraphs"] = []
+            torch.cuda.synchronize(st["dev"])
+            keep_tok, keep_pos = st["tok"].clone(), st["pos"].clone()
+            for ns, (limit, _) in zip(self._bucket_splits(st), st["graphs"]):
+                cuda_ext.check(ext._lib.exl_decoder_set_kv_splits(st["handle"], ns, None), "decoder_set_kv_splits")
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):                        # capture only records
+                    with cuda_ext._Guard(st["dev"]):
+                        cuda_ext.check(ext._lib.exl_decoder_step_greedy(st["handle"], st["tok"].data_ptr(), st["pos"].data_ptr(),
+                                                                        st["logits"].data_ptr(), st["history"].data_ptr(),
+                                                                        torch.cuda.current_stream(st["dev"]).cuda_stream),
+                                       "decoder_step_greedy")
+                st["ggraphs"].append((limit, g))
+            st["tok"].copy_(keep_tok); st["pos"].copy_(keep_pos)
+        st["tok"].copy_(first_token.view(1, 1), non_blocking=True)
+        if st["dev_pos"] != start:
+            st["pos"].fill_(start)
+        for i in range(num_tokens):
+            p = start + i
+            for limit, g in st["ggraphs"]:
+                if p <= limit:
+                    g.replay()
+                    break
+            else:
+                raise RuntimeError(f"position {p} beyond the decoder's context limit")
+        cache.current_seq_len = start + num_tokens
+        st["dev_pos"] = cache.current_seq_len
+        return st["history"][start + 1:start + num_tokens + 1].clone()
+
+    def last_decoder_logits(self):
+        """fp32 logits [1, 1, vocab] of the most recent executor step (a copy)."""
+        return self._decoder["logits"].clone()
+
+    @staticmethod
+    def _bucket_splits(st):
+        return st["bucket_splits"]
 
     DECODER_CLASSES = ("qkv", "attn", "merge", "o_proj", "gate_up", "down", "head")
 

@@ -186,6 +186,14 @@ int exl_decoder_step(void* decoder, const int64_t* token_dev, int32_t* pos_dev, 
  * (position) a step with this setting can serve.  A captured graph keeps the setting it was captured with, so a caller
  * can hold one graph per context bucket and pick by position (exllama_amd/model.py does). */
 int exl_decoder_set_kv_splits(void* decoder, int nsplit, int* max_context);
+/* One greedy generation step, all on the device: exl_decoder_step(..., advance = 1) followed by an argmax kernel that
+ * writes the next token to *token_io_dev (where the following step reads its input) and, if history_dev is not NULL, to
+ * history_dev[position of that token] (history_dev must hold max_seq_len + 1 entries).  Ties go to the lowest index.
+ * Captured into a hipGraph, N replays generate N tokens with no host work in between (the reference's loop runs
+ * torch.argmax and two copies on the host side per token, test_benchmark_inference.py:188-191). */
+int exl_decoder_step_greedy(void* decoder, int64_t* token_io_dev, int32_t* pos_dev, float* logits_out, int64_t* history_dev,
+                            void* stream);
+
 /* Measurement aid (bench.py): for each kernel class, `reps` passes over all layers' launches of that class back to
  * back between two hipEvents on `stream` (the weights stream from HBM as in a real step); class_ms_host[c] (HOST memory,
  * EXL_DEC_NCLASS floats) = mean time of one pass = that class' share of one token.  Overwrites the K/V slot at *pos_dev,

@@ -271,3 +271,38 @@ def test_lora_adapter_end_to_end(name, gs, act):
     ref_step = torch.from_numpy(np.asarray(orc.forward(tok.numpy()), dtype=np.float32))
     assert (step - ref_step).abs().max().item() <= 2e-2 * scale
     model.free_unmanaged()
+
+
+def test_device_greedy_generation_matches_the_host_loop():
+    """generate_greedy (argmax inside the captured graph, exl_decoder_step_greedy) produces the token sequence of the
+    reference's loop -- forward, torch.argmax on the logits, forward ... -- and leaves the same final logits and cache."""
+    from exllama_amd.model import ExLlamaCache
+    model, cache, tensors, dims = _build("tiny_hd128", 128, False, seed=4, max_seq_len=256)
+    ids = torch.randint(1, dims.vocab_size, (1, 150), generator=torch.Generator().manual_seed(3)).to("cuda:0")   # crosses the 160-key bucket limit
+    n = 24
+    lg = model.forward(ids, cache)
+    first = lg[0, -1].argmax().view(1, 1)
+    model.enable_decode_graph(cache)
+    # host loop: graph replay, torch.argmax, graph replay ... (same kernels, so the same logits bit for bit)
+    toks, tok, cur = [], first, lg
+    for _ in range(n):
+        cur = model.forward(tok, cache)
+        tok = cur[0, -1].argmax().view(1, 1)
+        toks.append(int(tok))
+    assert len(set(toks)) > 1
+    # device loop from the same position
+    cache.current_seq_len = 150
+    got = model.generate_greedy(first, cache, n)
+    assert cache.current_seq_len == 150 + n
+    assert got.dtype == torch.int64 and got.tolist() == toks
+    last = model.last_decoder_logits()
+    assert torch.equal(last, cur.to(last.device).view_as(last))
+    # the executor can continue token by token afterwards, and be rewound
+    nxt = model.forward(got[-1].view(1, 1), cache)
+    assert torch.isfinite(nxt).all() and cache.current_seq_len == 150 + n + 1
+    cache.current_seq_len = 150
+    again = model.generate_greedy(first, cache, n)
+    assert again.tolist() == toks
+    with pytest.raises(RuntimeError):
+        model.generate_greedy(first, cache, 1000)
+    model.free_unmanaged()
