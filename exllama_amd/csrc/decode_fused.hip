@@ -239,6 +239,14 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
 // (scores -> softmax -> PV with the V rows already in registers).  Longer splits loop over further chunks.
 // ---------------------------------------------------------------------------------------------------------------
 #define DEC_ATT_UN 10
+#define DEC_ATT_AHEAD 5          // rows per thread in flight during the score phase (8 waves x 5 KiB per CU)
+// Phase attribution (probe builds only, scripts/probe_attn.sh): cycles summed over blocks at 7 points of the kernel.
+#ifdef EXL_ATTN_PROBE
+__device__ unsigned long long g_attn_probe[512 * 8];                // [block][point]; read out by exl_debug_attn_probe
+#define AP_CLK(i) ap_t[i] = __builtin_readcyclecounter()
+#else
+#define AP_CLK(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q, const f16* __restrict__ k_new,
                                                        const f16* __restrict__ v_new, f16* __restrict__ kc,
                                                        f16* __restrict__ vc, const f16* __restrict__ sin,
@@ -264,6 +272,10 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
     }
     const int tid = threadIdx.x;
     const int d8 = tid & 15, ks = tid >> 4;
+#ifdef EXL_ATTN_PROBE
+    unsigned long long ap_t[7];
+    const unsigned long long ap_t0 = __builtin_readcyclecounter();
+#endif
     const int past = *pos_dev;
     const int vis = past + 1;
     int L = (vis + nsplit - 1) / nsplit;
@@ -274,26 +286,32 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
     f16* kbase = kc + (size_t) kvh * max_seq * HD + d8 * 8;
     f16* vbase = vc + (size_t) kvh * max_seq * HD + d8 * 8;
 
+    AP_CLK(0);                                                       // position known
     // ---- every load of the first chunk up front: small ones first, then K rows, then V rows -------------------------
     const f16x8 sn = *(const f16x8*) (sin + (size_t) past * HD + d8 * 8);
     const f16x8 cs = *(const f16x8*) (cos + (size_t) past * HD + d8 * 8);
     const f16x8 qraw = *(const f16x8*) (q + (size_t) h * HD + d8 * 8);
     const f16x8 kraw = *(const f16x8*) (k_new + (size_t) kvh * HD + d8 * 8);
     const f16x8 vn = *(const f16x8*) (v_new + (size_t) kvh * HD + d8 * 8);
+    // K and V rows of the first chunk (the whole split up to 160 keys) go through registers with a ROLLING prefetch of
+    // DEC_ATT_AHEAD rows per thread: a wave that issues all 20 row loads at once sits in the issue queue until most of the
+    // data is back (the CU's memory queue is full) and only then starts on the scores; with a bounded number in flight the
+    // score of row u is computed while rows u + AHEAD .. stream in, and the V rows arrive during scores and softmax.
     f16x8 kv0[UN], vv0[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
+    auto load_k0 = [&](int u) {
         const int j = u * KPI + ks;
         kv0[u] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
         if (j < nkeys) kv0[u] = *(const f16x8*) (kbase + (size_t) (s0 + j) * HD);
-    }
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
+    };
+    auto load_v0 = [&](int u) {
         const int j = u * KPI + ks;
         vv0[u] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
         if (j < nkeys) vv0[u] = *(const f16x8*) (vbase + (size_t) (s0 + j) * HD);
-    }
-
+    };
+#pragma unroll
+    for (int u = 0; u < DEC_ATT_AHEAD; ++u) load_k0(u);
+    __builtin_amdgcn_sched_barrier(0);
+    AP_CLK(1);                                                       // loads issued
     // RoPE on q and on the new key: element d pairs with d +- 64, i.e. lane d8 with lane d8 ^ 8
     const bool left = d8 < 8;
     auto rope8 = [&](f16x8 own) {
@@ -321,25 +339,37 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
 #pragma unroll
     for (int j = 0; j < 8; ++j) qf[j] = (float) qr[j] * scale;
 
+    AP_CLK(2);                                                       // q / k / sin / cos landed, RoPE done
     // ---- scores ---------------------------------------------------------------------------------------------------
     float mx = -INFINITY;
-    auto score_chunk = [&](int j0, const f16x8 (&kv)[UN]) {
+    auto score_one = [&](int j0, int u, const f16x8& kv) {
+        const int j = j0 + u * KPI + ks;
+        const f16x8 kk = (s0 + j == past) ? kr : kv;                   // the new key never comes from memory
+        float dot = 0.f;
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int j = j0 + u * KPI + ks;
-            const f16x8 kk = (s0 + j == past) ? kr : kv[u];            // the new key never comes from memory
-            float dot = 0.f;
+        for (int e = 0; e < 8; ++e) dot = fmaf(qf[e], (float) kk[e], dot);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dot = fmaf(qf[e], (float) kk[e], dot);
-#pragma unroll
-            for (int off = 1; off < LPK; off <<= 1) dot += __shfl_xor(dot, off, 64);
-            if (j < nkeys) {
-                if (d8 == 0) sc[j] = dot;
-                mx = fmaxf(mx, dot);
-            }
+        for (int off = 1; off < LPK; off <<= 1) dot += __shfl_xor(dot, off, 64);
+        if (j < nkeys) {
+            if (d8 == 0) sc[j] = dot;
+            mx = fmaxf(mx, dot);
         }
     };
-    score_chunk(0, kv0);
+    auto score_chunk = [&](int j0, const f16x8 (&kv)[UN]) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) score_one(j0, u, kv[u]);
+    };
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {                                     // first chunk: row u + AHEAD of the K-then-V list is requested, row u scored
+        const int t = u + DEC_ATT_AHEAD;
+        if (t < UN) load_k0(t);
+        else if (t - UN < UN) load_v0(t - UN);
+        score_one(0, u, kv0[u]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int u = DEC_ATT_AHEAD; u < UN; ++u) load_v0(u);               // the rest of V streams in during the softmax
+    __builtin_amdgcn_sched_barrier(0);
     for (int j0 = KPI * UN; j0 < nkeys; j0 += KPI * UN) {
         f16x8 kv[UN];
 #pragma unroll
@@ -349,6 +379,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
         }
         score_chunk(j0, kv);
     }
+    AP_CLK(3);                                                       // K rows landed, scores done
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
     if ((tid & 63) == 0) stat[tid >> 6] = mx;
@@ -367,6 +398,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
     __syncthreads();
     lsum = stat[4] + stat[5] + stat[6] + stat[7];
 
+    AP_CLK(4);                                                       // softmax done
     // ---- P V ------------------------------------------------------------------------------------------------------
     float o[8];
 #pragma unroll
@@ -391,6 +423,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
         }
         pv_chunk(j0, vv);
     }
+    AP_CLK(5);                                                       // V rows landed, P V done
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[ks][d8 * 8 + e] = o[e];
     __syncthreads();
@@ -406,7 +439,26 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
         pp[HD] = nkeys > 0 ? mx : -INFINITY;
         pp[HD + 1] = nkeys > 0 ? lsum : 0.f;
     }
+    AP_CLK(6);                                                       // partials written
+#ifdef EXL_ATTN_PROBE
+    if (tid == 0 && blockIdx.x < 512) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) g_attn_probe[blockIdx.x * 8 + i] = ap_t[i] - ap_t0;
+        g_attn_probe[blockIdx.x * 8 + 7] = 1;
+    }
+#endif
 }
+#ifdef EXL_ATTN_PROBE
+extern "C" int exl_debug_attn_probe(unsigned long long* out8)         // sums over the blocks of the LAST launch; out8[7] = block count
+{
+    static unsigned long long h[512 * 8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_attn_probe), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    for (int b = 0; b < 512; ++b)
+        for (int i = 0; i < 8; ++i) out8[i] += h[b * 8 + i];
+    return 0;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // K2b: merge the split-KV partials of one head -> fp16 attention output (the value the reference's ATen attention

@@ -10,6 +10,9 @@
 #include <math.h>
 #include <vector>
 #include "exl_amd.h"
+#ifdef EXL_ATTN_PROBE
+extern "C" int exl_debug_attn_probe(unsigned long long* out8);
+#endif
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 #define EX(x) do { int r = (x); if (r) { printf("%s -> %d: %s\n", #x, r, exl_last_error()); exit(1); } } while (0)
@@ -114,6 +117,17 @@ int main(int argc, char** argv)
         float tms = 0;
         CK(hipEventElapsedTime(&tms, e0, e1));
         printf("ctx %5d  graph replay: %.4f ms/token = %.1f tokens/s (x%d layers)\n", p0, tms / reps, 1e3 * reps / tms, L);
+#ifdef EXL_ATTN_PROBE
+        {
+            unsigned long long pr[8];
+            if (exl_debug_attn_probe(pr) == 0 && pr[7]) {
+                static const char* ph[7] = {"pos known", "loads issued", "rope done", "scores done", "softmax done", "PV done", "end"};
+                printf("ctx %5d  attention kernel, mean cycles since block start over %llu blocks:", p0, pr[7]);
+                for (int i = 0; i < 7; ++i) printf("  %s %.0f", ph[i], (double) pr[i] / (double) pr[7]);
+                printf("\n");
+            }
+        }
+#endif
         CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
     }
     float l0[4];
