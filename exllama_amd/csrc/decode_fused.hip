@@ -69,9 +69,20 @@ __device__ __forceinline__ f16 silu_mul_f16(f16 x, f16 y)
 // only per-tile synchronisation is one barrier for the 8-way partial-sum reduction (double-buffered by tile parity).
 // Load order matters: the small L2-resident prologue loads (x, norm weight) are issued BEFORE the first weight loads
 // (loads return in order).
+// Phase attribution (probe builds only, scripts/probe_attn.sh): cycles since block start at 6 points, per kernel class.
+#ifdef EXL_ATTN_PROBE
+__device__ unsigned long long g_stream_probe[4 * 512 * 8];          // [class = PNORM * 2 + (EMODE == 2 ? 1 : EMODE)][block][point]
+#define SP_CLK(i) sp_t[i] = __builtin_readcyclecounter()
+#else
+#define SP_CLK(i) do { } while (0)
+#endif
 template <int U, int NP, bool G16, int PNORM, int EMODE, int NV>
 __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvArgs a)
 {
+#ifdef EXL_ATTN_PROBE
+    unsigned long long sp_t[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long sp_t0 = __builtin_readcyclecounter();
+#endif
     constexpr int NSLOT = G16 ? (U * NP + 3) / 4 : 1;
     constexpr int WPT = EMODE == 2 ? DEC_WAVES / 2 : DEC_WAVES;      // waves per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -131,6 +142,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
     if constexpr (EMODE == 1) { if (tid < 16) resA = (float) a.hid_io[tileA * 16 + tid]; }
     t16_unit_issue<U, G16>(a.mat[miA], uA, 0, rsub, wv0, ep0);
 
+    SP_CLK(0);                                                       // prologue loads + first weight batch issued
     // ---- 3. activation image (once per block) ---------------------------------------------------------------
     f16x8 xv[NV];
     if constexpr (PNORM == 1) {
@@ -183,6 +195,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
         __syncthreads();
     }
 
+    SP_CLK(1);                                                       // activation image staged
     // ---- 4. walk the tiles ----------------------------------------------------------------------------------
 #define DEC_BUF(k) (((k) & 1) ? wv1 : wv0)
 #define DEC_EP(k)  (((k) & 1) ? ep1 : ep0)
@@ -205,9 +218,11 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
             if (a.ablate) { _Pragma("unroll") for (int q = 0; q < U; ++q) c[0] += __builtin_bit_cast(float, DEC_BUF(P * NP + p)[q].x ^ DEC_BUF(P * NP + p)[q].w); } \
             else if (uC.rb0 + p * U < uC.rb1) t16_unit_consume<U, G16, NSLOT>(uC, p, lane, DEC_BUF(P * NP + p), entC, DEC_EP(P * NP + p), xrow, c); \
         }                                                                                                                   \
+        if (i == 0) SP_CLK(2);                                                                                              \
         float* rp = red + P * DEC_WAVES * 16;                                                                               \
         if (lane < 16) rp[wave * 16 + lane] = c[0];                                                                         \
         __syncthreads();                                                                                                    \
+        if (i == 0) SP_CLK(3);                                                                                              \
         if (tid < 16) {                                                                                                     \
             const int n = tileC * 16 + tid;                                                                                 \
             if constexpr (EMODE == 2) {                                                                                     \
@@ -226,6 +241,16 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
         DEC_UNIT_BODY(0, uA, miA, tileA, entA, resA, uB, miB, tileB, entB, resB)
         DEC_UNIT_BODY(1, uB, miB, tileB, entB, resB, uA, miA, tileA, entA, resA)
     }
+    SP_CLK(4);                                                       // all units done
+#ifdef EXL_ATTN_PROBE
+    if (tid == 0 && b < 512) {
+        unsigned long long* dst = g_stream_probe + ((size_t) (PNORM * 2 + (EMODE == 2 ? 1 : EMODE)) * 512 + b) * 8;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) dst[q] = sp_t[q] - sp_t0;
+        dst[5] = (unsigned long long) n_my;
+        dst[7] = 1;
+    }
+#endif
 #undef DEC_UNIT_BODY
 #undef DEC_BUF
 #undef DEC_EP
@@ -449,6 +474,15 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
 #endif
 }
 #ifdef EXL_ATTN_PROBE
+extern "C" int exl_debug_stream_probe(int cls, unsigned long long* out8)     // sums over blocks; out8[7] = block count, out8[5] = units
+{
+    static unsigned long long h[512 * 8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stream_probe), sizeof(h), (size_t) cls * sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    for (int b = 0; b < 512; ++b)
+        for (int i = 0; i < 8; ++i) out8[i] += h[b * 8 + i];
+    return 0;
+}
 extern "C" int exl_debug_attn_probe(unsigned long long* out8)         // sums over the blocks of the LAST launch; out8[7] = block count
 {
     static unsigned long long h[512 * 8];

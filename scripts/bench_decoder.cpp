@@ -12,6 +12,7 @@
 #include "exl_amd.h"
 #ifdef EXL_ATTN_PROBE
 extern "C" int exl_debug_attn_probe(unsigned long long* out8);
+extern "C" int exl_debug_stream_probe(int cls, unsigned long long* out8);
 #endif
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
@@ -125,6 +126,12 @@ int main(int argc, char** argv)
                 printf("ctx %5d  attention kernel, mean cycles since block start over %llu blocks:", p0, pr[7]);
                 for (int i = 0; i < 7; ++i) printf("  %s %.0f", ph[i], (double) pr[i] / (double) pr[7]);
                 printf("\n");
+            }
+            static const char* cn[4] = {"o_proj/down (the LAST launched: down)", "-", "qkv", "gate_up"};
+            for (int cls = 0; cls < 4; ++cls) {
+                if (exl_debug_stream_probe(cls, pr) != 0 || !pr[7]) continue;
+                printf("ctx %5d  stream kernel class %d [%s], mean cycles over %llu blocks (%.2f units/block): loads issued %.0f  image staged %.0f  unit 0 consumed %.0f  unit 0 reduced %.0f  all units done %.0f\n",
+                       p0, cls, cn[cls], pr[7], (double) pr[5] / pr[7], (double) pr[0] / pr[7], (double) pr[1] / pr[7], (double) pr[2] / pr[7], (double) pr[3] / pr[7], (double) pr[4] / pr[7]);
             }
         }
 #endif
