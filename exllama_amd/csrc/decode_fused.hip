@@ -1,5 +1,5 @@
 // Native single-token decode executor: one C call (capturable into one hipGraph) runs a whole Llama token step
-// as 6 kernels per layer + 1 head kernel, instead of the ~20 launches per layer of the op-by-op path.
+// as 5 kernels per layer + 1 head kernel, instead of the ~20 launches per layer of the op-by-op path.
 //
 // It is the MI355X answer to the reference's decode loop (/root/reference/model.py:1053-1058 driving
 // q4_attn -> ATen attention -> q4_attn_2 -> q4_mlp, i.e. q4_attn.cu:74-228 + q4_mlp.cu:100-199 + model.py:376-409):
@@ -9,9 +9,10 @@
 //   K1 qkv      RMSNorm(hid) [layer 0: the embedding row] staged in LDS; q, k, v projections as ONE launch over the
 //               three matrices -> fp16 q/k/v
 //   K2 attn     RoPE(q), RoPE(k_new) in registers, k_new/v_new appended to the cache, split-KV attention over the
-//               cache -> fp32 partials (o, m, l) per (head, split)
-//   K2b merge   log-sum-exp merge of the partials -> fp16 attention output
-//   K3 o_proj   hid += attn_out @ Wo      (residual added in the epilogue, fp16 residual stream updated in place)
+//               cache -> per (head, split): its own fp16 attention output + fp32 (max, sum); one split: the output itself
+//   K3 o_proj   log-sum-exp merge of the splits while the activation image is built (a kernel boundary costs more than
+//               the merge: the stand-alone K2b kernel is kept behind EXL_DEC_SEPARATE_MERGE as the A/B reference), then
+//               hid += attn_out @ Wo   (residual added in the epilogue, fp16 residual stream updated in place)
 //   K4 gate_up  RMSNorm(hid); one block computes the SAME 16 columns of gate and up -> act = silu(gate) * up (fp16)
 //   K5 down     hid += act @ Wdown
 //   K6 head     final RMSNorm; fp16 lm_head GEMV -> fp32 logits; advances the device-side position
@@ -25,6 +26,7 @@
 #include <stdlib.h>
 
 #define DEC_MAX_MATS 3
+#define DEC_MAX_NSPLIT 16
 #define DEC_ATT_MAX_KEYS 1024
 #define DEC_WAVES 8
 #define DEC_THREADS (DEC_WAVES * 64)
@@ -38,6 +40,8 @@ struct DecGemvArgs {
     const f16* norm_w;            // PNORM 1
     float eps;
     f16* hid_copy;                // PNORM 1 with tok: block 0 stores the embedding row here (start of the residual stream)
+    const float* att_ml;          // PNORM 3: (max, sum) of every (head, split) of the attention kernel; vec = their fp16 outputs
+    int att_nsplit;               // PNORM 3
     // ---- matrices; 16-column tiles are numbered across them in order ----
     int nmat;
     T16Matrix mat[DEC_MAX_MATS];
@@ -122,12 +126,23 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
     const f16* src = a.vec;
     if constexpr (PNORM == 1) { if (a.tok) src = a.vec + (size_t) (*a.tok) * K; }
     uint4 xraw[NV], wraw[NV];
+    constexpr int MS = PNORM == 3 ? DEC_MAX_NSPLIT : 1;
+    uint4 praw[NV][MS];                                              // PNORM 3: this thread's 8 dims of every split's output
+    float2 pml[NV];                                                  //          (max, sum) of split lane & 15 of this thread's head
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = tid + i * DEC_THREADS;
         const int ci = idx < nvec ? idx : 0;
-        xraw[i] = *(const uint4*) (src + ci * 8);
-        if constexpr (PNORM == 1) wraw[i] = *(const uint4*) (a.norm_w + ci * 8);
+        if constexpr (PNORM == 3) {
+            const int hd = ci >> 4, sp = lane & 15;                  // 16 consecutive 8-dim vectors = one head
+            pml[i] = sp < a.att_nsplit ? *(const float2*) (a.att_ml + ((size_t) hd * a.att_nsplit + sp) * 2) : make_float2(-INFINITY, 0.f);
+#pragma unroll
+            for (int sp2 = 0; sp2 < MS; ++sp2)
+                praw[i][sp2] = sp2 < a.att_nsplit ? *(const uint4*) (src + ((size_t) hd * a.att_nsplit + sp2) * 128 + (ci & 15) * 8) : make_uint4(0, 0, 0, 0);
+        } else {
+            xraw[i] = *(const uint4*) (src + ci * 8);
+            if constexpr (PNORM == 1) wraw[i] = *(const uint4*) (a.norm_w + ci * 8);
+        }
     }
     // ---- 2. first unit's weight stream ----------------------------------------------------------------------
     uint4 wv0[U], wv1[U];
@@ -170,6 +185,30 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
             const f16x8 nw = __builtin_bit_cast(f16x8, wraw[i]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const f16 t = xv[i][j] * rm; xv[i][j] = t * nw[j]; }
+        }
+    } else if constexpr (PNORM == 3) {
+        // log-sum-exp merge of the attention splits (what the stand-alone dec_attn_merge_kernel does), per head inside its
+        // 16-lane group: lane s holds (m_s, l_s); coefficient of split s = l_s e^(m_s - M) / sum of those
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float M = pml[i].x;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
+            const float lw = pml[i].x > -INFINITY ? pml[i].y * __expf(pml[i].x - M) : 0.f;
+            float L = lw;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) L += __shfl_xor(L, off, 64);
+            const float coef = lw / L;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sp2 = 0; sp2 < MS; ++sp2) {
+                const float cf = __shfl(coef, sp2, 16);
+                const f16x8 o8 = __builtin_bit_cast(f16x8, praw[i][sp2]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf((float) o8[j], cf, acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[i][j] = (f16) acc[j];
         }
     } else {
 #pragma unroll
@@ -452,17 +491,21 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[ks][d8 * 8 + e] = o[e];
     __syncthreads();
-    float* pp = partial + ((size_t) h * nsplit + split) * (HD + 2);
+    // Several splits: each writes its OWN attention output (normalised by its own sum: a convex combination of V rows,
+    // safe in fp16) plus (max, sum); the o_proj kernel combines them while it builds its activation image.
+    f16* po = (f16*) partial + ((size_t) h * nsplit + split) * HD;
+    float* pml = partial + (size_t) heads * nsplit * (HD / 2) + ((size_t) h * nsplit + split) * 2;
     if (tid < HD) {
         float v = 0.f;
 #pragma unroll
         for (int s = 0; s < KPI; ++s) v += red[s][tid];
-        if (direct_out) direct_out[h * HD + tid] = (f16) (v / lsum);   // a single split: this IS the attention output
-        else pp[tid] = v;
+        const f16 r = (f16) (nkeys > 0 ? v / lsum : 0.f);
+        if (direct_out) direct_out[h * HD + tid] = r;                   // a single split: this IS the attention output
+        else po[tid] = r;
     }
     if (tid == 0 && !direct_out) {
-        pp[HD] = nkeys > 0 ? mx : -INFINITY;
-        pp[HD + 1] = nkeys > 0 ? lsum : 0.f;
+        pml[0] = nkeys > 0 ? mx : -INFINITY;
+        pml[1] = nkeys > 0 ? lsum : 0.f;
     }
     AP_CLK(6);                                                       // partials written
 #ifdef EXL_ATTN_PROBE
@@ -498,31 +541,20 @@ extern "C" int exl_debug_attn_probe(unsigned long long* out8)         // sums ov
 // K2b: merge the split-KV partials of one head -> fp16 attention output (the value the reference's ATen attention
 // rounds to fp16 before o_proj, model.py:407-409)
 // ---------------------------------------------------------------------------------------------------------------
-#define DEC_MAX_NSPLIT 16
-__global__ __launch_bounds__(128) void dec_attn_merge_kernel(const float* __restrict__ partial, f16* __restrict__ out, int nsplit)
+__global__ __launch_bounds__(128) void dec_attn_merge_kernel(const float* __restrict__ partial, f16* __restrict__ out, int nsplit, int heads)
 {
     const int h = blockIdx.x, d = threadIdx.x;
-    const float* pp = partial + (size_t) h * nsplit * 130;
-    // every load up front, no data-dependent control flow: one L2 round trip instead of 2 * nsplit
-    float ms[DEC_MAX_NSPLIT], ls[DEC_MAX_NSPLIT], os[DEC_MAX_NSPLIT];
-#pragma unroll
-    for (int s = 0; s < DEC_MAX_NSPLIT; ++s) {
-        const int cs = s < nsplit ? s : 0;
-        ms[s] = pp[cs * 130 + 128];
-        ls[s] = pp[cs * 130 + 129];
-        os[s] = pp[cs * 130 + d];
-    }
+    const f16* po = (const f16*) partial + (size_t) h * nsplit * 128;
+    const float* pml = partial + (size_t) heads * nsplit * 64 + (size_t) h * nsplit * 2;
     float M = -INFINITY;
-#pragma unroll
-    for (int s = 0; s < DEC_MAX_NSPLIT; ++s) if (s < nsplit) M = fmaxf(M, ms[s]);
-    float l = 0.f, o = 0.f;
-#pragma unroll
-    for (int s = 0; s < DEC_MAX_NSPLIT; ++s) {
-        const float w = (s < nsplit && ms[s] > -INFINITY) ? __expf(ms[s] - M) : 0.f;
-        l = fmaf(ls[s], w, l);
-        o = fmaf(os[s], w, o);
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pml[2 * s]);
+    float L = 0.f, o = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float w = pml[2 * s] > -INFINITY ? pml[2 * s + 1] * __expf(pml[2 * s] - M) : 0.f;
+        L += w;
+        o = fmaf((float) po[s * 128 + d], w, o);
     }
-    out[h * 128 + d] = (f16) (o / l);
+    out[h * 128 + d] = (f16) (o / L);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -636,6 +668,7 @@ struct Decoder {
     std::vector<DecLayer> layers;
     f16 *hid, *qbuf, *kbuf, *vbuf, *attn_out, *act;
     float* partial;
+    bool separate_merge;          // EXL_DEC_SEPARATE_MERGE: run the split merge as its own kernel (A/B switch)
     int nsplit;                   // KV splits of the attention kernel in use (<= nsplit_max)
     int nsplit_max;
     int max_blocks;               // persistent GEMV grid: blocks per CU x CUs
@@ -689,6 +722,7 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     d->hid = (f16*) (b + o_hid); d->qbuf = (f16*) (b + o_q);
     d->kbuf = (f16*) (b + o_k); d->vbuf = (f16*) (b + o_v); d->attn_out = (f16*) (b + o_ao); d->act = (f16*) (b + o_act);
     d->partial = (float*) (b + o_p);
+    d->separate_merge = getenv("EXL_DEC_SEPARATE_MERGE") != nullptr;
     int bpc = 2;
     if (const char* env = getenv("EXL_DEC_BLOCKS_PER_CU")) { bpc = atoi(env); if (bpc < 1) bpc = 1; if (bpc > 4) bpc = 4; }
     d->max_blocks = (cus > 0 ? cus : 256) * bpc;
@@ -780,10 +814,12 @@ static int launch_dec_gemv_cfg(bool g16, int rbw, dim3 grid, size_t smem, hipStr
 
 // pnorm / emode as in dec_gemv_kernel.  mats: nmat matrices sharing K (emode 2: gate, up).
 static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec, const int64_t* tok, const f16* norm_w, float eps, f16* hid_copy,
-                           int nmat, Q4Matrix* const* mats, f16* const* outs, f16* hid_io, hipStream_t s)
+                           int nmat, Q4Matrix* const* mats, f16* const* outs, f16* hid_io, hipStream_t s,
+                           const float* att_ml = nullptr, int att_nsplit = 0)
 {
     DecGemvArgs a;
     a.vec = vec; a.tok = tok; a.norm_w = norm_w; a.eps = eps; a.hid_copy = hid_copy; a.nmat = nmat; a.hid_io = hid_io;
+    a.att_ml = att_ml; a.att_nsplit = att_nsplit;
     int tiles = 0;
     bool any_map = false;
     for (int i = 0; i < DEC_MAX_MATS; ++i) {
@@ -821,6 +857,7 @@ static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec,
     if (pnorm == 1 && emode == 0) return DEC_NV(1, 0);
     if (pnorm == 1 && emode == 2) return DEC_NV(1, 2);
     if (pnorm == 0 && emode == 1) return DEC_NV(0, 1);
+    if (pnorm == 3 && emode == 1) return DEC_NV(3, 1);
 #undef DEC_NV
     EXL_FAIL(EXL_E_INVALID, "decoder: unsupported kernel combination");
 }
@@ -846,12 +883,16 @@ static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int3
         EXL_LAUNCH_CHECK();
         return 0;
     case EXL_DEC_MERGE:
-        if (d->nsplit == 1) return 0;                                // the attention kernel wrote the output itself
-        hipLaunchKernelGGL(dec_attn_merge_kernel, dim3(d->heads), dim3(128), 0, s, d->partial, d->attn_out, d->nsplit);
+        // the split merge runs inside the o_proj kernel's prologue (PNORM 3); the stand-alone kernel is the A/B reference
+        if (d->nsplit == 1 || !d->separate_merge) return 0;
+        hipLaunchKernelGGL(dec_attn_merge_kernel, dim3(d->heads), dim3(128), 0, s, d->partial, d->attn_out, d->nsplit, d->heads);
         EXL_LAUNCH_CHECK();
         return 0;
     case EXL_DEC_O: {
         Q4Matrix* om[1] = {l.o};
+        if (d->nsplit > 1 && !d->separate_merge)
+            return launch_dec_gemv(d->max_blocks, 3, 1, (const f16*) d->partial, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s,
+                                   d->partial + (size_t) d->heads * d->nsplit * 64, d->nsplit);
         return launch_dec_gemv(d->max_blocks, 0, 1, d->attn_out, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s);
     }
     case EXL_DEC_GATE_UP: {

@@ -666,12 +666,12 @@ class ExLlama:
             st["pos"].fill_(start)
             self._decoder_launch(st, advance=0)                 # eager dry run with the full split count (the K/V written
             torch.cuda.synchronize(dev)                          # at the current slot are overwritten by the real token later)
-            for ns in (1, 4, 0):                                # 0 = the decoder's maximum
+            for ns, bucket_limit in self.DECODE_BUCKETS:
                 lim = C.c_int()
                 rc = lib.exl_decoder_set_kv_splits(handle, ns, C.byref(lim))
                 if rc != 0:
                     continue                                    # more splits than this decoder has: covered by the last bucket
-                limit = min(lim.value, {1: 160, 4: 640}.get(ns, lim.value))
+                limit = lim.value if bucket_limit is None else min(lim.value, bucket_limit)
                 if st["graphs"] and limit <= st["graphs"][-1][0]:
                     continue
                 g = torch.cuda.CUDAGraph()
@@ -682,6 +682,19 @@ class ExLlama:
             st["graph"] = st["graphs"][-1][1]
             st["pos"].fill_(start)
             st["dev_pos"] = start
+
+    DECODE_BUCKETS = ((1, 160), (4, 640), (0, None))                 # (KV splits, last context served); 0 = the decoder's maximum
+
+    def _set_eager_splits(self, st, position):
+        """Eager (non-graph) launches pick the KV split count per step by the bucket table the graphs are captured with."""
+        import ctypes as C
+        for ns, limit in self.DECODE_BUCKETS:
+            lim = C.c_int()
+            if ext._lib.exl_decoder_set_kv_splits(st["handle"], ns, C.byref(lim)) != 0:
+                continue                                            # more splits than this decoder has
+            if position <= (lim.value if limit is None else min(limit, lim.value)):
+                return
+        raise RuntimeError(f"position {position} beyond the decoder's context limit")
 
     def _decoder_launch(self, st, advance):
         with cuda_ext._Guard(st["dev"]):
@@ -704,6 +717,7 @@ class ExLlama:
             else:
                 raise RuntimeError(f"position {cache.current_seq_len} beyond the decoder's context limit")
         else:
+            self._set_eager_splits(st, cache.current_seq_len)       # same split policy as the captured buckets
             self._decoder_launch(st, advance=1)
         cache.current_seq_len += 1
         st["dev_pos"] = cache.current_seq_len

@@ -143,13 +143,15 @@ def test_7b_layer_shapes_finite_and_consistent():
     model.free_unmanaged()
 
 
-@pytest.mark.parametrize("name,gs,act", [("tiny_hd128", 128, False), ("tiny_hd128_gqa", 64, True)])
-def test_native_decode_executor_matches_op_path_and_oracle(name, gs, act):
+@pytest.mark.parametrize("name,gs,act,prompt,max_seq", [("tiny_hd128", 128, False, 20, 96), ("tiny_hd128_gqa", 64, True, 20, 96),
+                                                        ("tiny_hd128", 128, False, 200, 320), ("tiny_hd128_gqa", 64, True, 700, 1024)])
+def test_native_decode_executor_matches_op_path_and_oracle(name, gs, act, prompt, max_seq):
     """The native decode executor (decode_fused.hip), eager and as a replayed hipGraph, against (a) the
-    op-by-op fused path (q4_attn -> attention -> q4_attn_2 -> q4_mlp) and (b) the CPU oracle model."""
+    op-by-op fused path (q4_attn -> attention -> q4_attn_2 -> q4_mlp) and (b) the CPU oracle model.  Prompts of 20 / 200 /
+    700 tokens put the decode steps into the 1- / 4- / 16-split buckets (several splits: merged inside the o_proj kernel)."""
     from exllama_amd.model import ExLlamaCache
-    model, cache, tensors, dims = _build(name, gs, act, seed=21, max_seq_len=96)
-    ids = torch.randint(1, dims.vocab_size, (1, 20), generator=torch.Generator().manual_seed(4)).to("cuda:0")
+    model, cache, tensors, dims = _build(name, gs, act, seed=21, max_seq_len=max_seq)
+    ids = torch.randint(1, dims.vocab_size, (1, prompt), generator=torch.Generator().manual_seed(4)).to("cuda:0")
     n_new = 12
 
     def run(mode, forced=None):
@@ -167,7 +169,7 @@ def test_native_decode_executor_matches_op_path_and_oracle(name, gs, act):
             tok = torch.tensor([[forced[i] if forced is not None else own]], device="cuda:0")
             logits = model.forward(tok, c)
             outs.append(logits[0, 0].float().cpu())
-        assert c.current_seq_len == 20 + n_new
+        assert c.current_seq_len == prompt + n_new
         return torch.stack(outs), toks, c
 
     ops, toks_ops, c_ops = run("ops")
@@ -181,16 +183,15 @@ def test_native_decode_executor_matches_op_path_and_oracle(name, gs, act):
     top2 = prev.topk(2, dim=-1).values
     clear = (top2[:, 0] - top2[:, 1]) > 4e-2 * scale
     assert all(a == b for a, b, ok in zip(toks_eager, toks_ops, clear.tolist()) if ok)
-    # the replayed graphs pick their KV-split count by context bucket (1 split here), the eager launches use the decoder's
-    # maximum: same arithmetic, different summation order of the attention partials
+    # replayed graphs and eager launches pick their KV-split count from the same context buckets: the same kernels
     assert (graph - eager).abs().max().item() <= 2e-3 * scale
     graph2, toks_graph2, _ = run("graph", forced=toks_ops)
     assert torch.equal(graph, graph2) and toks_graph == toks_graph2         # bit-reproducible run to run
     for l in range(len(c_ops.key_states)):
-        ka, kb = c_ops.key_states[l][:, :, :32].float(), c_graph.key_states[l][:, :, :32].float()
+        ka, kb = c_ops.key_states[l][:, :, :prompt + n_new].float(), c_graph.key_states[l][:, :, :prompt + n_new].float()
         assert (ka - kb).abs().max().item() <= 2e-2 * ka.abs().max().item()
     # oracle model on the same tokens
-    ref = OracleLlama(synth.config_dict(dims), tensors, max_seq_len=96)
+    ref = OracleLlama(synth.config_dict(dims), tensors, max_seq_len=max_seq)
     rl = ref.forward(ids.cpu().numpy())
     ref_steps = []
     for t in toks_ops:
@@ -199,7 +200,7 @@ def test_native_decode_executor_matches_op_path_and_oracle(name, gs, act):
     assert np.abs(graph.numpy() - ref_steps).max() <= 2e-2 * np.abs(ref_steps).max()
     # rewinding the cache on the host is picked up by the device-side position
     model.enable_decode_graph(c_graph, use_graph=True)
-    c_graph.current_seq_len = 20
+    c_graph.current_seq_len = prompt
     again = model.forward(torch.tensor([[toks_ops[0]]], device="cuda:0"), c_graph)[0, 0].float().cpu()
     assert torch.equal(again, graph[0])
     model.free_unmanaged()
