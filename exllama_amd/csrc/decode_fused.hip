@@ -563,7 +563,7 @@ __global__ __launch_bounds__(128) void dec_attn_merge_kernel(const float* __rest
 __global__ __launch_bounds__(256) void dec_head_kernel(const f16* __restrict__ hid, const f16* __restrict__ norm_w, float eps, int h,
                                                        const f16* __restrict__ lm_head, int vocab,
                                                        float* __restrict__ logits, int rows_per_block,
-                                                       int32_t* __restrict__ pos_dev, int advance)
+                                                       int32_t* __restrict__ pos_dev, int advance, float2* __restrict__ blk_best)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f16* xlin = (f16*) smem;
@@ -594,6 +594,8 @@ __global__ __launch_bounds__(256) void dec_head_kernel(const f16* __restrict__ h
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
     const int row0 = blockIdx.x * rows_per_block;
+    float best = -INFINITY;                                          // this wave's largest logit and its row (greedy generation)
+    int best_row = 0x7fffffff;
     for (int r = wave; r < rows_per_block; r += 4) {
         const int row = row0 + r;
         if (row >= vocab) break;
@@ -609,18 +611,34 @@ __global__ __launch_bounds__(256) void dec_head_kernel(const f16* __restrict__ h
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        if (lane == 0) logits[row] = (float) (f16) acc;        // nn.Linear in fp16, then .float() (model.py:1077-1080)
+        const float lg = (float) (f16) acc;                     // nn.Linear in fp16, then .float() (model.py:1077-1080)
+        if (lane == 0) logits[row] = lg;
+        if (lg > best) { best = lg; best_row = row; }           // rows ascend: the lowest index wins a tie
+    }
+    if (blk_best) {
+        __syncthreads();                                       // red4 (norm statistics) is free again
+        if (lane == 0) { red4[wave] = best; red4[4 + wave] = __builtin_bit_cast(float, best_row); }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const int ir = __builtin_bit_cast(int, red4[4 + w]);
+                if (red4[w] > best || (red4[w] == best && ir < best_row)) { best = red4[w]; best_row = ir; }
+            }
+            blk_best[blockIdx.x] = make_float2(best, __builtin_bit_cast(float, best_row));
+        }
     }
     if (advance && blockIdx.x == 0 && tid == 0) *pos_dev += 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // K7 (greedy generation only): argmax of the logits -> the next token, written where the next step reads its input and
-// into history[position of that token].  Lowest index wins ties; NaNs never win.  One block: 128 KB of logits.
+// into history[position of that token].  Lowest index wins ties; NaNs never win.  The head kernel leaves (largest logit,
+// row) per block, so this kernel only scans ~1000 candidates (scanning the 128 KB of logits from one block took 14 us).
 // Replaces the host-driven torch.argmax + two small copies per token of the reference's loop
 // (test_benchmark_inference.py:188-191).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void dec_argmax_kernel(const float* __restrict__ logits, int vocab, int64_t* __restrict__ token_io,
+__global__ __launch_bounds__(1024) void dec_argmax_kernel(const float2* __restrict__ blk_best, int nblk, int64_t* __restrict__ token_io,
                                                           int64_t* __restrict__ history, const int32_t* __restrict__ pos_dev)
 {
     __shared__ float bv[16];
@@ -628,9 +646,10 @@ __global__ __launch_bounds__(1024) void dec_argmax_kernel(const float* __restric
     const int tid = threadIdx.x;
     float best = -INFINITY;
     int idx = 0x7fffffff;
-    for (int i = tid; i < vocab; i += 1024) {
-        const float v = logits[i];
-        if (v > best || (v == best && i < idx)) { best = v; idx = i; }
+    for (int i = tid; i < nblk; i += 1024) {                             // (largest logit, its row) of every head-kernel block
+        const float2 e = blk_best[i];
+        const int ei = __builtin_bit_cast(int, e.y);
+        if (e.x > best || (e.x == best && ei < idx)) { best = e.x; idx = ei; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -668,6 +687,7 @@ struct Decoder {
     std::vector<DecLayer> layers;
     f16 *hid, *qbuf, *kbuf, *vbuf, *attn_out, *act;
     float* partial;
+    float2* head_best;            // (largest logit, row) per head-kernel block, for exl_decoder_step_greedy
     bool separate_merge;          // EXL_DEC_SEPARATE_MERGE: run the split merge as its own kernel (A/B switch)
     int nsplit;                   // KV splits of the attention kernel in use (<= nsplit_max)
     int nsplit_max;
@@ -710,6 +730,7 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     const size_t o_k = carve((size_t) kvd * 2), o_v = carve((size_t) kvd * 2);
     const size_t o_ao = carve((size_t) hidden * 2), o_act = carve((size_t) inter * 2);
     const size_t o_p = carve((size_t) heads * ns * 130 * 4);
+    const size_t o_hb = carve((size_t) ((vocab + 31) / 32) * sizeof(float2));
     int prev = 0;
     hipError_t e = hipGetDevice(&prev);
     if (e == hipSuccess) e = hipSetDevice(device);
@@ -722,6 +743,7 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     d->hid = (f16*) (b + o_hid); d->qbuf = (f16*) (b + o_q);
     d->kbuf = (f16*) (b + o_k); d->vbuf = (f16*) (b + o_v); d->attn_out = (f16*) (b + o_ao); d->act = (f16*) (b + o_act);
     d->partial = (float*) (b + o_p);
+    d->head_best = (float2*) (b + o_hb);
     d->separate_merge = getenv("EXL_DEC_SEPARATE_MERGE") != nullptr;
     int bpc = 2;
     if (const char* env = getenv("EXL_DEC_BLOCKS_PER_CU")) { bpc = atoi(env); if (bpc < 1) bpc = 1; if (bpc > 4) bpc = 4; }
@@ -909,7 +931,7 @@ static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int3
         const int blocks = (d->vocab + rows_per_block - 1) / rows_per_block;
         const size_t smem = (size_t) d->h * 2 + 8 * sizeof(float);
         hipLaunchKernelGGL(dec_head_kernel, dim3(blocks), dim3(256), smem, s, d->hid, d->final_norm, d->eps, d->h, d->lm_head,
-                           d->vocab, logits_out, rows_per_block, pos_dev, advance);
+                           d->vocab, logits_out, rows_per_block, pos_dev, advance, d->head_best);
         EXL_LAUNCH_CHECK();
         return 0;
     }
@@ -947,7 +969,7 @@ extern "C" int exl_decoder_step_greedy(void* dec, int64_t* token_io_dev, int32_t
     int prev = 0;
     EXL_HIP(hipGetDevice(&prev));
     if (prev != d->device) EXL_HIP(hipSetDevice(d->device));
-    hipLaunchKernelGGL(dec_argmax_kernel, dim3(1), dim3(1024), 0, (hipStream_t) stream, logits_out, d->vocab, token_io_dev, history_dev, pos_dev);
+    hipLaunchKernelGGL(dec_argmax_kernel, dim3(1), dim3(1024), 0, (hipStream_t) stream, d->head_best, (d->vocab + 31) / 32, token_io_dev, history_dev, pos_dev);
     const hipError_t e = hipGetLastError();
     if (prev != d->device) (void) hipSetDevice(prev);
     if (e != hipSuccess) EXL_FAIL((int) e, "decoder_step_greedy: %s", hipGetErrorString(e));
