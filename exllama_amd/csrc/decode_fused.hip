@@ -127,19 +127,25 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
     if constexpr (PNORM == 1) { if (a.tok) src = a.vec + (size_t) (*a.tok) * K; }
     uint4 xraw[NV], wraw[NV];
     constexpr int MS = PNORM == 3 ? DEC_MAX_NSPLIT : 1;
-    uint4 praw[NV][MS];                                              // PNORM 3: this thread's 8 dims of every split's output
-    float2 pml[NV];                                                  //          (max, sum) of split lane & 15 of this thread's head
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
+    uint4 praw[MS];                                                  // PNORM 3: this thread's 8 dims of every split's output (one vector at a time)
+    float2 pml = make_float2(-INFINITY, 0.f);                        //          (max, sum) of split lane & 15 of this thread's head
+    auto load_splits = [&](int i) {                                  // 16 consecutive 8-dim vectors = one head
         const int idx = tid + i * DEC_THREADS;
         const int ci = idx < nvec ? idx : 0;
-        if constexpr (PNORM == 3) {
-            const int hd = ci >> 4, sp = lane & 15;                  // 16 consecutive 8-dim vectors = one head
-            pml[i] = sp < a.att_nsplit ? *(const float2*) (a.att_ml + ((size_t) hd * a.att_nsplit + sp) * 2) : make_float2(-INFINITY, 0.f);
+        const int hd = ci >> 4, sp = lane & 15;
+        pml = sp < a.att_nsplit ? *(const float2*) (a.att_ml + ((size_t) hd * a.att_nsplit + sp) * 2) : make_float2(-INFINITY, 0.f);
+        // one per-lane base + uniform offsets (splits beyond nsplit re-read the last one: their coefficient is 0)
+        const uint4* base = (const uint4*) (src + (size_t) hd * a.att_nsplit * 128 + (ci & 15) * 8);
 #pragma unroll
-            for (int sp2 = 0; sp2 < MS; ++sp2)
-                praw[i][sp2] = sp2 < a.att_nsplit ? *(const uint4*) (src + ((size_t) hd * a.att_nsplit + sp2) * 128 + (ci & 15) * 8) : make_uint4(0, 0, 0, 0);
-        } else {
+        for (int sp2 = 0; sp2 < MS; ++sp2) praw[sp2] = base[min(sp2, a.att_nsplit - 1) * 16];
+    };
+    if constexpr (PNORM == 3) {
+        load_splits(0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * DEC_THREADS;
+            const int ci = idx < nvec ? idx : 0;
             xraw[i] = *(const uint4*) (src + ci * 8);
             if constexpr (PNORM == 1) wraw[i] = *(const uint4*) (a.norm_w + ci * 8);
         }
@@ -188,13 +194,14 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
         }
     } else if constexpr (PNORM == 3) {
         // log-sum-exp merge of the attention splits (what the stand-alone dec_attn_merge_kernel does), per head inside its
-        // 16-lane group: lane s holds (m_s, l_s); coefficient of split s = l_s e^(m_s - M) / sum of those
+        // 16-lane group: lane s holds (m_s, l_s); coefficient of split s = l_s e^(m_s - M) / sum of those.  One 8-dim vector
+        // at a time: 16 x 16 bytes of split outputs per thread are the register budget (hidden > 4096: 2 vectors per thread).
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            float M = pml[i].x;
+            float M = pml.x;
 #pragma unroll
             for (int off = 1; off < 16; off <<= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
-            const float lw = pml[i].x > -INFINITY ? pml[i].y * __expf(pml[i].x - M) : 0.f;
+            const float lw = pml.x > -INFINITY ? pml.y * __expf(pml.x - M) : 0.f;
             float L = lw;
 #pragma unroll
             for (int off = 1; off < 16; off <<= 1) L += __shfl_xor(L, off, 64);
@@ -203,12 +210,13 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
 #pragma unroll
             for (int sp2 = 0; sp2 < MS; ++sp2) {
                 const float cf = __shfl(coef, sp2, 16);
-                const f16x8 o8 = __builtin_bit_cast(f16x8, praw[i][sp2]);
+                const f16x8 o8 = __builtin_bit_cast(f16x8, praw[sp2]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] = fmaf((float) o8[j], cf, acc[j]);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) xv[i][j] = (f16) acc[j];
+            if (i + 1 < NV) { asm volatile("" ::: "memory"); load_splits(i + 1); asm volatile("" ::: "memory"); }   // not hoisted above the merge of vector i
         }
     } else {
 #pragma unroll
@@ -545,14 +553,25 @@ __global__ __launch_bounds__(128) void dec_attn_merge_kernel(const float* __rest
 {
     const int h = blockIdx.x, d = threadIdx.x;
     const f16* po = (const f16*) partial + (size_t) h * nsplit * 128;
-    const float* pml = partial + (size_t) heads * nsplit * 64 + (size_t) h * nsplit * 2;
+    const float2* pml = (const float2*) (partial + (size_t) heads * nsplit * 64) + (size_t) h * nsplit;
+    // every load up front, no data-dependent control flow: one memory round trip
+    float2 ml[DEC_MAX_NSPLIT];
+    f16 os[DEC_MAX_NSPLIT];
+#pragma unroll
+    for (int s = 0; s < DEC_MAX_NSPLIT; ++s) {
+        const int cs = s < nsplit ? s : 0;
+        ml[s] = pml[cs];
+        os[s] = po[cs * 128 + d];
+    }
     float M = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pml[2 * s]);
+#pragma unroll
+    for (int s = 0; s < DEC_MAX_NSPLIT; ++s) if (s < nsplit) M = fmaxf(M, ml[s].x);
     float L = 0.f, o = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float w = pml[2 * s] > -INFINITY ? pml[2 * s + 1] * __expf(pml[2 * s] - M) : 0.f;
+#pragma unroll
+    for (int s = 0; s < DEC_MAX_NSPLIT; ++s) {
+        const float w = (s < nsplit && ml[s].x > -INFINITY) ? ml[s].y * __expf(ml[s].x - M) : 0.f;
         L += w;
-        o = fmaf((float) po[s * 128 + d], w, o);
+        o = fmaf((float) os[s], w, o);
     }
     out[h * 128 + d] = (f16) (o / L);
 }
@@ -884,6 +903,12 @@ static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec,
     EXL_FAIL(EXL_E_INVALID, "decoder: unsupported kernel combination");
 }
 
+// The split merge rides in the o_proj prologue when a thread owns ONE 8-dim vector of the attention output (hidden <= 4096:
+// 16 split loads = 64 registers); wider models keep it as its own kernel (with 2+ vectors per thread hipcc keeps every
+// vector's loads live and o_proj, which needs two blocks per CU from hidden 5120 on, drops to one: measured 13B 204 -> 177
+// tokens/s), where the boundary is also a smaller share of the layer.
+static bool dec_folds_merge(const Decoder* d) { return !d->separate_merge && d->h <= DEC_THREADS * 8; }
+
 // One kernel class of one layer (EXL_DEC_* in include/exl_amd.h); EXL_DEC_HEAD ignores `i`.
 static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int32_t* pos_dev, float* logits_out, int advance,
                       hipStream_t s)
@@ -906,13 +931,13 @@ static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int3
         return 0;
     case EXL_DEC_MERGE:
         // the split merge runs inside the o_proj kernel's prologue (PNORM 3); the stand-alone kernel is the A/B reference
-        if (d->nsplit == 1 || !d->separate_merge) return 0;
+        if (d->nsplit == 1 || dec_folds_merge(d)) return 0;
         hipLaunchKernelGGL(dec_attn_merge_kernel, dim3(d->heads), dim3(128), 0, s, d->partial, d->attn_out, d->nsplit, d->heads);
         EXL_LAUNCH_CHECK();
         return 0;
     case EXL_DEC_O: {
         Q4Matrix* om[1] = {l.o};
-        if (d->nsplit > 1 && !d->separate_merge)
+        if (d->nsplit > 1 && dec_folds_merge(d))
             return launch_dec_gemv(d->max_blocks, 3, 1, (const f16*) d->partial, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s,
                                    d->partial + (size_t) d->heads * d->nsplit * 64, d->nsplit);
         return launch_dec_gemv(d->max_blocks, 0, 1, d->attn_out, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s);
