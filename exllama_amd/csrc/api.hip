@@ -303,6 +303,31 @@ extern "C" int exl_q4_matmul_dual(void* w1, void* w2, const void* x, int x_heigh
     return r;
 }
 
+extern "C" int exl_q4_qkv_rope_cache(void* wq, void* wk, void* wv, const void* x, int bsz, int q_len, void* q_out, const void* sin,
+                                     const void* cos, void* key_cache, void* value_cache, int heads, int kv_heads, int head_dim,
+                                     int past_len, int max_seq_len, void* stream, int* launched)
+{
+    EXL_REQUIRE(launched, EXL_E_INVALID, "q4_qkv_rope_cache: launched is null");
+    *launched = 0;
+    Q4Matrix* mq = q4_from_handle(wq);
+    Q4Matrix* mk = q4_from_handle(wk);
+    Q4Matrix* mv = q4_from_handle(wv);
+    EXL_REQUIRE(mq && mk && mv, EXL_E_INVALID, "q4_qkv_rope_cache: invalid q4 handle");
+    EXL_REQUIRE(bsz >= 0 && q_len >= 0 && past_len >= 0, EXL_E_INVALID, "q4_qkv_rope_cache: negative size");
+    if (bsz == 0 || q_len == 0) { *launched = 1; return 0; }
+    EXL_REQUIRE(x && q_out && sin && cos && key_cache && value_cache, EXL_E_INVALID, "q4_qkv_rope_cache: null tensor pointer");
+    EXL_REQUIRE(past_len + q_len <= max_seq_len, EXL_E_INVALID, "q4_qkv_rope_cache: past_len %d + q_len %d exceeds the cache length %d",
+                past_len, q_len, max_seq_len);
+    DeviceGuard guard(mq->device);
+    EXL_REQUIRE(guard.ok, EXL_E_INVALID, "q4_qkv_rope_cache: cannot select device %d", mq->device);
+    const int r = launch_q4_qkv_rope_cache(mq, mk, mv, (const f16*) x, bsz * q_len, (f16*) q_out, (const f16*) sin, (const f16*) cos,
+                                           (f16*) key_cache, (f16*) value_cache, q_len, heads, kv_heads, head_dim, past_len, max_seq_len,
+                                           (hipStream_t) stream);
+    if (r == 1) return 0;                                    // not eligible: the caller runs the separate ops
+    if (r == 0) *launched = 1;
+    return r;
+}
+
 extern "C" int exl_q4_matmul_lora(void* w, const void* x, int x_height, void* out, const void* lora_a,
                                   const void* lora_b, int rank, void* lora_temp, void* stream)
 {

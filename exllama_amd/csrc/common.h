@@ -89,6 +89,9 @@ int launch_q4_gemv(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
                    hipStream_t s);
 int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_zero, f16* remap_tmp,
                    size_t remap_tmp_numel, hipStream_t s);
+int launch_q4_qkv_rope_cache(const Q4Matrix* wq, const Q4Matrix* wk, const Q4Matrix* wv, const f16* x, int rows, f16* q_out,
+                             const f16* sin, const f16* cos, f16* kc, f16* vc, int q_len, int heads, int kv_heads, int head_dim,
+                             int past_len, int max_seq, hipStream_t s);
 int launch_q4_gemm_dual(const Q4Matrix* w1, const Q4Matrix* w2, const f16* x, int rows, f16* out1, f16* out2, int silu,
                         hipStream_t s);                     // 1 = not eligible (run the products separately)
 int launch_half_gemm(const f16* x, const f16* w, f16* out, int M, int K, int N, int no_zero, hipStream_t s);

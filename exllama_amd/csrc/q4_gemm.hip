@@ -917,10 +917,25 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void q4_gemm_t16m_kernel(co
 #define GW_CONS 8
 #define GW_PROD 4
 #define GW_BATCH_STR "11"       // 3 loads + 8 DMA pieces
+// EPI 1 = the attention front half of the prompt pass in ONE launch (exl_q4_qkv_rope_cache): the block's 128 columns are one
+// head of q, k or v (three matrices sharing x and K, tiles numbered across them); the epilogue applies RoPE to q and k
+// (the partner column d +- 64 sits in the other column wave: exchanged through LDS) and writes q to its buffer, k and v
+// straight into the KV cache -- the reference runs 3 matmuls, 2 RoPE kernels and a cache scatter (model.py:431-445).
+struct GwQkv {
+    const uint4* qw[3]; const uint32_t* qz[3]; const f16* sc[3];
+    int n[3];                      // out_features of q, k, v
+    int nt_end[3];                 // cumulative 128-column tile counts
+    f16* q_out;                    // [rows][n[0]]
+    const f16 *sin, *cos;          // [max_seq][128]
+    f16 *kc, *vc;                  // [bsz][kv_heads][max_seq][128]
+    int q_len, past_len, max_seq, kv_heads;
+};
+template <int EPI>
 __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(const f16* __restrict__ x, const uint4* __restrict__ qw,
                                                                const uint32_t* __restrict__ qzeros,
                                                                const f16* __restrict__ scales, f16* __restrict__ out, int M,
-                                                               int K, int N, int gshift, int no_zero, int mtiles, int ntiles)
+                                                               int K, int N, int gshift, int no_zero, int mtiles, int ntiles,
+                                                               const GwQkv e)
 {
     constexpr int TM = 4, TN = 4, WAVES_N = 2;
     constexpr int TBM = 256;
@@ -934,9 +949,15 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
     const int idx = b >> 3;
     const int nl = idx / mtiles;
     const int mt = idx - nl * mtiles;
-    const int nt = nl * 8 + xcd;
+    int nt = nl * 8 + xcd;
     if (nt >= ntiles) return;
     const int m0 = mt * TBM;
+    int mi = 0;                                                        // EPI 1: which of q / k / v this block works on
+    if constexpr (EPI == 1) {
+        if (nt >= e.nt_end[1]) { mi = 2; nt -= e.nt_end[1]; }
+        else if (nt >= e.nt_end[0]) { mi = 1; nt -= e.nt_end[0]; }
+        qw = e.qw[mi]; qzeros = e.qz[mi]; scales = e.sc[mi]; N = e.n[mi];
+    }
     const int n0 = nt * GT_BN;
 
     const int tid = threadIdx.x;
@@ -1070,6 +1091,9 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
             a_slot = ring(a_slot, 1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the redundant fetches must not outlive the block's LDS
+        if constexpr (EPI == 1) {
+            if (mi < 2) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }   // the RoPE exchange of the MFMA waves reuses the tiles
+        }
 #ifdef EXL_GEMM_PROBE
         if (lane == 0 && b < 1024) {                                    // producers report in slots 4..7 of the block: {issue, wait, store, barrier} of the even steps
             unsigned long long* pp = g_gemm_probe + ((size_t) b * 8 + 4 + pw) * 4;
@@ -1147,6 +1171,59 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
 #undef GW_MFMA4
 #undef GW_SB
 
+    if constexpr (EPI == 1) {
+        // acc[in][im][j]: row m0 + (wm * 4 + im) * 16 + fr, column d = wn * 64 + in * 16 + fk * 4 + j of head n0 / 128
+        const int head = n0 >> 7;
+        uint2 val[TN][TM];                                             // fp16 results, 4 consecutive columns per (in, im)
+#pragma unroll
+        for (int in = 0; in < TN; ++in)
+#pragma unroll
+            for (int im = 0; im < TM; ++im) {
+                const f16x4 h4 = {(f16) acc[in][im][0], (f16) acc[in][im][1], (f16) acc[in][im][2], (f16) acc[in][im][3]};
+                val[in][im] = __builtin_bit_cast(uint2, h4);
+            }
+        uint2 oth[TN][TM];
+        if (mi < 2) {                                                  // q, k: fetch the partner half (d +- 64) from the other column wave
+            uint2* xch = (uint2*) lds;                                 // [8 waves][16 tiles][64 lanes]
+            __builtin_amdgcn_s_barrier();                              // every wave is past its last fragment read, the loaders' DMAs have landed
+#pragma unroll
+            for (int in = 0; in < TN; ++in)
+#pragma unroll
+                for (int im = 0; im < TM; ++im) xch[(wave * 16 + in * 4 + im) * 64 + lane] = val[in][im];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int in = 0; in < TN; ++in)
+#pragma unroll
+                for (int im = 0; im < TM; ++im) oth[in][im] = xch[((wave ^ 1) * 16 + in * 4 + im) * 64 + lane];
+        }
+#pragma unroll
+        for (int im = 0; im < TM; ++im) {
+            const int row = m0 + (wm * TM + im) * 16 + fr;
+            if (row >= M) continue;
+            const int bb = row / e.q_len, pos = e.past_len + (row - bb * e.q_len);
+#pragma unroll
+            for (int in = 0; in < TN; ++in) {
+                const int d = wn * 64 + in * 16 + fk * 4;
+                f16x4 r = __builtin_bit_cast(f16x4, val[in][im]);
+                if (mi < 2) {                                          // rope.cu:21-88: l' = fma(l, cos_l, h(r * h(-sin_l))), r' = fma(r, cos_r, h(l * sin_r))
+                    const f16x4 o4 = __builtin_bit_cast(f16x4, oth[in][im]);
+                    const f16x4 sn = *(const f16x4*) (e.sin + (size_t) pos * 128 + d);
+                    const f16x4 cs = *(const f16x4*) (e.cos + (size_t) pos * 128 + d);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f16 t = o4[j] * (wn == 0 ? (f16) (-sn[j]) : sn[j]);
+                        r[j] = __builtin_fmaf16(r[j], cs[j], t);
+                    }
+                }
+                f16* dst = mi == 0 ? e.q_out + (size_t) row * e.n[0] + head * 128 + d
+                                   : (mi == 1 ? e.kc : e.vc) + (((size_t) bb * e.kv_heads + head) * e.max_seq + pos) * 128 + d;
+                *(f16x4*) dst = r;
+            }
+        }
+        return;
+    }
+
 #pragma unroll
     for (int im = 0; im < TM; ++im) {
         const int row = m0 + (wm * TM + im) * 16 + fr;
@@ -1169,6 +1246,12 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
     }
 }
 
+static int gw_opt_in(const void* kfn)
+{
+    EXL_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return 0;
+}
+
 static int launch_gemm_t16w(const Q4Matrix* w, const f16* xin, int rows, f16* out, int no_zero, int gshift, hipStream_t s)
 {
     const int K = w->height, N = w->width;
@@ -1177,12 +1260,49 @@ static int launch_gemm_t16w(const Q4Matrix* w, const f16* xin, int rows, f16* ou
     const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
     const size_t smem = 3 * (size_t) 256 * 128 + 2 * GT_BTILE_BYTES;
     static bool big = false;
-    if (!big) {
-        EXL_HIP(hipFuncSetAttribute((const void*) q4_gemm_t16w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        big = true;
+    if (!big) { EXL_TRY(gw_opt_in((const void*) q4_gemm_t16w_kernel<0>)); big = true; }
+    GwQkv none = {};
+    hipLaunchKernelGGL(q4_gemm_t16w_kernel<0>, dim3(grid), dim3((GW_CONS + GW_PROD) * 64), smem, s, xin, (const uint4*) w->qweight, w->qzeros,
+                       w->scales, out, rows, K, N, gshift, no_zero, mtiles, ntiles, none);
+    EXL_LAUNCH_CHECK();
+    return 0;
+}
+
+// q = rope(x @ Wq), cache_k <- rope(x @ Wk), cache_v <- x @ Wv in one launch.  Returns 1 (nothing launched) when the
+// matrices / shapes are outside what the fused kernel covers; the caller then runs the separate ops.
+int launch_q4_qkv_rope_cache(const Q4Matrix* wq, const Q4Matrix* wk, const Q4Matrix* wv, const f16* x, int rows, f16* q_out,
+                             const f16* sin, const f16* cos, f16* kc, f16* vc, int q_len, int heads, int kv_heads, int head_dim,
+                             int past_len, int max_seq, hipStream_t s)
+{
+    static const bool off = getenv("EXL_GEMM_NO_QKV_FUSION") != nullptr;      // A/B switch
+    const Q4Matrix* m[3] = {wq, wk, wv};
+    const int K = wq->height;
+    if (off || rows <= 512 || head_dim != 128 || q_len <= 0 || rows % q_len != 0) return 1;
+    if (wq->width != heads * 128 || wk->width != kv_heads * 128 || wv->width != kv_heads * 128) return 1;
+    if ((uint64_t) rows * (uint64_t) K >= (1ull << 31)) return 1;
+    int gshift = -1;
+    for (int i = 0; i < 3; ++i) {
+        if (m[i]->layout != EXL_LAYOUT_T16 || m[i]->x_map || m[i]->height != K || m[i]->groupsize != wq->groupsize) return 1;
+        if ((uint64_t) K * (uint64_t) m[i]->width >= (1ull << 32)) return 1;
     }
-    hipLaunchKernelGGL(q4_gemm_t16w_kernel, dim3(grid), dim3((GW_CONS + GW_PROD) * 64), smem, s, xin, (const uint4*) w->qweight, w->qzeros,
-                       w->scales, out, rows, K, N, gshift, no_zero, mtiles, ntiles);
+    if ((wq->groupsize & (wq->groupsize - 1)) == 0) { gshift = 0; while ((1 << gshift) < wq->groupsize) ++gshift; }
+    if (gshift < 5) return 1;
+    GwQkv e = {};
+    int tiles = 0;
+    for (int i = 0; i < 3; ++i) {
+        e.qw[i] = (const uint4*) m[i]->qweight; e.qz[i] = m[i]->qzeros; e.sc[i] = m[i]->scales; e.n[i] = m[i]->width;
+        tiles += m[i]->width / 128;
+        e.nt_end[i] = tiles;
+    }
+    e.q_out = q_out; e.sin = sin; e.cos = cos; e.kc = kc; e.vc = vc;
+    e.q_len = q_len; e.past_len = past_len; e.max_seq = max_seq; e.kv_heads = kv_heads;
+    const int mtiles = (rows + 255) / 256;
+    const int grid = 8 * ((tiles + 7) / 8) * mtiles;
+    const size_t smem = 3 * (size_t) 256 * 128 + 2 * GT_BTILE_BYTES;
+    static bool big = false;
+    if (!big) { EXL_TRY(gw_opt_in((const void*) q4_gemm_t16w_kernel<1>)); big = true; }
+    hipLaunchKernelGGL(q4_gemm_t16w_kernel<1>, dim3(grid), dim3((GW_CONS + GW_PROD) * 64), smem, s, x, (const uint4*) nullptr, (const uint32_t*) nullptr,
+                       (const f16*) nullptr, (f16*) nullptr, rows, K, 0, gshift, 0, mtiles, tiles, e);
     EXL_LAUNCH_CHECK();
     return 0;
 }

@@ -181,6 +181,22 @@ class _ExllamaExt:
                                                C.byref(done)), "q4_matmul_dual")
         return bool(done.value)
 
+    def q4_qkv_rope_cache(self, x, wq, wk, wv, q_out, sin, cos, key_cache, value_cache, q_len, past_len, num_heads, num_kv_heads,
+                          head_dim, max_seq_len):
+        """q_out = rope(x @ Wq), key_cache <- rope(x @ Wk), value_cache <- x @ Wv at past_len in one kernel (include/exl_amd.h:
+        exl_q4_qkv_rope_cache).  x: [bsz * q_len, hidden].  Returns False when the shapes are not eligible: nothing was launched."""
+        if x.dtype != torch.float16 or q_out.dtype != torch.float16 or not x.is_contiguous() or not q_out.is_contiguous():
+            raise RuntimeError("q4_qkv_rope_cache: x and q_out must be contiguous fp16")
+        rows = x.size(0)
+        if rows % q_len != 0 or q_out.size(0) != rows or q_out.size(1) != num_heads * head_dim:
+            raise RuntimeError("q4_qkv_rope_cache: x, q_out and q_len have incompatible shapes")
+        done = C.c_int()
+        with _Guard(x.device):
+            check(self._lib.exl_q4_qkv_rope_cache(wq, wk, wv, x.data_ptr(), rows // q_len, q_len, q_out.data_ptr(), sin.data_ptr(), cos.data_ptr(),
+                                                  key_cache.data_ptr(), value_cache.data_ptr(), num_heads, num_kv_heads, head_dim, past_len,
+                                                  max_seq_len, _stream(x), C.byref(done)), "q4_qkv_rope_cache")
+        return bool(done.value)
+
     def q4_reconstruct(self, w, out):
         _req_dtype(out, torch.float16, "out")
         _req_cuda(out, "out")

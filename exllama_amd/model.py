@@ -268,13 +268,22 @@ class ExLlamaAttention:
         cfg = self.config
         bsz, q_len, _ = normed.shape
         past_len = cache.current_seq_len
-        q = self.q_proj.forward(normed, lora)
-        k = self.k_proj.forward(normed, lora)
-        v = self.v_proj.forward(normed, lora)
-        ext.rope_(q, self.sin, self.cos, past_len, cfg.num_attention_heads, cfg.head_dim)
-        ext.rope_(k, self.sin, self.cos, past_len, cfg.num_key_value_heads, cfg.head_dim)
         kc, vc = cache.key_states[self.index], cache.value_states[self.index]
-        ext.update_cache(k, v, kc, vc, past_len)
+        q = None
+        if not any(p.lora_applies(lora) or p.bias is not None for p in (self.q_proj, self.k_proj, self.v_proj)):
+            # long prompts: the three projections, both RoPEs and the cache write as one kernel (exl_q4_qkv_rope_cache)
+            q = torch.empty((bsz, q_len, cfg.num_attention_heads * cfg.head_dim), dtype=torch.float16, device=normed.device)
+            if not ext.q4_qkv_rope_cache(normed.view(-1, normed.shape[-1]), self.q_proj.q4, self.k_proj.q4, self.v_proj.q4,
+                                         q.view(-1, q.shape[-1]), self.sin, self.cos, kc, vc, q_len, past_len,
+                                         cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cache.max_seq_len):
+                q = None
+        if q is None:
+            q = self.q_proj.forward(normed, lora)
+            k = self.k_proj.forward(normed, lora)
+            v = self.v_proj.forward(normed, lora)
+            ext.rope_(q, self.sin, self.cos, past_len, cfg.num_attention_heads, cfg.head_dim)
+            ext.rope_(k, self.sin, self.cos, past_len, cfg.num_key_value_heads, cfg.head_dim)
+            ext.update_cache(k, v, kc, vc, past_len)
         attn = torch.empty_like(q)
         mask = buffer.attn_mask if (buffer is not None and buffer.needs_mask) else None
         ext.attention(q, kc, vc, attn, past_len, cfg.num_attention_heads, mask=mask)

@@ -105,6 +105,14 @@ int exl_q4_matmul_gemm(void* w, const void* x, int x_height, void* out, int no_z
  * issues the separate calls (exl_q4_matmul twice + exl_silu_mul). */
 int exl_q4_matmul_dual(void* w1, void* w2, const void* x, int x_height, void* out1, void* out2, int silu, void* stream,
                        int* launched);
+/* Prompt-pass fusion of the attention front half (reference: model.py:431-445 -- three q4_matmul, two rope_, the cache
+ * scatter): q_out [bsz*q_len, heads*128] = rope(x @ Wq); key_cache[b, h, past_len + t, :] = rope(x @ Wk);
+ * value_cache[b, h, past_len + t, :] = x @ Wv, in ONE kernel (RoPE and the cache write are the GEMM's epilogue).  Same
+ * eligibility rule and `launched` protocol as exl_q4_matmul_dual, plus head_dim == 128; results are bit-identical to the
+ * separate calls. */
+int exl_q4_qkv_rope_cache(void* wq, void* wk, void* wv, const void* x, int bsz, int q_len, void* q_out, const void* sin,
+                          const void* cos, void* key_cache, void* value_cache, int heads, int kv_heads, int head_dim,
+                          int past_len, int max_seq_len, void* stream, int* launched);
 /* out = x @ W + (x @ lora_A) @ lora_B   (reference: exllama_ext.cpp:245-324 q4_matmul_lora) */
 int exl_q4_matmul_lora(void* w, const void* x, int x_height, void* out, const void* lora_a, const void* lora_b,
                        int rank, void* lora_temp, void* stream);

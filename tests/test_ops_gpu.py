@@ -287,6 +287,47 @@ def test_q4_matmul_dual_declines_what_it_does_not_cover(ce):
     assert float(out.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("hidden,heads,kvh,gs,bsz,q_len,past", [(512, 4, 4, 128, 1, 600, 0), (1024, 8, 2, 64, 2, 300, 5), (4096, 32, 32, 128, 1, 2048, 0)])
+def test_q4_qkv_rope_cache_equals_separate_ops(ce, hidden, heads, kvh, gs, bsz, q_len, past):
+    """exl_q4_qkv_rope_cache (long-prompt fusion of the attention front half) against the calls the reference issues
+    (model.py:431-445: three q4_matmul, two rope_, the cache scatter): q and both caches bit-identical, the rest of the
+    cache untouched."""
+    hd, max_seq = 128, past + q_len + 7
+    gen = torch.Generator().manual_seed(hidden + q_len)
+    std = 0.02 * (4096 / hidden) ** 0.5
+    lq, _ = _lin(hidden, heads * hd, gs, False, seed=1 + hidden, std=std)
+    lk, _ = _lin(hidden, kvh * hd, gs, False, seed=2 + hidden, std=std)
+    lv, _ = _lin(hidden, kvh * hd, gs, False, seed=3 + hidden, std=std)
+    (hq, _dq), (hk, _dk), (hv, _dv) = _handle(ce, lq), _handle(ce, lk), _handle(ce, lv)
+    x = torch.randn(bsz * q_len, hidden, generator=gen).half().to(DEV)
+    pos = torch.arange(max_seq, dtype=torch.float32)[:, None] * (10000.0 ** (-torch.arange(0, hd, 2, dtype=torch.float32) / hd))[None, :]
+    emb = torch.cat([pos, pos], dim=-1)
+    sin, cos = emb.sin().half().to(DEV), emb.cos().half().to(DEV)
+    ext = ce.exllama_ext
+    # reference sequence
+    q = torch.empty((bsz, q_len, heads * hd), dtype=torch.float16, device=DEV)
+    k = torch.empty((bsz, q_len, kvh * hd), dtype=torch.float16, device=DEV)
+    v = torch.empty_like(k)
+    ext.q4_matmul_gemm(x, hq, q.view(-1, heads * hd))
+    ext.q4_matmul_gemm(x, hk, k.view(-1, kvh * hd))
+    ext.q4_matmul_gemm(x, hv, v.view(-1, kvh * hd))
+    ext.rope_(q, sin, cos, past, heads, hd)
+    ext.rope_(k, sin, cos, past, kvh, hd)
+    kc = torch.full((bsz, kvh, max_seq, hd), 7.0, dtype=torch.float16, device=DEV)
+    vc = torch.full_like(kc, -3.0)
+    ext.update_cache(k, v, kc, vc, past)
+    # fused
+    q2 = torch.full_like(q, float("nan"))
+    kc2 = torch.full_like(kc, 7.0)
+    vc2 = torch.full_like(vc, -3.0)
+    assert ext.q4_qkv_rope_cache(x, hq, hk, hv, q2.view(-1, heads * hd), sin, cos, kc2, vc2, q_len, past, heads, kvh, hd, max_seq)
+    assert torch.equal(q2, q)
+    assert torch.equal(kc2, kc) and torch.equal(vc2, vc)
+    assert float(kc2[:, :, past + q_len:].float().min()) == 7.0 and float(vc2[:, :, past + q_len:].float().max()) == -3.0     # beyond the prompt: untouched
+    # declines short prompts and act-order
+    assert not ext.q4_qkv_rope_cache(x[:256].contiguous(), hq, hk, hv, q2.view(-1, heads * hd)[:256], sin, cos, kc2, vc2, 256 // bsz, 0, heads, kvh, hd, max_seq)
+
+
 def test_q4_matmul_lora(ce):
     lin, gen = _lin(512, 256, 128, False, seed=21)
     h, d = _handle(ce, lin)
