@@ -2,19 +2,16 @@
 //
 // Replaces /root/reference/exllama_ext/cuda_func/q4_matmul.cu:301-344 (q4_matmul_recons_cuda), which
 // materialises the whole fp16 weight (q4_matrix.cu:170-224 reconstruct_kernel, K*N*2 bytes written and read
-// back per call) and then calls cublasHgemm.  Here nothing is materialised:
-//   * the GPTQ word (8 consecutive k of ONE output column) is exactly the per-lane B fragment of
-//     v_mfma_f32_32x32x16_f16 (lane = column, 8 consecutive k).  So packed weights go
-//     HBM -> VGPR -> (magic-number nibble expand, exact zero subtraction, ONE fp16 multiply by the group
-//     scale = bit-identical W16 to the reference's reconstruct) -> MFMA operand.  No LDS, no fp16 copy;
-//   * nibble pairs come out of a word in the order (0,4)(1,5)(2,6)(3,7); instead of re-ordering the weights
-//     (4 v_perm per word, per wave) the ACTIVATION tile is written to LDS in that k-order once per block --
-//     any k-permutation shared by A and B leaves the dot product unchanged;
-//   * A tile 128x64 fp16 through LDS, register-staged, double-buffered, XOR-swizzled so every
-//     ds_read_b128 lane group hits 16 distinct 16-byte slots;
-//   * 256 threads = 4 waves as 2(M) x 2(N), each 64x64 = 2x2 MFMA 32x32 tiles, fp32 accumulate;
-//   * blocks of one XCD walk m-tiles of the same weight column tile first, so a W tile is pulled from HBM
-//     once per XCD L2 rather than once per m-tile.
+// back per call) and then calls cublasHgemm.  Here nothing is materialised.  Kernels in this file:
+//   q4_gemm_kernel<T16>      generic register-B kernel (any layout / shape the T16 tiling cannot express; A/B reference):
+//                            the packed word is the per-lane B fragment of v_mfma_f32_32x32x16_f16, dequantised in
+//                            registers by every wave; the activation tile goes through LDS in the nibble order;
+//   q4_gemm_t16m_kernel      T16 layout, weights dequantised ONCE per block into an LDS tile, mid-step barrier schedule
+//                            (<= 512 rows: 128 x 128 tile; also the fallback of the next one);
+//   q4_gemm_t16w_kernel<EPI> the default above 512 rows: 8 MFMA waves + 4 loader waves on a 256 x 128 tile; EPI 1 is the
+//                            q/k/v projection with RoPE and the KV-cache write as its epilogue;
+//   q4_gemm_t16d_kernel      gate and up projections of the MLP in one kernel with the SiLU epilogue;
+//   half_gemm_kernel         plain fp16 GEMM of the LoRA path (correctness first).
 // Act-order weights: x is gathered through x_map by column_remap into the borrowed temp_state buffer first
 // (same as the reference, q4_matmul.cu:320-325); folding the gather into the A-tile load is future work.
 #include "gemv_t16.h"
@@ -228,9 +225,9 @@ __global__ __launch_bounds__(256) void q4_gemm_kernel(const f16* __restrict__ x,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// T16 layout, LDS-staged B: the prefill kernel of the product path.
+// T16 layout, LDS-staged B: the prefill kernels of the product path (what all of them share).
 //
-//   * block tile BM(M) x 128(N), K step 64; BM = 256 with 8 waves (4 x 2) for large M, 128 with 4 waves (2 x 2) otherwise;
+//   * block tile BM(M) x 128(N), K step 64; BM = 256 with 8 MFMA waves (4 x 2) for large M, 128 with 4 waves (2 x 2) otherwise;
 //     each wave 64 x 64 = 4 x 4 tiles of v_mfma_f32_16x16x32_f16, fp32 accumulate (64 accumulator registers);
 //   * activations: global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip), 128-byte rows XOR-swizzled
 //     through the per-lane SOURCE address (the LDS image of a DMA is lane-linear), so the fragment reads
@@ -240,7 +237,10 @@ __global__ __launch_bounds__(256) void q4_gemm_kernel(const f16* __restrict__ x,
 //     reconstruct (q4_matrix.cu:207), already in natural k order (the T16 words are nibble-interleaved), and writes
 //     them to the swizzled [n][k] LDS tile.  The dequantisation cost is paid once per BM rows of M instead of once per
 //     wave as in the register-B kernel above; at BM = 256 it is 1/4 of the VALU work of the 128-row tile per MFMA;
-//   * double-buffered LDS, tile t+1 is staged while tile t feeds the MFMAs, one barrier per K step;
+//   * activations run two K steps ahead through a 3-slot LDS ring, the packed weights of step t+2 are in flight in
+//     registers while step t feeds the MFMAs and step t+1 is dequantised; hipcc cannot count LDS-DMA next to ordinary
+//     loads (it drains with vmcnt(0)), so the register loads are inline asm with hand-counted s_waitcnt, barriers are raw
+//     s_barrier, LDS stores go through inline asm; one barrier per K step;
 //   * MFMA roles are swapped (A operand = weights, B operand = activations) so that a lane ends up with 4 CONSECUTIVE
 //     output columns of one row: 8-byte stores instead of 2-byte ones;
 //   * blocks of one XCD walk the m-tiles of the same weight column tile first (weights are pulled from HBM once per
@@ -253,169 +253,6 @@ __global__ __launch_bounds__(256) void q4_gemm_kernel(const f16* __restrict__ x,
 // byte offset of the 16-byte chunk c (8 halves) of row r in a swizzled [rows][64] fp16 tile
 __device__ __forceinline__ int gt_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
 
-template <int WM>          // waves along M: block = WM x 2 waves, BM = 64 * WM rows
-__global__ __launch_bounds__(WM * 128) void q4_gemm_t16_kernel(const f16* __restrict__ x, const uint4* __restrict__ qw,
-                                                              const uint32_t* __restrict__ qzeros,
-                                                              const f16* __restrict__ scales, f16* __restrict__ out, int M,
-                                                              int K, int N, int gshift, int groupsize, int no_zero, int mtiles,
-                                                              int ntiles)
-{
-    constexpr int TBM = 64 * WM;
-    constexpr int NTH = WM * 128;
-    constexpr int A_BYTES = TBM * 128;
-    constexpr int STAGE = A_BYTES + GT_BTILE_BYTES;
-    constexpr int PW = 4 * 256 / NTH;                                 // words of a piece per thread (4 or 2)
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [2][A | B]
-
-    const int b = blockIdx.x;
-    const int xcd = b & 7;
-    const int idx = b >> 3;
-    const int nl = idx / mtiles;
-    const int mt = idx - nl * mtiles;
-    const int nt = nl * 8 + xcd;
-    if (nt >= ntiles) return;
-    const int m0 = mt * TBM;
-    const int n0 = nt * GT_BN;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int RB = K >> 7;
-    const int nk = K / GT_BK;
-
-    // ---- A staging (LDS-DMA): BM / 8 pieces of 1 KiB per tile, 4 per wave; piece c = rows 8c .. 8c+7 ---------------
-    const f16* a_src[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = wave * 4 + i;
-        const int row = c * 8 + (lane >> 3);
-        const int slot = lane & 7;
-        const int grow = min(m0 + row, M - 1);                       // rows past M re-read the last row (never stored)
-        a_src[i] = x + (size_t) grow * K + ((slot ^ (row & 7)) << 3);
-    }
-    auto stage_a = [&](int buf, int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __attribute__((address_space(3))) unsigned char* dst =
-                (__attribute__((address_space(3))) unsigned char*) (lds + (size_t) buf * STAGE + (wave * 4 + i) * 1024);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (a_src[i] + k0), dst, 16, 0, 0);
-        }
-    };
-
-    // ---- B staging: thread -> PW words of one T16 piece per K step -----------------------------------------------------
-    const int pid = PW == 4 ? tid : tid >> 1;                         // piece within the K step (0..255)
-    const int ph = PW == 4 ? 0 : tid & 1;                             // which half of the piece
-    const int b_tile = pid >> 5;                                      // 16-column tile within the block (0..7)
-    const int b_rs = (pid >> 4) & 1;                                  // which 32-k half of the K step
-    const int b_col = pid & 15;
-    const int b_nloc = b_tile * 16 + b_col;                           // row of the LDS B tile
-    const int b_n = min(n0 + b_nloc, N - 1);                          // clamped column (a partial last n-tile is never stored)
-    const uint32_t* b_src = (const uint32_t*) (qw + ((size_t) (b_n >> 4) * RB) * 64 + (b_n & 15)) + ph * PW;
-    const int b_zsh = (b_n & 7) * 4;
-    const uint32_t magic = t16_magic();
-    uint32_t breg[PW];
-    uint32_t bzw;
-    f16 bsc;
-    auto issue_b = [&](int it) {
-        const int rb = it >> 1, rsub = (it & 1) * 2 + b_rs;
-        const uint32_t* p = b_src + ((size_t) rb * 64 + rsub * 16) * 4;
-        if constexpr (PW == 4) { const uint4 v = *(const uint4*) p; breg[0] = v.x; breg[1] = v.y; breg[2] = v.z; breg[3] = v.w; }
-        else                   { const uint2 v = *(const uint2*) p; breg[0] = v.x; breg[1] = v.y; }
-        const int k = it * GT_BK + b_rs * 32;
-        const int grp = gshift >= 0 ? (k >> gshift) : (k / groupsize);
-        bzw = qzeros[(size_t) grp * (N >> 3) + (b_n >> 3)];
-        bsc = scales[(size_t) grp * N + b_n];
-    };
-    auto store_b = [&](int buf) {
-        const int z = (int) ((bzw >> b_zsh) & 0xFu) + 1;
-        const f16 za = (f16) (float) (-(1024 + z));
-        const f16 zb = (f16) (float) (-(64 + z));
-        const f16x2 zc0 = {za, za}, zc1 = {zb, zb}, s2 = {bsc, bsc};
-        unsigned char* base = lds + (size_t) buf * STAGE + A_BYTES;
-#pragma unroll
-        for (int j = 0; j < PW; ++j) {
-            const f16x8 d = t16_dequant_exact(breg[j], magic, zc0, zc1);                // natural k order
-            const uint4 u = __builtin_bit_cast(uint4, d);
-            uint4 o;
-            o.x = __builtin_bit_cast(uint32_t, as_h2(u.x) * s2); o.y = __builtin_bit_cast(uint32_t, as_h2(u.y) * s2);
-            o.z = __builtin_bit_cast(uint32_t, as_h2(u.z) * s2); o.w = __builtin_bit_cast(uint32_t, as_h2(u.w) * s2);
-            *(uint4*) (base + gt_off(b_nloc, b_rs * 4 + ph * PW + j)) = o;
-        }
-    };
-
-    f32x4 acc[4][4];                                                    // [n-tile][m-tile]
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    stage_a(0, 0);
-    issue_b(0);
-    store_b(0);
-    __syncthreads();
-
-    const int fr = lane & 15, fk = lane >> 4;
-    for (int it = 0; it < nk; ++it) {
-        const int cur = it & 1;
-        const bool more = it + 1 < nk;
-        if (more) {
-            stage_a(cur ^ 1, (it + 1) * GT_BK);
-            issue_b(it + 1);
-        }
-        const unsigned char* at = lds + (size_t) cur * STAGE;
-        const unsigned char* bt = at + A_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            f16x8 xf[4], wf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                xf[i] = *(const f16x8*) (at + gt_off(wm * 64 + i * 16 + fr, kk * 4 + fk));
-                wf[i] = *(const f16x8*) (bt + gt_off(wn * 64 + i * 16 + fr, kk * 4 + fk));
-            }
-#pragma unroll
-            for (int in = 0; in < 4; ++in)
-#pragma unroll
-                for (int im = 0; im < 4; ++im)
-                    acc[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[in], xf[im], acc[in][im], 0, 0, 0);
-        }
-        if (more) store_b(cur ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue: lane holds D[n = 4 * fk + j][m = fr] of each 16 x 16 tile: 4 consecutive columns of one row -----------
-#pragma unroll
-    for (int im = 0; im < 4; ++im) {
-        const int row = m0 + wm * 64 + im * 16 + fr;
-        if (row < M) {
-#pragma unroll
-            for (int in = 0; in < 4; ++in) {
-                const int n = n0 + wn * 64 + in * 16 + fk * 4;
-                if (n < N) {
-                    f16* op = out + (size_t) row * N + n;
-                    float v[4] = {acc[in][im][0], acc[in][im][1], acc[in][im][2], acc[in][im][3]};
-                    if (no_zero) {
-                        const f16x4 prev = *(const f16x4*) op;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += (float) prev[j];
-                    }
-                    *(f16x4*) op = (f16x4){(f16) v[0], (f16) v[1], (f16) v[2], (f16) v[3]};
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Same tile, deeper pipeline: activation tiles run TWO K steps ahead through a 3-slot LDS ring, the packed weight piece
-// (+ its zero word and scale) of step t+2 is in flight in registers while step t feeds the MFMAs and step t+1 is being
-// dequantised.  hipcc cannot count LDS-DMA next to ordinary loads (it drains with vmcnt(0)), so the register loads are
-// issued from inline asm and waited for with a hand-counted s_waitcnt: every K step issues exactly GP_BATCH VMEM
-// operations (4 DMA pieces + 3 loads), so "vmcnt(GP_BATCH)" = "everything of the previous step's batch has landed".
-// Barriers are raw s_barrier (a __syncthreads() would drain the DMA queue as well).
-// ---------------------------------------------------------------------------------------------------------------
-#define GP_BATCH 7
-
 // Stall attribution for scripts/probe_gemm.hip (compiled only there): cycles a wave spends in the VMEM wait, the dequant +
 // LDS store, and the barrier of each K step; [block][wave][4] = {total, wait, store, barrier}.
 #ifdef EXL_GEMM_PROBE
@@ -427,236 +264,10 @@ __device__ unsigned long long g_gemm_probe[1024 * 8 * 4];
 #define GP_ACC(dst, a, b) do { } while (0)
 #endif
 
-// WAVES_M x WAVES_N waves, each TM x TN tiles of 16 x 16: block = (WAVES_M * TM * 16) rows x 128 columns (WAVES_N * TN == 8).
-// Fewer, fatter waves read fewer LDS fragments per MFMA ((TM + TN) / (TM * TN)): the kernel is LDS-bandwidth bound.
-template <int WAVES_M, int WAVES_N, int TM, int TN>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void q4_gemm_t16p_kernel(const f16* __restrict__ x, const uint4* __restrict__ qw,
-                                                               const uint32_t* __restrict__ qzeros,
-                                                               const f16* __restrict__ scales, f16* __restrict__ out, int M,
-                                                               int K, int N, int gshift, int groupsize, int no_zero, int mtiles,
-                                                               int ntiles)
-{
-    static_assert(WAVES_N * TN == 8, "block is 128 columns wide");
-    constexpr int TBM = WAVES_M * TM * 16;
-    constexpr int NW = WAVES_M * WAVES_N;
-    constexpr int NTH = NW * 64;
-    constexpr int APW = (TBM / 8) / NW;                               // 1 KiB activation pieces per wave per K step
-    static_assert(APW * NW * 8 == TBM, "activation pieces must divide evenly");
-    constexpr int A_BYTES = TBM * 128;
-    constexpr int PW = 4 * 256 / NTH;                                 // words of a piece per thread (4 or 2)
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [3][A] then [2][B]
-    unsigned char* const ldsB = lds + 3 * A_BYTES;
-
-    const int b = blockIdx.x;
-    const int xcd = b & 7;
-    const int idx = b >> 3;
-    const int nl = idx / mtiles;
-    const int mt = idx - nl * mtiles;
-    const int nt = nl * 8 + xcd;
-    if (nt >= ntiles) return;
-    const int m0 = mt * TBM;
-    const int n0 = nt * GT_BN;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int RB = K >> 7;
-    const int nk = K / GT_BK;                                         // even (K % 128 == 0)
-
-    const f16* a_src[APW];
-#pragma unroll
-    for (int i = 0; i < APW; ++i) {
-        const int c = wave * APW + i;
-        const int row = c * 8 + (lane >> 3);
-        const int slot = lane & 7;
-        const int grow = min(m0 + row, M - 1);
-        a_src[i] = x + (size_t) grow * K + ((slot ^ (row & 7)) << 3);
-    }
-    auto stage_a = [&](int slot3, int k0) {
-#pragma unroll
-        for (int i = 0; i < APW; ++i) {
-            __attribute__((address_space(3))) unsigned char* dst =
-                (__attribute__((address_space(3))) unsigned char*) (lds + (size_t) slot3 * A_BYTES + (wave * APW + i) * 1024);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (a_src[i] + k0), dst, 16, 0, 0);
-        }
-    };
-
-    const int pid = PW == 4 ? tid : tid >> 1;                          // 256 or 512 threads
-    const int ph = PW == 4 ? 0 : tid & 1;
-    const int b_tile = pid >> 5;
-    const int b_rs = (pid >> 4) & 1;
-    const int b_col = pid & 15;
-    const int b_nloc = b_tile * 16 + b_col;
-    const int b_n = min(n0 + b_nloc, N - 1);
-    const uint32_t* b_src = (const uint32_t*) (qw + ((size_t) (b_n >> 4) * RB) * 64 + (b_n & 15)) + ph * PW;
-    const int b_zsh = (b_n & 7) * 4;
-    const uint32_t magic = t16_magic();
-
-    // register set of one K step: packed words, zero word, scale -- loaded by inline asm (3 VMEM operations)
-    struct BRegs { u32x4 w4; u32x2 w2; uint32_t zw, sc; };            // w4 (256 threads) or w2 (512 threads) holds the packed words
-    auto issue_b = [&](int it, BRegs& r) {
-        const int rb = it >> 1, rsub = (it & 1) * 2 + b_rs;
-        const uint32_t* p = b_src + ((size_t) rb * 64 + rsub * 16) * 4;
-        const int k = it * GT_BK + b_rs * 32;
-        const int grp = gshift >= 0 ? (k >> gshift) : (k / groupsize);
-        const uint32_t* zp = qzeros + (size_t) grp * (N >> 3) + (b_n >> 3);
-        const f16* sp = scales + (size_t) grp * N + b_n;
-        if constexpr (PW == 4) {
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.w4) : "v"(p) : "memory");
-        } else {
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r.w2) : "v"(p) : "memory");
-        }
-        asm volatile("global_load_dword %0, %1, off" : "=v"(r.zw) : "v"(zp) : "memory");
-        asm volatile("global_load_ushort %0, %1, off" : "=v"(r.sc) : "v"(sp) : "memory");
-    };
-    // wait until at most `N` VMEM operations are outstanding, and tie the registers of `r` to the wait
-#define GP_WAIT(NSTR, r)                                                                                              \
-    do {                                                                                                              \
-        if constexpr (PW == 4) asm volatile("s_waitcnt vmcnt(" NSTR ")" : "+v"(r.w4), "+v"(r.zw), "+v"(r.sc) :: "memory"); \
-        else                   asm volatile("s_waitcnt vmcnt(" NSTR ")" : "+v"(r.w2), "+v"(r.zw), "+v"(r.sc) :: "memory"); \
-    } while (0)
-    // one K step's batch = APW DMA pieces + 3 loads: "at most one batch outstanding" = the previous batch has landed
-#define GP_WAITB(r) do { if constexpr (APW == 4) GP_WAIT("7", r); else if constexpr (APW == 8) GP_WAIT("11", r); else GP_WAIT("5", r); } while (0)
-    static_assert(APW == 2 || APW == 4 || APW == 8, "unsupported activation piece count");
-    auto store_b = [&](int slot2, const BRegs& r) {
-        const int z = (int) ((r.zw >> b_zsh) & 0xFu) + 1;
-        const f16 za = (f16) (float) (-(1024 + z));
-        const f16 zb = (f16) (float) (-(64 + z));
-        const f16 bsc = __builtin_bit_cast(f16, (uint16_t) (r.sc & 0xFFFFu));
-        const f16x2 zc0 = {za, za}, zc1 = {zb, zb}, s2 = {bsc, bsc};
-        // LDS byte address of this thread's first chunk; the stores go through inline asm: hipcc would otherwise drain
-        // the whole VMEM queue (vmcnt(0)) before an LDS store it can see while LDS-DMA writes are in flight
-        const uint32_t lbase = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned char*) (ldsB + (size_t) slot2 * GT_BTILE_BYTES);
-        const uint32_t words[4] = {PW == 4 ? r.w4[0] : r.w2[0], PW == 4 ? r.w4[1] : r.w2[1], PW == 4 ? r.w4[2] : 0u, PW == 4 ? r.w4[3] : 0u};
-#pragma unroll
-        for (int j = 0; j < PW; ++j) {
-            const f16x8 d = t16_dequant_exact(words[j], magic, zc0, zc1);
-            const uint4 u = __builtin_bit_cast(uint4, d);
-            uint4 o;
-            o.x = __builtin_bit_cast(uint32_t, as_h2(u.x) * s2); o.y = __builtin_bit_cast(uint32_t, as_h2(u.y) * s2);
-            o.z = __builtin_bit_cast(uint32_t, as_h2(u.z) * s2); o.w = __builtin_bit_cast(uint32_t, as_h2(u.w) * s2);
-            const u32x4 ov = {o.x, o.y, o.z, o.w};
-            asm volatile("ds_write_b128 %0, %1" :: "v"(lbase + (uint32_t) gt_off(b_nloc, b_rs * 4 + ph * PW + j)), "v"(ov) : "memory");
-        }
-    };
-    auto block_barrier = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wave's ds_writes are in LDS
-        __builtin_amdgcn_s_barrier();
-    };
-
-    f32x4 acc[TN][TM];                                                   // [n-tile][m-tile]
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int fr = lane & 15, fk = lane >> 4;
-    auto compute = [&](int slot3, int slot2) {
-        const unsigned char* at = lds + (size_t) slot3 * A_BYTES;
-        const unsigned char* bt = ldsB + (size_t) slot2 * GT_BTILE_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            f16x8 xf[TM], wf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) xf[i] = *(const f16x8*) (at + gt_off((wm * TM + i) * 16 + fr, kk * 4 + fk));
-#pragma unroll
-            for (int i = 0; i < TN; ++i) wf[i] = *(const f16x8*) (bt + gt_off((wn * TN + i) * 16 + fr, kk * 4 + fk));
-#pragma unroll
-            for (int in = 0; in < TN; ++in)
-#pragma unroll
-                for (int im = 0; im < TM; ++im)
-                    acc[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[in], xf[im], acc[in][im], 0, 0, 0);
-        }
-    };
-
-    // ---- prologue: batches 0 and 1 in flight, B(0) dequantised --------------------------------------------------------
-#ifdef EXL_GEMM_PROBE
-    unsigned long long p_wait = 0, p_store = 0, p_bar = 0;
-    const unsigned long long p_t0 = __builtin_readcyclecounter();
-#endif
-    BRegs rX, rY;
-    stage_a(0, 0);
-    issue_b(0, rX);
-    stage_a(1, GT_BK);                                                    // nk >= 2 always
-    issue_b(1, rY);
-    GP_WAITB(rX);                                                         // batch 0 landed (batch 1 may still fly)
-    store_b(0, rX);
-    block_barrier();
-
-    // ---- main loop, two K steps per trip (register sets X / Y swap roles); straight-line: every wait is unconditional ----
-    int a_slot = 0;                                                       // LDS ring slot of tile `it`
-    auto ring = [](int s, int d) { const int v = s + d; return v >= 3 ? v - 3 : v; };
-    int it = 0;
-    for (; it + 3 < nk; it += 2) {
-        // step it: tile it computes, B(it+1) waits in rY, batch it+2 is fetched into (ring slot + 2, rX)
-        stage_a(ring(a_slot, 2), (it + 2) * GT_BK);
-        issue_b(it + 2, rX);
-        compute(a_slot, 0);
-        GP_CLK(c0);
-        GP_WAITB(rY);                                                     // batch it+1 landed
-        GP_CLK(c1);
-        store_b(1, rY);
-        GP_CLK(c2);
-        block_barrier();
-        GP_CLK(c3);
-        GP_ACC(p_wait, c0, c1); GP_ACC(p_store, c1, c2); GP_ACC(p_bar, c2, c3);
-        a_slot = ring(a_slot, 1);
-        // step it+1: tile it+1 computes, B(it+2) waits in rX, batch it+3 is fetched into rY
-        stage_a(ring(a_slot, 2), (it + 3) * GT_BK);
-        issue_b(it + 3, rY);
-        compute(a_slot, 1);
-        GP_CLK(d0);
-        GP_WAITB(rX);                                                     // batch it+2 landed
-        GP_CLK(d1);
-        store_b(0, rX);
-        GP_CLK(d2);
-        block_barrier();
-        GP_CLK(d3);
-        GP_ACC(p_wait, d0, d1); GP_ACC(p_store, d1, d2); GP_ACC(p_bar, d2, d3);
-        a_slot = ring(a_slot, 1);
-    }
-    // ---- last two K steps: nothing left to fetch ----------------------------------------------------------------------
-    compute(a_slot, 0);
-    GP_WAIT("0", rY);
-    store_b(1, rY);
-    block_barrier();
-    a_slot = ring(a_slot, 1);
-    compute(a_slot, 1);
-#undef GP_WAITB
-#undef GP_WAIT
-#ifdef EXL_GEMM_PROBE
-    if (lane == 0 && b < 1024) {
-        unsigned long long* pp = g_gemm_probe + ((size_t) b * 8 + wave) * 4;
-        pp[0] = __builtin_readcyclecounter() - p_t0; pp[1] = p_wait; pp[2] = p_store; pp[3] = p_bar;
-    }
-#endif
-
-#pragma unroll
-    for (int im = 0; im < TM; ++im) {
-        const int row = m0 + (wm * TM + im) * 16 + fr;
-        if (row < M) {
-#pragma unroll
-            for (int in = 0; in < TN; ++in) {
-                const int n = n0 + (wn * TN + in) * 16 + fk * 4;
-                if (n < N) {
-                    f16* op = out + (size_t) row * N + n;
-                    float v[4] = {acc[in][im][0], acc[in][im][1], acc[in][im][2], acc[in][im][3]};
-                    if (no_zero) {
-                        const f16x4 prev = *(const f16x4*) op;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += (float) prev[j];
-                    }
-                    *(f16x4*) op = (f16x4){(f16) v[0], (f16) v[1], (f16) v[2], (f16) v[3]};
-                }
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// Mid-step barrier schedule of the same tile (the default).  Stall attribution of the kernel above
-// (scripts/probe_gemm.hip): of ~2100 cycles per K step only ~1000 are MFMA issue; after every barrier both waves of a
+// Mid-step barrier schedule (<= 512 rows, and the fallback of the wave-specialised kernel).  Stall attribution of its
+// predecessor, which loaded, dequantised and multiplied tile by tile (scripts/probe_gemm.hip, profiles/r01_gemm_ablation.txt):
+// of ~2100 cycles per K step only ~1000 were MFMA issue; after every barrier both waves of a
 // SIMD wait for their first fragments, and the dequant + LDS store (300 cycles) and the barrier (150-500) run with an
 // idle matrix pipe.  Here a K step is cut into two halves of 16 MFMAs and the barrier sits between the SECOND half of
 // tile t-1 and the FIRST half of tile t:
@@ -1534,27 +1145,6 @@ int launch_q4_gemm_dual(const Q4Matrix* w1, const Q4Matrix* w2, const f16* x, in
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
-static int launch_gemm_t16p(const Q4Matrix* w, const f16* xin, int rows, f16* out, int no_zero, int gshift, hipStream_t s)
-{
-    constexpr int TBM = WAVES_M * TM * 16;
-    const int K = w->height, N = w->width;
-    const int mtiles = (rows + TBM - 1) / TBM;
-    const int ntiles = (N + GT_BN - 1) / GT_BN;
-    const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
-    const size_t smem = 3 * (size_t) TBM * 128 + 2 * GT_BTILE_BYTES;
-    auto kfn = q4_gemm_t16p_kernel<WAVES_M, WAVES_N, TM, TN>;
-    static bool big = false;
-    if (smem > 64 * 1024 && !big) {
-        EXL_HIP(hipFuncSetAttribute((const void*) kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        big = true;
-    }
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(WAVES_M * WAVES_N * 64), smem, s, xin, (const uint4*) w->qweight, w->qzeros,
-                       w->scales, out, rows, K, N, gshift, w->groupsize, no_zero, mtiles, ntiles);
-    EXL_LAUNCH_CHECK();
-    return 0;
-}
-
-template <int WAVES_M, int WAVES_N, int TM, int TN>
 static int launch_gemm_t16m(const Q4Matrix* w, const f16* xin, int rows, f16* out, int no_zero, int gshift, hipStream_t s)
 {
     constexpr int TBM = WAVES_M * TM * 16;
@@ -1570,26 +1160,6 @@ static int launch_gemm_t16m(const Q4Matrix* w, const f16* xin, int rows, f16* ou
         big = true;
     }
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(WAVES_M * WAVES_N * 64), smem, s, xin, (const uint4*) w->qweight, w->qzeros,
-                       w->scales, out, rows, K, N, gshift, w->groupsize, no_zero, mtiles, ntiles);
-    EXL_LAUNCH_CHECK();
-    return 0;
-}
-
-template <int WM>
-static int launch_gemm_t16(const Q4Matrix* w, const f16* xin, int rows, f16* out, int no_zero, int gshift, hipStream_t s)
-{
-    constexpr int TBM = 64 * WM;
-    const int K = w->height, N = w->width;
-    const int mtiles = (rows + TBM - 1) / TBM;
-    const int ntiles = (N + GT_BN - 1) / GT_BN;
-    const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
-    const size_t smem = 2 * ((size_t) TBM * 128 + GT_BTILE_BYTES);
-    static bool big = false;
-    if (smem > 64 * 1024 && !big) {
-        EXL_HIP(hipFuncSetAttribute((const void*) q4_gemm_t16_kernel<WM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        big = true;
-    }
-    hipLaunchKernelGGL(q4_gemm_t16_kernel<WM>, dim3(grid), dim3(WM * 128), smem, s, xin, (const uint4*) w->qweight, w->qzeros,
                        w->scales, out, rows, K, N, gshift, w->groupsize, no_zero, mtiles, ntiles);
     EXL_LAUNCH_CHECK();
     return 0;
@@ -1615,24 +1185,13 @@ int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
     const int mtiles = (rows + BM - 1) / BM;
     const int ntiles = (N + BN - 1) / BN;
     const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
-    static const bool use_reg_b = getenv("EXL_GEMM_REGISTER_B") != nullptr;     // A/B switch for measurements
-    static const int force_wm = getenv("EXL_GEMM_WM") ? atoi(getenv("EXL_GEMM_WM")) : 0;
-    if (w->layout == EXL_LAYOUT_T16 && !use_reg_b) {
-        const bool big_tile = force_wm ? force_wm == 4 : rows > 512;      // 256-row tiles once there are enough rows to fill the chip
-        static const bool two_stage = getenv("EXL_GEMM_TWO_STAGE") != nullptr;          // A/B switch: the simpler double-buffered kernel
-        if (two_stage) return big_tile ? launch_gemm_t16<4>(w, xin, rows, out, no_zero, gshift, s) : launch_gemm_t16<2>(w, xin, rows, out, no_zero, gshift, s);
-        static const int variant = getenv("EXL_GEMM_VARIANT") ? atoi(getenv("EXL_GEMM_VARIANT")) : 0;
-        const bool mid = variant == 0 && (uint64_t) rows * (uint64_t) K < (1ull << 31);          // 32-bit activation byte offsets
-        const bool spec = mid && gshift >= 5 && (uint64_t) K * (uint64_t) N < (1ull << 32);       // loader waves: power-of-two groups, 32-bit weight offsets
-        if (!big_tile) return mid ? launch_gemm_t16m<2, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s)
-                                  : launch_gemm_t16p<2, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s);        // 128 x 128, 4 waves
+    static const bool use_reg_b = getenv("EXL_GEMM_REGISTER_B") != nullptr;     // A/B switch: the generic register-B kernel
+    static const bool no_spec = getenv("EXL_GEMM_NO_LOADER_WAVES") != nullptr;   // A/B switch: mid-step kernel for every row count
+    if (w->layout == EXL_LAYOUT_T16 && !use_reg_b && (uint64_t) rows * (uint64_t) K < (1ull << 31)) {    // 32-bit activation byte offsets
+        const bool spec = !no_spec && rows > 512 && gshift >= 5 && (uint64_t) K * (uint64_t) N < (1ull << 32);   // loader waves: power-of-two groups, 32-bit weight offsets
         if (spec) return launch_gemm_t16w(w, xin, rows, out, no_zero, gshift, s);                 // 256 x 128, 8 MFMA waves + 4 loader waves
-        if (mid || (variant == 4 && (uint64_t) rows * (uint64_t) K < (1ull << 31))) return launch_gemm_t16m<4, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s);
-        switch (variant) {                                               // measured at M = 2048 (7B layer): 812-827 / 735 / 738 TFLOP/s
-        case 2:  return launch_gemm_t16p<4, 1, 4, 8>(w, xin, rows, out, no_zero, gshift, s);               // 256 x 128, 4 waves of 64 x 128
-        case 3:  return launch_gemm_t16p<2, 2, 8, 4>(w, xin, rows, out, no_zero, gshift, s);               // 256 x 128, 4 waves of 128 x 64
-        default: return launch_gemm_t16p<4, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s);               // 256 x 128, 8 waves of 64 x 64
-        }
+        if (rows > 512) return launch_gemm_t16m<4, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s);  // 256 x 128, 8 waves
+        return launch_gemm_t16m<2, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s);                // 128 x 128, 4 waves
     }
     if (w->layout == EXL_LAYOUT_T16)
         hipLaunchKernelGGL(q4_gemm_kernel<true>, dim3(grid), dim3(256), 0, s, xin, w->qweight, w->qzeros, w->scales, out, rows, K,
