@@ -144,11 +144,13 @@ def test_7b_layer_shapes_finite_and_consistent():
 
 
 @pytest.mark.parametrize("name,gs,act,prompt,max_seq", [("tiny_hd128", 128, False, 20, 96), ("tiny_hd128_gqa", 64, True, 20, 96),
-                                                        ("tiny_hd128", 128, False, 200, 320), ("tiny_hd128_gqa", 64, True, 700, 1024)])
+                                                        ("tiny_hd128", 128, False, 200, 320), ("tiny_hd128_gqa", 64, True, 700, 1024),
+                                                        ("tiny_hd128", 128, False, 2900, 3072)])
 def test_native_decode_executor_matches_op_path_and_oracle(name, gs, act, prompt, max_seq):
     """The native decode executor (decode_fused.hip), eager and as a replayed hipGraph, against (a) the
     op-by-op fused path (q4_attn -> attention -> q4_attn_2 -> q4_mlp) and (b) the CPU oracle model.  Prompts of 20 / 200 /
-    700 tokens put the decode steps into the 1- / 4- / 16-split buckets (several splits: merged inside the o_proj kernel)."""
+    700 tokens put the decode steps into the 1- / 4- / 16-split buckets (several splits: merged inside the o_proj kernel);
+    2900 tokens make a split longer than the 160 keys one pass of the attention kernel holds (its chunk loop)."""
     from exllama_amd.model import ExLlamaCache
     model, cache, tensors, dims = _build(name, gs, act, seed=21, max_seq_len=max_seq)
     ids = torch.randint(1, dims.vocab_size, (1, prompt), generator=torch.Generator().manual_seed(4)).to("cuda:0")
