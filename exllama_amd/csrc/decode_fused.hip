@@ -905,8 +905,9 @@ static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec,
 
 // The split merge rides in the o_proj prologue when a thread owns ONE 8-dim vector of the attention output (hidden <= 4096:
 // 16 split loads = 64 registers); wider models keep it as its own kernel (with 2+ vectors per thread hipcc keeps every
-// vector's loads live and o_proj, which needs two blocks per CU from hidden 5120 on, drops to one: measured 13B 204 -> 177
-// tokens/s), where the boundary is also a smaller share of the layer.
+// vector's loads live and o_proj, which needs two blocks per CU from hidden 5120 on, drops to one; a rolled loop under a
+// 128-register cap spills instead.  Same box, 13B: 177 tokens/s folded vs 193.5 with the merge kernel; 33B: 76.9 vs 81.1),
+// where the boundary is also a smaller share of the layer.
 static bool dec_folds_merge(const Decoder* d) { return !d->separate_merge && d->h <= DEC_THREADS * 8; }
 
 // One kernel class of one layer (EXL_DEC_* in include/exl_amd.h); EXL_DEC_HEAD ignores `i`.
