@@ -668,7 +668,7 @@ class ExLlama:
         }
         self._decoder = st
         if use_graph:
-            # one captured graph per context bucket: short contexts use fewer KV splits (1 split = no merge kernel)
+            # one captured graph per context bucket: short contexts use fewer KV splits (1 split = nothing to merge)
             st["graphs"] = []
             st["bucket_splits"] = []
             start = cache.current_seq_len

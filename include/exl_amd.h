@@ -186,11 +186,13 @@ int exl_decoder_set_layer(void* decoder, int index, void* q, void* k, void* v, v
                           void* down, const void* in_norm, const void* post_norm, void* key_cache, void* value_cache);
 /* One token: reads the token id (int64) and the position (int32) from DEVICE memory, appends K/V at that position,
  * writes fp32 logits [vocab]; when advance != 0 the device position is incremented at the end of the step.
- * 6 kernels per layer + 1, no allocation, no synchronisation: capturable in a hipGraph. */
+ * 5 kernels per layer + 1 (hidden sizes above 4096 with several KV splits: 6), no allocation, no synchronisation: capturable
+ * in a hipGraph. */
 int exl_decoder_step(void* decoder, const int64_t* token_dev, int32_t* pos_dev, float* logits_out, int advance,
                      void* stream);
 /* Number of KV splits the attention kernel of subsequent steps uses (1 .. the value chosen at creation; 0 = that value).
- * One split skips the merge kernel (5 kernels per layer).  *max_context (may be NULL) receives the longest context
+ * One split writes the attention output directly; several are merged in the o_proj kernel (hidden <= 4096) or by a small
+ * kernel of their own.  *max_context (may be NULL) receives the longest context
  * (position) a step with this setting can serve.  A captured graph keeps the setting it was captured with, so a caller
  * can hold one graph per context bucket and pick by position (exllama_amd/model.py does). */
 int exl_decoder_set_kv_splits(void* decoder, int nsplit, int* max_context);
