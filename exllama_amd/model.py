@@ -19,6 +19,8 @@ test_benchmark_inference.py -- drives this class unchanged.  The implementation 
 import json
 import math
 
+import os
+
 import torch
 
 from . import cuda_ext
@@ -92,6 +94,7 @@ class ExLlamaConfig:
         self.alpha_value = 1.0
         self.gpu_peer_fix = False
         self.auto_map = None
+        self.weight_arena = True                # one allocation per device for all weight tensors (not in the reference)
 
         # tuning (reference: model.py:92-103)
         self.use_flash_attn_2 = False           # ignored: attention is always the in-tree HIP kernel
@@ -469,7 +472,11 @@ class ExLlama:
         return tensor
 
     def _place_tensors(self, tensors):
-        out = {}
+        """Casts and moves the checkpoint tensors to their devices.  With config.weight_arena (default) all tensors of a
+        device live in ONE allocation, 2 MiB-aligned each: a 33B model is ~2,000 tensors, and one contiguous range lets the
+        driver back it with its largest page fragments (TLB reach of the weight stream) instead of whatever each small
+        allocation happened to get."""
+        out, plan = {}, {}
         for key, t in tensors.items():
             if _skip_key(key):
                 continue
@@ -477,7 +484,24 @@ class ExLlama:
             if key.endswith(".g_idx"):
                 out[key] = t                                    # consumed on the host by make_q4
                 continue
-            out[key] = self._cast(key, t, device).to(device).contiguous()
+            out[key] = self._cast(key, t, device)
+            if str(device).startswith("cuda") and getattr(self.config, "weight_arena", True) and not os.environ.get("EXL_NO_WEIGHT_ARENA"):
+                plan.setdefault(str(device), []).append(key)
+            else:
+                out[key] = out[key].to(device).contiguous()
+        align = 2 << 20
+        for device, keys in plan.items():
+            sizes = [out[k].numel() * out[k].element_size() for k in keys]
+            total = sum((n + align - 1) // align * align for n in sizes)
+            arena = torch.empty(total, dtype=torch.uint8, device=device)
+            self._arenas = getattr(self, "_arenas", []) + [arena]
+            off = 0
+            for k, n in zip(keys, sizes):
+                src = out[k]
+                view = arena[off:off + n].view(src.dtype).view(src.shape)
+                view.copy_(src, non_blocking=True)
+                out[k] = view
+                off += (n + align - 1) // align * align
         return out
 
     def _load_safetensors(self):

@@ -309,3 +309,22 @@ def test_device_greedy_generation_matches_the_host_loop():
     with pytest.raises(RuntimeError):
         model.generate_greedy(first, cache, 1000)
     model.free_unmanaged()
+
+
+def test_weight_arena_is_one_allocation_and_changes_nothing():
+    """config.weight_arena (default): every device tensor of the model is a 2 MiB-aligned view into one allocation;
+    logits are bit-identical to a model loaded tensor by tensor."""
+    model, cache, tensors, dims = _build("tiny_gqa", 64, True, seed=8)
+    ids = torch.randint(1, dims.vocab_size, (1, 17), generator=torch.Generator().manual_seed(9)).to("cuda:0")
+    a = model.forward(ids, cache, last_id_only=False).cpu()
+    assert len(model._arenas) == 1
+    base, size = model._arenas[0].data_ptr(), model._arenas[0].numel()
+    lin = model.layers[1].mlp.down_proj
+    for t in (model.embed_weight, model.lm_head_weight, model.norm.weight, lin.qweight, lin.scales, lin.qzeros):
+        assert base <= t.data_ptr() < base + size and (t.data_ptr() - base) % (2 << 20) == 0
+    model.free_unmanaged()
+    model2, cache2, _, _ = _build("tiny_gqa", 64, True, seed=8, weight_arena=False)
+    assert not getattr(model2, "_arenas", [])
+    b = model2.forward(ids, cache2, last_id_only=False).cpu()
+    assert torch.equal(a, b)
+    model2.free_unmanaged()
