@@ -140,3 +140,33 @@ def test_tiny_model_golden(golden_dir):
     m2 = OracleLlama(synth.config_dict(dims), tensors, max_seq_len=64)
     step = np.concatenate([m2.forward(g["tiny_ids"][:, i:i + 1]) for i in range(g["tiny_ids"].shape[1])], axis=1)
     np.testing.assert_allclose(step, logits, rtol=0, atol=2e-2 * np.abs(logits).max())
+
+
+def test_oracle_model_lora_path():
+    """OracleLlama.set_lora (the checker of tests/test_model_gpu.py::test_lora_adapter_end_to_end): an all-zero B leaves the
+    logits unchanged bit for bit, a rank-1 adapter on one projection changes them, and OracleLinear.with_lora follows the
+    reference's order (exllama_ext.cpp:245-324): adapter product first (two fp16-rounded GEMMs), quantised product onto it."""
+    import torch
+    from exllama_amd import synth
+    from oracle.model_oracle import OracleLlama
+    dims = synth.PRESETS["tiny"]
+    tensors = synth.make_checkpoint(dims, groupsize=64, act_order=False, seed=9, device="cpu")
+    o = OracleLlama(synth.config_dict(dims), tensors, max_seq_len=32)
+    ids = np.array([[3, 5, 7, 9, 11]])
+    base = o.forward(ids, last_id_only=False)
+    g = torch.Generator().manual_seed(1)
+    key = "model.layers.0.self_attn.q_proj"
+    a = (torch.randn(dims.hidden_size, 4, generator=g) * 0.05).half()
+    zero_b = torch.zeros(4, dims.hidden_size).half()
+    o.reset(); o.set_lora({key + ".lora_A.weight": a, key + ".lora_B.weight": zero_b})
+    assert np.array_equal(o.forward(ids, last_id_only=False), base)
+    b = (torch.randn(4, dims.hidden_size, generator=g) * 0.05).half()
+    o.reset(); o.set_lora({key + ".lora_A.weight": a, key + ".lora_B.weight": b})
+    assert np.abs(o.forward(ids, last_id_only=False) - base).max() > 1e-3
+    o.reset(); o.set_lora(None)
+    assert np.array_equal(o.forward(ids, last_id_only=False), base)
+    lin = o.layers[0]["q"]
+    x = (torch.randn(3, dims.hidden_size, generator=g)).half().numpy()
+    t = (x.astype(np.float32) @ a.numpy().astype(np.float32)).astype(np.float16)
+    d = (t.astype(np.float32) @ b.numpy().astype(np.float32)).astype(np.float16)
+    assert np.array_equal(lin.with_lora(x, a.numpy(), b.numpy()), lin(x, residual=d))
