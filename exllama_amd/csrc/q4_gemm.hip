@@ -1249,11 +1249,75 @@ __global__ __launch_bounds__(256) void half_gemm_kernel(const f16* __restrict__ 
     }
 }
 
+// Same 64 x 64 tile, K step 64 with 16-byte global loads (K % 8 == 0, N % 8 == 0, 16-byte aligned pointers): the LoRA
+// down-projection x[M, hidden] @ A[hidden, r] walks a long K with a handful of blocks, so the K loop is what costs; the
+// scalar kernel above (16 k per step, 2-byte loads) stays for odd shapes.  B is transposed on its way into LDS.
+__global__ __launch_bounds__(256) void half_gemm64_kernel(const f16* __restrict__ x, const f16* __restrict__ w,
+                                                          f16* __restrict__ out, int M, int K, int N, int no_zero)
+{
+    __shared__ __attribute__((aligned(16))) f16 As[64][64 + 8];      // [m][k]
+    __shared__ __attribute__((aligned(16))) f16 Bs[64][64 + 8];      // [n][k]
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = lane >> 5, c = lane & 31;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // this thread's two 16-byte chunks of each tile: A rows ar, ar + 32 at k-chunk ac; B k-rows bk, bk + 32 at n-chunk bc
+    const int ar = tid >> 3, ac = tid & 7;
+    const int bk = tid >> 3, bc = tid & 7;
+    f16x8 ra[2], rb[2];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = m0 + ar + 32 * h, k = k0 + ac * 8;
+            ra[h] = (row < M && k < K) ? *(const f16x8*) (x + (size_t) row * K + k) : zero8;
+            const int kr = k0 + bk + 32 * h, col = n0 + bc * 8;
+            rb[h] = (kr < K && col < N) ? *(const f16x8*) (w + (size_t) kr * N + col) : zero8;
+        }
+    };
+    load(0);
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        __syncthreads();                                   // the previous step's fragment reads are done
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *(f16x8*) &As[ar + 32 * h][ac * 8] = ra[h];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Bs[bc * 8 + j][bk + 32 * h] = rb[h][j];
+        }
+        __syncthreads();
+        if (k0 + 64 < K) load(k0 + 64);                    // next tile in flight during the MFMAs
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const f16x8 af = *(const f16x8*) &As[wm * 32 + c][kk * 16 + g * 8];
+            const f16x8 bf = *(const f16x8*) &Bs[wn * 32 + c][kk * 16 + g * 8];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+        }
+    }
+    const int col = n0 + wn * 32 + c;
+    if (col >= N) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        if (row < M) {
+            float v = acc[r];
+            if (no_zero) v += (float) out[(size_t) row * N + col];
+            out[(size_t) row * N + col] = (f16) v;
+        }
+    }
+}
+
 int launch_half_gemm(const f16* x, const f16* w, f16* out, int M, int K, int N, int no_zero, hipStream_t s)
 {
     if (M <= 0 || N <= 0) return 0;
     dim3 grid((N + 63) / 64, (M + 63) / 64);
-    hipLaunchKernelGGL(half_gemm_kernel, grid, dim3(256), 0, s, x, w, out, M, K, N, no_zero);
+    const bool vec = K % 8 == 0 && N % 8 == 0 && (((uintptr_t) x | (uintptr_t) w) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(half_gemm64_kernel, grid, dim3(256), 0, s, x, w, out, M, K, N, no_zero);
+    else     hipLaunchKernelGGL(half_gemm_kernel, grid, dim3(256), 0, s, x, w, out, M, K, N, no_zero);
     EXL_LAUNCH_CHECK();
     return 0;
 }

@@ -341,7 +341,8 @@ def test_q4_matmul_lora(ce):
     _close(out.cpu().numpy(), ref, ulps=3.0)
 
 
-@pytest.mark.parametrize("M,K,N", [(1, 512, 16), (3, 64, 200), (70, 130 // 2 * 2, 96), (130, 256, 64)])
+@pytest.mark.parametrize("M,K,N", [(1, 512, 16), (3, 64, 200), (70, 130 // 2 * 2, 96), (130, 256, 64),
+                                   (1, 4096, 16), (600, 4096, 64), (600, 64, 4096), (77, 200, 72), (5, 136, 8)])    # LoRA down / up shapes, ragged K
 def test_half_matmul(ce, M, K, N):
     gen = torch.Generator().manual_seed(M * K + N)
     x = torch.randn(M, K, generator=gen).half()
