@@ -96,3 +96,101 @@ def test_rep_penalty_batch_and_bounds():
     assert logits.tolist() == [[1.0, -2.0, 1.0, -4.0], [0.5, -1.0, 2.0, -4.0]]
     with pytest.raises(RuntimeError, match="outside the vocabulary"):
         cuda_ext.ext_rep_penalty_mask_cpu(2, torch.tensor([[5]], dtype=torch.long), 1.2, -1, 0)
+
+
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference checkout not present (GPU box)")
+def test_every_reference_call_site_binds():
+    """Drop-in check at the API level: every call the reference's own model.py / generator.py / alt_generator.py make into
+    `cuda_ext` and `cuda_ext.exllama_ext` is parsed out of their source and bound (argument count and keyword names) against
+    the signature of the function this repository exports under the same name."""
+    import ast
+    import inspect
+    from exllama_amd import cuda_ext
+
+    def dotted(node):
+        parts = []
+        while isinstance(node, ast.Attribute):
+            parts.append(node.attr)
+            node = node.value
+        if isinstance(node, ast.Name):
+            parts.append(node.id)
+        return ".".join(reversed(parts))
+
+    seen = set()
+    for fname in ("model.py", "generator.py", "alt_generator.py"):
+        tree = ast.parse(open(os.path.join(REFERENCE, fname)).read())
+        for node in ast.walk(tree):
+            if not isinstance(node, ast.Call):
+                continue
+            name = dotted(node.func)
+            if name.startswith("cuda_ext.exllama_ext."):
+                target = getattr(cuda_ext.exllama_ext, name.split(".")[-1], None)
+            elif name.startswith("cuda_ext."):
+                target = getattr(cuda_ext, name.split(".")[-1], None)
+            else:
+                continue
+            assert callable(target), f"{fname}:{node.lineno}: {name} is not provided"
+            sig = inspect.signature(target)
+            try:
+                sig.bind(*[None] * len(node.args), **{k.arg: None for k in node.keywords})
+            except TypeError as e:
+                raise AssertionError(f"{fname}:{node.lineno}: {name}(...) does not bind: {e}")
+            seen.add(name)
+    # the fused decode ops, the loader and the sampler hooks are all among them
+    for must in ("cuda_ext.exllama_ext.q4_attn", "cuda_ext.exllama_ext.q4_attn_2", "cuda_ext.exllama_ext.q4_mlp",
+                 "cuda_ext.exllama_ext.prepare_buffers", "cuda_ext.ext_make_q4", "cuda_ext.ext_q4_matmul",
+                 "cuda_ext.ext_apply_rep_penalty_mask_cpu"):
+        assert must in seen, must
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference checkout not present (GPU box)")
+def test_reference_generator_and_harness_calls_bind_to_model_api():
+    """Same check one level up: what the reference's generator.py / alt_generator.py / perplexity.py /
+    test_benchmark_inference.py call on the model and the cache (`self.model.forward(...)`, `cache.copy_states(...)`, ...) binds
+    to exllama_amd.model's classes, and the config fields they read exist."""
+    import ast
+    import inspect
+    from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
+    from exllama_amd import synth
+
+    def dotted(node):
+        parts = []
+        while isinstance(node, ast.Attribute):
+            parts.append(node.attr)
+            node = node.value
+        if isinstance(node, ast.Name):
+            parts.append(node.id)
+        return ".".join(reversed(parts))
+
+    cfg = ExLlamaConfig(synth.config_dict(synth.LLAMA_TINY))
+    owners = {"model": ExLlama, "cache": ExLlamaCache}
+    calls, fields = set(), set()
+    for fname in ("generator.py", "alt_generator.py", "perplexity.py", "test_benchmark_inference.py"):
+        tree = ast.parse(open(os.path.join(REFERENCE, fname)).read())
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Call):
+                parts = dotted(node.func).split(".")
+                if parts[0] == "self":
+                    parts = parts[1:]
+                if len(parts) == 2 and parts[0] in owners:
+                    fn = getattr(owners[parts[0]], parts[1], None)
+                    assert callable(fn), f"{fname}:{node.lineno}: {'.'.join(parts)} is not provided"
+                    try:
+                        inspect.signature(fn).bind(None, *[None] * len(node.args), **{k.arg: None for k in node.keywords})
+                    except TypeError as e:
+                        raise AssertionError(f"{fname}:{node.lineno}: {'.'.join(parts)}(...) does not bind: {e}")
+                    calls.add(".".join(parts))
+            elif isinstance(node, ast.Attribute):
+                parts = dotted(node).split(".")
+                if "config" in parts[:-1] and parts[-2] == "config":
+                    assert hasattr(cfg, parts[-1]), f"{fname}:{node.lineno}: config.{parts[-1]} missing"
+                    fields.add(parts[-1])
+    assert {"model.forward", "cache.clone", "cache.roll_left", "cache.copy_states"} <= calls, calls
+    assert {"max_seq_len", "vocab_size", "matmul_recons_thd"} <= fields, fields
+    # constructor forms used by the reference: ExLlamaCache(model), ExLlamaCache(model, batch_size = n), ExLlamaCache(model, copy_from = c)
+    sig = inspect.signature(ExLlamaCache.__init__)
+    for kw in ({}, {"batch_size": 2}, {"copy_from": None}, {"max_seq_len": 8}):
+        sig.bind(None, None, **kw)
