@@ -194,3 +194,29 @@ def test_reference_generator_and_harness_calls_bind_to_model_api():
     sig = inspect.signature(ExLlamaCache.__init__)
     for kw in ({}, {"batch_size": 2}, {"copy_from": None}, {"max_seq_len": 8}):
         sig.bind(None, None, **kw)
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference checkout not present (GPU box)")
+def test_reference_modules_import_against_the_shim():
+    """With this repository ahead of the reference on PYTHONPATH, the reference's OWN model.py, generator.py, lora.py,
+    perplexity.py and model_init.py import (their module-level `import cuda_ext` resolves to our shim) and their config /
+    argument plumbing runs; only constructing the model needs a HIP device."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import json, tempfile, os, argparse\n"
+        "import cuda_ext, model, lora, generator, perplexity, model_init\n"
+        "assert cuda_ext.__file__.startswith(%r) and model.__file__.startswith(%r)\n"
+        "from exllama_amd import synth\n"
+        "d = tempfile.mkdtemp(); p = os.path.join(d, 'config.json')\n"
+        "json.dump(synth.config_dict(synth.LLAMA_TINY), open(p, 'w'))\n"
+        "ap = argparse.ArgumentParser(); model_init.add_args(ap); perplexity.add_args(ap)\n"
+        "a = ap.parse_args(['-t', 'tok', '-c', p, '-m', 'w.safetensors', '-l', '512']); model_init.post_parse(a)\n"
+        "c = model_init.make_config(a)\n"
+        "assert c.max_seq_len == 512 and c.hidden_size == synth.LLAMA_TINY.hidden_size\n"
+        "c.set_tuning_params()\n"                       # reference code path: cuda_ext.exllama_ext.set_tuning_params(...) -> exl_set_tuning
+        "print('OK')\n" % (root, REFERENCE))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + REFERENCE)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stderr[-2000:]
