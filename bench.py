@@ -20,6 +20,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -178,7 +180,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("EXL_BENCH_FORCE_DIST"):        # the env switch exercises the RCCL code path with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
