@@ -274,3 +274,22 @@ def test_lora_loader(tmp_path):
     for c, tensors in bad:
         with pytest.raises(ValueError):
             ExLlamaLora(m, c, "x.bin", tensors=tensors)
+
+
+# ---- bench.py: the algorithmic byte / FLOP counts behind the roofline numbers equal SURVEY.md 8d --------------------------
+def test_bench_algorithmic_counts_match_the_survey_table():
+    import bench
+    table = {  # model: (groupsize, decode GB at ctx 0, decode GB at ctx 2048, prefill TFLOP at S = 1920, at S = 2048)
+        "7b": (128, 3.627, 4.701, 26.80, 28.73), "13b": (128, 6.920, 8.598, 51.74, 55.41),
+        "33b": (32, 18.987, 22.26, 129.2, 138.2), "65b": (128, 34.172, 39.54, 258.3, 276.3)}
+    for name, (g, b0, b2048, f1920, f2048) in table.items():
+        d = synth.PRESETS[name]
+        assert bench.decode_bytes_per_token(d, g, 0) / 1e9 == pytest.approx(b0, abs=6e-3)
+        assert bench.decode_bytes_per_token(d, g, 2048) / 1e9 == pytest.approx(b2048, rel=1e-3)
+        assert bench.prefill_flops(d, 1920) / 1e12 == pytest.approx(f1920, rel=1e-3)
+        assert bench.prefill_flops(d, 2048) / 1e12 == pytest.approx(f2048, rel=1e-3)
+    # per-matmul bytes: K N / 2 + (K / g) N 2.5 + 2 M (K + N); the 7B gate + up pair of the decode step
+    per = 2 * bench.algorithmic_bytes_per_matmul(4096, 11008, 128, M=1)
+    assert per == pytest.approx(46.9e6, rel=2e-3)
+    r = bench.whole_job_rates(4, 2048, 128, prefill_ms=20.0, worst_ms=200.0, best_ms=100.0)
+    assert r == {"prefill": pytest.approx(4 * 2048 / 0.02), "worst": pytest.approx(4 * 128 / 0.2), "best": pytest.approx(4 * 128 / 0.1)}
