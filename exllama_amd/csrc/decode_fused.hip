@@ -52,7 +52,96 @@ struct DecGemvArgs {
     int rb_per_wave;
     int xs_images;                // 1, or 2 when gate and up carry different act-order maps (EMODE 2)
     int ablate;                   // measurement only (EXL_DEC_ABLATE): 1 = skip the dequant + MFMA work, 2 = also skip the norm
+    int nblocks;                  // = gridDim.x (passed explicitly: the implicit-argument load is one more scalar round trip)
+    int units_lo, units_rem;      // unit count per block: units_lo + (block < units_rem)
 };
+
+// Every field of a matrix view the streaming loop touches, forced into SGPRs at the top of the kernel: the compiler
+// otherwise indexes the kernarg segment dynamically (a.mat[mi] with a computed mi), i.e. issues a scalar load, waits,
+// computes, issues the next -- six dependent round trips to a cold scalar cache (~1.4 us) before the first weight load.
+#define DEC_PIN_S(x) asm volatile("" : "+s"(x))
+// pointers: pinned as integers and rebuilt as GLOBAL pointers (an opaque generic pointer would turn every access into a
+// flat_load, which counts against both the vector-memory and the LDS wait counters)
+template <typename T>
+__device__ __forceinline__ T* dec_pin_ptr(T* p)
+{
+    uint64_t v = (uint64_t) p;
+    asm volatile("" : "+s"(v));
+    return (T*) (T __attribute__((address_space(1)))*) v;
+}
+__device__ __forceinline__ void dec_pin(T16Matrix& m)
+{
+    m.qw = dec_pin_ptr(m.qw); m.qzeros = dec_pin_ptr(m.qzeros); m.scales = dec_pin_ptr(m.scales); m.x_map = dec_pin_ptr(m.x_map);
+    DEC_PIN_S(m.N); DEC_PIN_S(m.RB); DEC_PIN_S(m.gprows); DEC_PIN_S(m.gshift);
+}
+// One wave's share of one 16-column tile.  Everything here is wave-uniform (SGPRs): a weight load is
+// (uniform base + uniform row-block offset) + lane * 16 bytes -- the saddr form, one VALU instruction for all of them.
+struct DecUnit {
+    const uint4* base;              // tile base (piece 0 of row-block 0)
+    int rb0, rb1, rbsafe;           // row-block range [rb0, rb1); rbsafe: a valid row-block for clamped addresses
+    int n0;                         // first column of the tile
+};
+__device__ __forceinline__ DecUnit dec_unit(const T16Matrix& m, int t, int rb_begin, int rb_end)
+{
+    DecUnit u;
+    u.base = m.qw + (size_t) (uint32_t) t * (uint32_t) m.RB * 64u;
+    u.rb0 = rb_begin; u.rb1 = rb_end < rb_begin ? rb_begin : rb_end;
+    u.rbsafe = min(rb_begin, m.RB - 1);
+    u.n0 = t * 16;
+    return u;
+}
+// G16 entries of a unit: slot h holds the entry of row-block rb0 + 4h + rsub
+template <int NSLOT>
+__device__ __forceinline__ void dec_unit_entries(const T16Matrix& m, const DecUnit& u, int lane, uint32_t (&ent)[NSLOT])
+{
+    const int rsub = lane >> 4, n = u.n0 + (lane & 15);
+#pragma unroll
+    for (int h = 0; h < NSLOT; ++h) {
+        const int rb = min(u.rb0 + 4 * h + rsub, m.RB - 1);
+        const uint32_t e = t16_load_entry(m, t16_group_of_row(m, rb * 16), n);
+        ent[h] = (u.rb0 + 4 * h + rsub < u.rb1) ? e : 0u;               // rows past the range: scale 0 -> contribute nothing
+    }
+}
+template <int U, bool G16>
+__device__ __forceinline__ void dec_unit_issue(const T16Matrix& m, const DecUnit& u, int pass, uint32_t lane, uint4 (&wv)[U],
+                                               uint32_t (&entp)[U])
+{
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int rb = u.rb0 + pass * U + i;
+        const int rbc = rb < u.rb1 ? rb : u.rbsafe;                     // uniform
+        if constexpr (!G16) {
+            const uint32_t e = t16_load_entry(m, t16_group_of_row(m, rbc * 16 + (int) (lane >> 4) * 4), u.n0 + (int) (lane & 15));
+            entp[i] = rb < u.rb1 ? e : 0u;
+        }
+        wv[i] = nt_load16(u.base + (size_t) (uint32_t) rbc * 64u + lane);
+    }
+}
+template <int U, bool G16, int NSLOT>
+__device__ __forceinline__ void dec_unit_consume(const DecUnit& u, int pass, int lane, const uint4 (&wv)[U],
+                                                 const uint32_t (&ent)[NSLOT], const uint32_t (&entp)[U], const uint4* xrow,
+                                                 f32x4& c)
+{
+    const uint32_t magic = t16_magic();
+    const int col = lane & 15, rsub = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int li = pass * U + i;
+        const int rb = u.rb0 + li;
+        const int rbc = rb < u.rb1 ? rb : u.rbsafe;                     // branch-free: out-of-range row-blocks carry scale 0
+        uint32_t e;
+        if constexpr (G16) e = (uint32_t) __shfl((int) ent[(li >> 2) < NSLOT ? (li >> 2) : 0], ((li & 3) << 4) | col, 64);
+        else e = entp[i];
+        t16_rowblock<G16>(wv[i], e, magic, xrow + rbc * 16 + rsub * 4, c);
+    }
+}
+__device__ __forceinline__ T16Matrix dec_pick(const T16Matrix& m0, const T16Matrix& m1, const T16Matrix& m2, int mi)
+{
+    T16Matrix m = m0;                                                // mi is wave-uniform: scalar selects
+    if (mi == 1) m = m1;
+    if (mi == 2) m = m2;
+    return m;
+}
 
 __device__ __forceinline__ f16 silu_mul_f16(f16 x, f16 y)
 {
@@ -90,22 +179,32 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
     constexpr int NSLOT = G16 ? (U * NP + 3) / 4 : 1;
     constexpr int WPT = EMODE == 2 ? DEC_WAVES / 2 : DEC_WAVES;      // waves per tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int K = a.mat[0].K, R = a.mat[0].R, RB = a.mat[0].RB;
+    // ---- 0. every kernel argument the start-up path needs, requested as ONE batch of scalar loads -----------------
+    T16Matrix M0 = a.mat[0], M1 = a.mat[1], M2 = a.mat[2];
+    dec_pin(M0); dec_pin(M1); dec_pin(M2);
+    int K = M0.K, R = M0.R;
+    const f16* a_vec = dec_pin_ptr(a.vec); const f16* a_norm_w = dec_pin_ptr(a.norm_w); const int64_t* a_tok = dec_pin_ptr(a.tok);
+    int te0 = a.tile_end[0], te1 = a.tile_end[1], te2 = a.tile_end[2], a_nmat = a.nmat;
+    int a_rbw = a.rb_per_wave, a_images = a.xs_images, nb = a.nblocks, units_lo = a.units_lo, units_rem = a.units_rem;
+    DEC_PIN_S(K); DEC_PIN_S(R);
+    DEC_PIN_S(te0); DEC_PIN_S(te1); DEC_PIN_S(te2); DEC_PIN_S(a_nmat); DEC_PIN_S(a_rbw); DEC_PIN_S(a_images);
+    DEC_PIN_S(nb); DEC_PIN_S(units_lo); DEC_PIN_S(units_rem);
+    const int RB = M0.RB;
     uint4* xs = (uint4*) smem;                                       // [xs_images][R]
-    float* red = (float*) (smem + (size_t) a.xs_images * R * 16);    // [2][DEC_WAVES][16] + [DEC_WAVES]
+    float* red = (float*) (smem + (size_t) a_images * R * 16);       // [2][DEC_WAVES][16] + [DEC_WAVES]
     constexpr int RED_FLOATS = 2 * DEC_WAVES * 16 + DEC_WAVES;
-    f16* xlin = (f16*) (smem + (size_t) a.xs_images * R * 16 + RED_FLOATS * sizeof(float));   // [K], act-order only
+    f16* xlin = (f16*) (smem + (size_t) a_images * R * 16 + RED_FLOATS * sizeof(float));   // [K], act-order only
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rsub = lane >> 4;
-    const int nunits = a.tile_end[EMODE == 2 ? 0 : a.nmat - 1];
-    const int nb = gridDim.x, b = blockIdx.x;
-    const int n_my = (nunits - b + nb - 1) / nb;
+    const int nunits = EMODE == 2 ? te0 : (a_nmat == 1 ? te0 : a_nmat == 2 ? te1 : te2);
+    const int b = blockIdx.x;
+    const int n_my = units_lo + (b < units_rem ? 1 : 0);             // = ceil((nunits - b) / nb), divided on the host
     const bool remap = (nunits & 7) == 0 && (nb & 7) == 0;           // XCD x (= b % 8) walks one contiguous eighth of the tiles
     const int per = nunits >> 3;
-    const int rb_lo = (wave % WPT) * a.rb_per_wave;
-    const int rb_hi = min(RB, rb_lo + a.rb_per_wave);
+    const int rb_lo = (wave % WPT) * a_rbw;
+    const int rb_hi = min(RB, rb_lo + a_rbw);
 
     // unit i of this block -> (matrix, tile) of this wave
     auto describe = [&](int i, int& mi, int& tile) {
@@ -115,16 +214,15 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
         if constexpr (EMODE == 2) {
             mi = wave / WPT;                                         // waves 0-3: gate tile g, waves 4-7: up tile g
         } else {
-#pragma unroll
-            for (int k = 0; k < DEC_MAX_MATS - 1; ++k)
-                if (mi == k && k + 1 < a.nmat && g >= a.tile_end[k]) { mi = k + 1; tile = g - a.tile_end[k]; }
+            if (a_nmat > 1 && g >= te0) { mi = 1; tile = g - te0; }
+            if (a_nmat > 2 && g >= te1) { mi = 2; tile = g - te1; }
         }
     };
 
     // ---- 1. prologue loads ------------------------------------------------------------------------------------
     const int nvec = K >> 3;
-    const f16* src = a.vec;
-    if constexpr (PNORM == 1) { if (a.tok) src = a.vec + (size_t) (*a.tok) * K; }
+    const f16* src = a_vec;
+    if constexpr (PNORM == 1) { if (a_tok) src = a_vec + (size_t) (*a_tok) * K; }
     uint4 xraw[NV], wraw[NV];
     constexpr int MS = PNORM == 3 ? DEC_MAX_NSPLIT : 1;
     uint4 praw[MS];                                                  // PNORM 3: this thread's 8 dims of every split's output (one vector at a time)
@@ -147,21 +245,23 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
             const int idx = tid + i * DEC_THREADS;
             const int ci = idx < nvec ? idx : 0;
             xraw[i] = *(const uint4*) (src + ci * 8);
-            if constexpr (PNORM == 1) wraw[i] = *(const uint4*) (a.norm_w + ci * 8);
+            if constexpr (PNORM == 1) wraw[i] = *(const uint4*) (a_norm_w + ci * 8);
         }
     }
     // ---- 2. first unit's weight stream ----------------------------------------------------------------------
     uint4 wv0[U], wv1[U];
     uint32_t ep0[U], ep1[U];
     uint32_t entA[NSLOT], entB[NSLOT];
-    T16Unit uA, uB;
+    DecUnit uA, uB;
+    T16Matrix mA, mB;
     int miA = 0, miB = 0, tileA = 0, tileB = 0;
     float resA = 0.f, resB = 0.f;                                    // EMODE 1: residual value of this thread's column
     describe(0, miA, tileA);
-    uA = t16_unit(a.mat[miA], tileA, lane, rb_lo, rb_hi);
-    if constexpr (G16) t16_unit_entries<NSLOT>(a.mat[miA], uA, rsub, entA);
+    mA = dec_pick(M0, M1, M2, miA); mB = mA;
+    uA = dec_unit(mA, tileA, rb_lo, rb_hi);
+    dec_unit_issue<U, G16>(mA, uA, 0, lane, wv0, ep0);               // weights first: their addresses are scalar arithmetic + one VALU
+    if constexpr (G16) dec_unit_entries<NSLOT>(mA, uA, lane, entA);
     if constexpr (EMODE == 1) { if (tid < 16) resA = (float) a.hid_io[tileA * 16 + tid]; }
-    t16_unit_issue<U, G16>(a.mat[miA], uA, 0, rsub, wv0, ep0);
 
     SP_CLK(0);                                                       // prologue loads + first weight batch issued
     // ---- 3. activation image (once per block) ---------------------------------------------------------------
@@ -173,7 +273,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
             const int idx = tid + i * DEC_THREADS;
             xv[i] = __builtin_bit_cast(f16x8, xraw[i]);
             if (idx < nvec) {
-                if (a.tok && a.hid_copy && b == 0) *(f16x8*) (a.hid_copy + idx * 8) = xv[i];
+                if (a_tok && a.hid_copy && b == 0) *(f16x8*) (a.hid_copy + idx * 8) = xv[i];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float f = (float) xv[i][j]; ss = fmaf(f, f, ss); }
             }
@@ -222,7 +322,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
 #pragma unroll
         for (int i = 0; i < NV; ++i) xv[i] = __builtin_bit_cast(f16x8, xraw[i]);
     }
-    const bool gather = a.mat[0].x_map != nullptr;                   // all matrices of a launch agree (checked on the host)
+    const bool gather = M0.x_map != nullptr;                         // all matrices of a launch agree (checked on the host)
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = tid + i * DEC_THREADS;
@@ -235,9 +335,10 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
     if (gather) {                                                    // act-order: one image per matrix (each has its own x_map)
         if constexpr (EMODE == 2) {                                  // gate image built by waves 0-3, up image by waves 4-7
             const int mi = wave / WPT;
-            t16_stage_from_lds(xlin, a.mat[mi].x_map, R, xs + (size_t) mi * R, tid % (WPT * 64), WPT * 64);
+            t16_stage_from_lds(xlin, mi ? M1.x_map : M0.x_map, R, xs + (size_t) mi * R, tid % (WPT * 64), WPT * 64);
         } else {
-            for (int k = 0; k < a.xs_images; ++k) t16_stage_from_lds(xlin, a.mat[k].x_map, R, xs + (size_t) k * R, tid, DEC_THREADS);
+            for (int k = 0; k < a_images; ++k)
+                t16_stage_from_lds(xlin, k == 0 ? M0.x_map : k == 1 ? M1.x_map : M2.x_map, R, xs + (size_t) k * R, tid, DEC_THREADS);
         }
         __syncthreads();
     }
@@ -246,24 +347,24 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
     // ---- 4. walk the tiles ----------------------------------------------------------------------------------
 #define DEC_BUF(k) (((k) & 1) ? wv1 : wv0)
 #define DEC_EP(k)  (((k) & 1) ? ep1 : ep0)
-#define DEC_UNIT_BODY(P, uC, miC, tileC, entC, resC, uN, miN, tileN, entN, resN)                                            \
+#define DEC_UNIT_BODY(P, uC, mC, miC, tileC, entC, resC, uN, mN, miN, tileN, entN, resN)                                    \
     {                                                                                                                       \
         const int i = 2 * j + P;                                                                                            \
         if (i >= n_my) break;                                                                                               \
         const bool have_next = i + 1 < n_my;                                                                                \
-        if (have_next) { describe(i + 1, miN, tileN); uN = t16_unit(a.mat[miN], tileN, lane, rb_lo, rb_hi); }               \
-        const uint4* xrow = xs + (a.xs_images > 1 ? (size_t) miC * R : 0);                                                  \
+        if (have_next) { describe(i + 1, miN, tileN); mN = dec_pick(M0, M1, M2, miN); uN = dec_unit(mN, tileN, rb_lo, rb_hi); } \
+        const uint4* xrow = xs + (a_images > 1 ? (size_t) miC * R : 0);                                                     \
         f32x4 c = {0.f, 0.f, 0.f, 0.f};                                                                                     \
         _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                                                    \
             if (p + 1 < NP) {                                                                                               \
-                if (uC.rb0 + (p + 1) * U < uC.rb1) t16_unit_issue<U, G16>(a.mat[miC], uC, p + 1, rsub, DEC_BUF(P * NP + p + 1), DEC_EP(P * NP + p + 1)); \
+                if (uC.rb0 + (p + 1) * U < uC.rb1) dec_unit_issue<U, G16>(mC, uC, p + 1, lane, DEC_BUF(P * NP + p + 1), DEC_EP(P * NP + p + 1)); \
             } else if (have_next) {                                                                                         \
-                if constexpr (G16) t16_unit_entries<NSLOT>(a.mat[miN], uN, rsub, entN);                                     \
+                if constexpr (G16) dec_unit_entries<NSLOT>(mN, uN, lane, entN);                                             \
                 if constexpr (EMODE == 1) { if (tid < 16) resN = (float) a.hid_io[tileN * 16 + tid]; }                      \
-                t16_unit_issue<U, G16>(a.mat[miN], uN, 0, rsub, DEC_BUF((P ^ 1) * NP), DEC_EP((P ^ 1) * NP));               \
+                dec_unit_issue<U, G16>(mN, uN, 0, lane, DEC_BUF((P ^ 1) * NP), DEC_EP((P ^ 1) * NP));                       \
             }                                                                                                               \
             if (a.ablate) { _Pragma("unroll") for (int q = 0; q < U; ++q) c[0] += __builtin_bit_cast(float, DEC_BUF(P * NP + p)[q].x ^ DEC_BUF(P * NP + p)[q].w); } \
-            else if (uC.rb0 + p * U < uC.rb1) t16_unit_consume<U, G16, NSLOT>(uC, p, lane, DEC_BUF(P * NP + p), entC, DEC_EP(P * NP + p), xrow, c); \
+            else if (uC.rb0 + p * U < uC.rb1) dec_unit_consume<U, G16, NSLOT>(uC, p, lane, DEC_BUF(P * NP + p), entC, DEC_EP(P * NP + p), xrow, c); \
         }                                                                                                                   \
         if (i == 0) SP_CLK(2);                                                                                              \
         float* rp = red + P * DEC_WAVES * 16;                                                                               \
@@ -285,8 +386,8 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
         }                                                                                                                   \
     }
     for (int j = 0;; ++j) {
-        DEC_UNIT_BODY(0, uA, miA, tileA, entA, resA, uB, miB, tileB, entB, resB)
-        DEC_UNIT_BODY(1, uB, miB, tileB, entB, resB, uA, miA, tileA, entA, resA)
+        DEC_UNIT_BODY(0, uA, mA, miA, tileA, entA, resA, uB, mB, miB, tileB, entB, resB)
+        DEC_UNIT_BODY(1, uB, mB, miB, tileB, entB, resB, uA, mA, miA, tileA, entA, resA)
     }
     SP_CLK(4);                                                       // all units done
 #ifdef EXL_ATTN_PROBE
@@ -692,6 +793,9 @@ __global__ __launch_bounds__(1024) void dec_argmax_kernel(const float2* __restri
     }
 }
 
+// A decoder stage without the head kernel advances the device-side position itself.
+__global__ void dec_advance_kernel(int32_t* pos_dev) { *pos_dev += 1; }
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
@@ -716,6 +820,8 @@ struct Decoder {
     int nsplit_max;
     int max_blocks;               // persistent GEMV grid: blocks per CU x CUs
     void* block;                  // one hipMalloc
+    bool has_embed() const { return embed != nullptr; }
+    bool has_head() const { return lm_head != nullptr; }
 };
 #define DEC_MAGIC 0x44454332u
 
@@ -730,7 +836,12 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     EXL_REQUIRE(hidden % 128 == 0 && hidden == heads * head_dim && heads % kv_heads == 0, EXL_E_UNSUPPORTED, "decoder: bad head geometry");
     EXL_REQUIRE(inter % 128 == 0, EXL_E_UNSUPPORTED, "decoder: intermediate size must be a multiple of 128 (got %d)", inter);
     EXL_REQUIRE(hidden <= 8192 && inter <= 24576, EXL_E_UNSUPPORTED, "decoder: hidden (%d) / intermediate (%d) size too large", hidden, inter);
-    EXL_REQUIRE(embed && final_norm && lm_head && sin && cos, EXL_E_INVALID, "decoder_create: null pointer");
+    // A decoder may be one STAGE of a layer-split model (reference: ExLlamaDeviceMap, model.py:636-668): embed == NULL ->
+    // the step reads the residual stream the caller put into exl_decoder_hidden(); lm_head == NULL -> no final norm / head,
+    // the residual stream is left there for the next stage.
+    EXL_REQUIRE(sin && cos, EXL_E_INVALID, "decoder_create: null pointer");
+    EXL_REQUIRE((final_norm != nullptr) == (lm_head != nullptr), EXL_E_INVALID, "decoder_create: final_norm and lm_head go together");
+    EXL_REQUIRE(n_layers >= 1, EXL_E_INVALID, "decoder_create: a decoder needs at least one layer");
     Decoder* d = new Decoder();
     d->magic = DEC_MAGIC;
     d->device = device; d->L = n_layers; d->h = hidden; d->inter = inter; d->heads = heads; d->kv_heads = kv_heads;
@@ -835,22 +946,38 @@ extern "C" int exl_decoder_free(void* dec)
     return 0;
 }
 
+// exl_decoder_plan: when set, the launch helpers record the configuration they would launch and return without launching
+static thread_local int* g_plan = nullptr;
+
 // (U, NP) by row-blocks per wave; G16 by group size; NV by K
 template <int PNORM, int EMODE, int NV>
 static int launch_dec_gemv_cfg(bool g16, int rbw, dim3 grid, size_t smem, hipStream_t s, const DecGemvArgs& a)
 {
+    // The opt-in for more than 64 KiB of dynamic LDS is a per-device function attribute: tracked per (kernel, device).
 #define DEC_LAUNCH1(U, NP, G) do { auto kfn = dec_stream_kernel<U, NP, G, PNORM, EMODE, NV>;                                   \
-        static bool big = false;                                                                                              \
-        if (smem > 64 * 1024 && !big) {               /* more than the default dynamic-LDS limit: opt in once */              \
-            EXL_HIP(hipFuncSetAttribute((const void*) kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));          \
-            big = true;                                                                                                       \
+        if (g_plan) { g_plan[0] = 1; g_plan[1] = U; g_plan[2] = NP; g_plan[3] = G ? 1 : 0; g_plan[4] = PNORM; g_plan[5] = EMODE;  \
+                      g_plan[6] = NV; g_plan[7] = (int) grid.x; g_plan[8] = (int) smem; g_plan[9] = a.xs_images; return 0; }    \
+        static bool big[EXL_MAX_DEVICES] = {};                                                                                \
+        int dev_ = 0;                                                                                                         \
+        if (smem > 64 * 1024) {                       /* more than the default dynamic-LDS limit: opt in once per device */   \
+            EXL_HIP(hipGetDevice(&dev_));                                                                                     \
+            if (dev_ >= 0 && dev_ < EXL_MAX_DEVICES && !big[dev_]) {                                                          \
+                EXL_HIP(hipFuncSetAttribute((const void*) kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      \
+                big[dev_] = true;                                                                                             \
+            }                                                                                                                 \
         }                                                                                                                     \
         hipLaunchKernelGGL(kfn, grid, dim3(DEC_THREADS), smem, s, a); } while (0)
 #define DEC_LAUNCH(U, NP) do { if (g16) DEC_LAUNCH1(U, NP, true); else DEC_LAUNCH1(U, NP, false); } while (0)
+#ifdef EXL_DEC_FAST_BUILD                                            /* ISA inspection builds: 7B instantiations only */
+    if (rbw <= 4)       DEC_LAUNCH1(4, 1, true);
+    else if (rbw <= 8)  DEC_LAUNCH1(4, 2, true);
+    else                DEC_LAUNCH1(6, 2, true);
+#else
     if (rbw <= 4)       DEC_LAUNCH(4, 1);
     else if (rbw <= 8)  DEC_LAUNCH(4, 2);
     else if (rbw <= 12) DEC_LAUNCH(6, 2);
     else                DEC_LAUNCH(6, 4);
+#endif
 #undef DEC_LAUNCH
 #undef DEC_LAUNCH1
     EXL_LAUNCH_CHECK();
@@ -897,8 +1024,15 @@ static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec,
         EXL_REQUIRE((mats[i]->x_map == nullptr) == (mats[0]->x_map == nullptr), EXL_E_UNSUPPORTED,
                     "decoder: matrices fused into one launch must agree on act-order");
     dim3 grid(tiles < max_blocks ? tiles : max_blocks);
+    a.nblocks = (int) grid.x;
+    a.units_lo = tiles / (int) grid.x;
+    a.units_rem = tiles % (int) grid.x;
+#ifdef EXL_DEC_FAST_BUILD
+#define DEC_NV(P, E) (nv <= 1 ? launch_dec_gemv_cfg<P, E, 1>(g16, rbw, grid, smem, s, a) : launch_dec_gemv_cfg<P, E, 3>(g16, rbw, grid, smem, s, a))
+#else
 #define DEC_NV(P, E) (nv <= 1 ? launch_dec_gemv_cfg<P, E, 1>(g16, rbw, grid, smem, s, a) : nv <= 2 ? launch_dec_gemv_cfg<P, E, 2>(g16, rbw, grid, smem, s, a) \
                       : nv <= 3 ? launch_dec_gemv_cfg<P, E, 3>(g16, rbw, grid, smem, s, a) : launch_dec_gemv_cfg<P, E, 6>(g16, rbw, grid, smem, s, a))
+#endif
     if (pnorm == 1 && emode == 0) return DEC_NV(1, 0);
     if (pnorm == 1 && emode == 2) return DEC_NV(1, 2);
     if (pnorm == 0 && emode == 1) return DEC_NV(0, 1);
@@ -923,13 +1057,15 @@ static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int3
     case EXL_DEC_QKV: {
         Q4Matrix* qkv[3] = {l.q, l.k, l.v};
         f16* qkv_out[3] = {d->qbuf, d->kbuf, d->vbuf};
-        const f16* xin = i == 0 ? d->embed : d->hid;
-        const int64_t* tk = i == 0 ? token_dev : nullptr;
-        f16* hc = i == 0 ? d->hid : nullptr;
+        const bool emb = i == 0 && d->has_embed();                   // later stages of a layer split start from d->hid
+        const f16* xin = emb ? d->embed : d->hid;
+        const int64_t* tk = emb ? token_dev : nullptr;
+        f16* hc = emb ? d->hid : nullptr;
         return launch_dec_gemv(d->max_blocks, 1, 0, xin, tk, l.in_norm, d->eps, hc, 3, qkv, qkv_out, nullptr, s);
     }
     case EXL_DEC_ATTN: {
         const float scale = 1.0f / sqrtf((float) d->hd);
+        if (g_plan) { g_plan[0] = 1; g_plan[1] = d->nsplit; g_plan[7] = d->nsplit * d->heads; return 0; }
         if (d->nsplit == 1)
             hipLaunchKernelGGL(dec_attn_kernel<true>, dim3(d->heads), dim3(256), 0, s, d->qbuf, d->kbuf, d->vbuf, l.kc, l.vc, d->sin, d->cos,
                                d->partial, pos_dev, d->heads, d->kv_heads, d->max_seq, 1, scale, d->attn_out);
@@ -942,6 +1078,7 @@ static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int3
     case EXL_DEC_MERGE:
         // the split merge runs inside the o_proj kernel's prologue (PNORM 3); the stand-alone kernel is the A/B reference
         if (d->nsplit == 1 || dec_folds_merge(d)) return 0;
+        if (g_plan) { g_plan[0] = 1; g_plan[1] = d->nsplit; g_plan[7] = d->heads; return 0; }
         hipLaunchKernelGGL(dec_attn_merge_kernel, dim3(d->heads), dim3(128), 0, s, d->partial, d->attn_out, d->nsplit, d->heads);
         EXL_LAUNCH_CHECK();
         return 0;
@@ -962,8 +1099,10 @@ static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int3
         return launch_dec_gemv(d->max_blocks, 0, 1, d->act, nullptr, nullptr, 0.f, nullptr, 1, dm, nullptr, d->hid, s);
     }
     case EXL_DEC_HEAD: {
+        if (!d->has_head()) return 0;
         const int rows_per_block = 32;
         const int blocks = (d->vocab + rows_per_block - 1) / rows_per_block;
+        if (g_plan) { g_plan[0] = 1; g_plan[7] = blocks; return 0; }
         const size_t smem = (size_t) d->h * 2 + 8 * sizeof(float);
         hipLaunchKernelGGL(dec_head_kernel, dim3(blocks), dim3(256), smem, s, d->hid, d->final_norm, d->eps, d->h, d->lm_head,
                            d->vocab, logits_out, rows_per_block, pos_dev, advance, d->head_best);
@@ -979,7 +1118,7 @@ extern "C" int exl_decoder_step(void* dec, const int64_t* token_dev, int32_t* po
 {
     Decoder* d = dec_from(dec);
     EXL_REQUIRE(d, EXL_E_INVALID, "decoder_step: invalid decoder");
-    EXL_REQUIRE(token_dev && pos_dev && logits_out, EXL_E_INVALID, "decoder_step: null pointer");
+    EXL_REQUIRE(pos_dev && (token_dev || !d->has_embed()) && (logits_out || !d->has_head()), EXL_E_INVALID, "decoder_step: null pointer");
     for (const DecLayer& l : d->layers) EXL_REQUIRE(l.set, EXL_E_INVALID, "decoder_step: a layer was not set");
     hipStream_t s = (hipStream_t) stream;
     int prev = 0;
@@ -990,7 +1129,33 @@ extern "C" int exl_decoder_step(void* dec, const int64_t* token_dev, int32_t* po
         for (int cls = EXL_DEC_QKV; cls <= EXL_DEC_DOWN && rc == 0; ++cls)
             rc = dec_launch(d, cls, i, token_dev, pos_dev, logits_out, advance, s);
     if (rc == 0) rc = dec_launch(d, EXL_DEC_HEAD, 0, token_dev, pos_dev, logits_out, advance, s);
+    if (rc == 0 && !d->has_head() && advance) {                      // a stage without the head advances its own position
+        hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(1), 0, s, pos_dev);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { exl_set_error("decoder_step: %s", hipGetErrorString(e)); rc = (int) e; }
+    }
     if (prev != d->device) (void) hipSetDevice(prev);
+    return rc;
+}
+
+extern "C" int exl_decoder_hidden(void* dec, void** out)
+{
+    Decoder* d = dec_from(dec);
+    EXL_REQUIRE(d && out, EXL_E_INVALID, "decoder_hidden: invalid argument");
+    *out = d->hid;
+    return 0;
+}
+
+extern "C" int exl_decoder_plan(void* dec, int cls, int* out10)
+{
+    Decoder* d = dec_from(dec);
+    EXL_REQUIRE(d && out10, EXL_E_INVALID, "decoder_plan: invalid argument");
+    EXL_REQUIRE(cls >= 0 && cls < EXL_DEC_NCLASS, EXL_E_INVALID, "decoder_plan: unknown kernel class %d", cls);
+    for (const DecLayer& l : d->layers) EXL_REQUIRE(l.set, EXL_E_INVALID, "decoder_plan: a layer was not set");
+    for (int i = 0; i < 10; ++i) out10[i] = 0;
+    g_plan = out10;
+    const int rc = dec_launch(d, cls, d->L - 1, nullptr, nullptr, nullptr, 0, nullptr);   // records, launches nothing
+    g_plan = nullptr;
     return rc;
 }
 
@@ -999,6 +1164,7 @@ extern "C" int exl_decoder_step_greedy(void* dec, int64_t* token_io_dev, int32_t
 {
     Decoder* d = dec_from(dec);
     EXL_REQUIRE(d, EXL_E_INVALID, "decoder_step_greedy: invalid decoder");
+    EXL_REQUIRE(d->has_head(), EXL_E_INVALID, "decoder_step_greedy: this decoder stage has no lm_head");
     const int rc = exl_decoder_step(dec, token_io_dev, pos_dev, logits_out, 1, stream);
     if (rc) return rc;
     int prev = 0;
@@ -1019,7 +1185,8 @@ extern "C" int exl_decoder_step_timed(void* dec, const int64_t* token_dev, int32
                                       void* stream, float* class_ms_host)
 {
     Decoder* d = dec_from(dec);
-    EXL_REQUIRE(d && class_ms_host && token_dev && pos_dev && logits_out, EXL_E_INVALID, "decoder_step_timed: invalid argument");
+    EXL_REQUIRE(d && class_ms_host && pos_dev && (token_dev || !d->has_embed()) && (logits_out || !d->has_head()), EXL_E_INVALID,
+                "decoder_step_timed: invalid argument");
     for (const DecLayer& l : d->layers) EXL_REQUIRE(l.set, EXL_E_INVALID, "decoder_step_timed: a layer was not set");
     if (reps < 1) reps = 1;
     hipStream_t s = (hipStream_t) stream;

@@ -177,7 +177,10 @@ int exl_q4_mlp(int device, void* x, const void* rms_norm_weight, float epsilon, 
 /* ---- native single-token decode executor (no counterpart in the reference: it replaces the Python layer loop
  * model.py:1053-1058 + the three fused ops + the ATen attention for bsz = 1, q_len = 1) -------------------------- */
 /* All pointers are device pointers that must stay valid for the decoder's lifetime: embed [vocab, hidden] fp16,
- * final_norm [hidden] fp16, lm_head [vocab, hidden] fp16, sin/cos [max_seq_len, head_dim] fp16. head_dim must be 128. */
+ * final_norm [hidden] fp16, lm_head [vocab, hidden] fp16, sin/cos [max_seq_len, head_dim] fp16. head_dim must be 128.
+ * A decoder may be ONE STAGE of a layer-split model (reference: ExLlamaDeviceMap, model.py:636-668, hop at :1053-1058):
+ * n_layers is then the stage's own layer count; embed == NULL -> the step starts from the residual stream the caller wrote to
+ * exl_decoder_hidden(); final_norm == lm_head == NULL -> no head: the step leaves the residual stream there for the next stage. */
 int exl_decoder_create(int device, int n_layers, int hidden, int inter, int heads, int kv_heads, int head_dim,
                        int vocab, int max_seq_len, float eps, const void* embed, const void* final_norm,
                        const void* lm_head, const void* sin, const void* cos, void** out_decoder);
@@ -218,6 +221,14 @@ int exl_decoder_step_greedy(void* decoder, int64_t* token_io_dev, int32_t* pos_d
 #define EXL_DEC_NCLASS  7
 int exl_decoder_step_timed(void* decoder, const int64_t* token_dev, int32_t* pos_dev, float* logits_out, int reps,
                            void* stream, float* class_ms_host);
+/* The decoder's residual stream, fp16 [hidden] in device memory: input of a stage created without `embed`, output of a stage
+ * created without `lm_head` (valid after the step's kernels have run on its stream). */
+int exl_decoder_hidden(void* decoder, void** out_hidden_dev);
+/* Test / measurement aid: which kernel configuration one step launches for kernel class `cls` with the current KV-split
+ * setting, without launching anything.  out10: [0] launched (0 = this class is folded away), GEMV classes: [1] U (16-byte
+ * loads in flight per lane), [2] NP (passes), [3] G16 (group size % 128 == 0), [4] PNORM, [5] EMODE, [6] NV (8-half
+ * activation vectors per thread), [7] grid, [8] dynamic LDS bytes, [9] activation images; attention / merge: [1] KV splits. */
+int exl_decoder_plan(void* decoder, int cls, int* out10);
 int exl_decoder_free(void* decoder);
 
 /* ---- repetition penalty, HOST memory, fp32 (reference: exllama_ext.cpp:684-741, cpu_func/rep_penalty.cpp) */

@@ -24,28 +24,70 @@ def _np(t):
     return np.asarray(t)
 
 
+def dequant_rows_f32(qweight, qzeros, scales, g_idx=None):
+    """W16[k, n] = h( h(q[k, n] - z[g(k), n]) * s[g(k), n] ) held as fp32, for the ORIGINAL row order of the checkpoint.
+
+    The same bits as exl_oracle.dequant_w16 (exllama_ext/cuda_func/q4_matrix.cu:170-210: exact `__int2half_rn` of the integer
+    difference, then one fp16 multiply -- the product of two fp16 values is exact in fp32, so one rounding), computed one
+    nibble position at a time to keep the temporaries small at 65B shapes.  g(k) = k // groupsize, or g_idx[k] for an
+    act-order checkpoint: x @ W in the original row order equals x[:, x_map] @ W_sequential (q4_matrix.cu:104-168,
+    column_remap.cu:7-36) term by term, so the prepared oracle needs neither the repack nor the gather.
+    """
+    w = np.asarray(qweight).view(np.uint32)
+    R, N = w.shape
+    K = R * 8
+    z = O.unpack_qzeros(qzeros).astype(np.int8)             # [G, N], 1..16
+    s = np.asarray(scales).astype(f32)
+    gs = K // z.shape[0]
+    gi = None if g_idx is None else np.asarray(g_idx).astype(np.int64)
+    out = np.empty((K, N), dtype=f32)
+    for j in range(8):
+        qj = ((w >> np.uint32(4 * j)) & np.uint32(0xF)).astype(np.int8)
+        rows = np.arange(j, K, 8)
+        grp = rows // gs if gi is None else gi[rows]
+        d = (qj - z[grp]).astype(f32)                         # exact small integers
+        out[j::8] = (d * s[grp]).astype(f16)
+    return out
+
+
 class OracleLinear:
     def __init__(self, tensors, key):
-        self.qweight = _np(tensors[key + ".qweight"]).view(np.uint32).copy()
+        self.qweight_raw = _np(tensors[key + ".qweight"]).view(np.uint32)
         self.qzeros = _np(tensors[key + ".qzeros"]).view(np.uint32)
         self.scales = _np(tensors[key + ".scales"]).astype(f16)
-        self.x_map = None
+        self.g_idx = None
         gk = key + ".g_idx"
         if gk in tensors:
             g_idx = _np(tensors[gk])
-            if not (g_idx == 0).all():
-                self.x_map, self.qweight = O.make_sequential(self.qweight, g_idx, self.qzeros.shape[0])
+            if not (g_idx == 0).all():                      # model.py:147-149: an all-zero g_idx means "no act-order"
+                self.g_idx = g_idx
+        self._seq = None                                    # (x_map, sequential qweight), built on first use
         self.w32 = None
+
+    def _sequential(self):
+        if self._seq is None:
+            if self.g_idx is None:
+                self._seq = (None, self.qweight_raw)
+            else:
+                self._seq = O.make_sequential(self.qweight_raw.copy(), self.g_idx, self.qzeros.shape[0])
+        return self._seq
+
+    @property
+    def x_map(self):
+        return self._sequential()[0]
+
+    @property
+    def qweight(self):
+        return self._sequential()[1]
 
     def prepare(self):
         """Dequantise once: W16 exactly as the reference reconstructs it, held as fp32 for the BLAS call."""
-        self.w32 = O.dequant_w16(self.qweight, self.qzeros, self.scales).astype(f32)
+        self.w32 = dequant_rows_f32(self.qweight_raw, self.qzeros, self.scales, self.g_idx)
 
     def __call__(self, x, residual=None):
         x = np.asarray(x).astype(f16)
         if self.w32 is not None:
-            xx = O.column_remap(x, self.x_map) if self.x_map is not None else x
-            acc = xx.astype(f32) @ self.w32
+            acc = x.astype(f32) @ self.w32                  # original row order: no gather needed (see dequant_rows_f32)
             if residual is not None:
                 acc = acc + np.asarray(residual).astype(f32)
             return acc.astype(f16)

@@ -61,6 +61,20 @@ def _close(got, ref, ulps=2.0):
     atol = ulps * scale * 2.0 ** -10
     err = np.abs(got - ref).max()
     assert err <= atol, f"max |diff| {err:.3e} > atol {atol:.3e} (scale {scale:.3e})"
+    # relative check: the absolute bound above is set by the LARGEST element, so a wrong low-magnitude region could hide
+    # under it.  Correct fp16 rounding alone gives rms(err) / rms(ref) ~ 2^-11 / sqrt(3); anything systematically wrong in
+    # the small elements shows up here, over the whole array and over every 16-column / 16-element block of it.
+    rms_ref = float(np.sqrt(np.mean(ref ** 2)))
+    if rms_ref > 0 and ref.size >= 64:
+        rel = float(np.sqrt(np.mean((got - ref) ** 2))) / rms_ref
+        assert rel <= ulps * 2.0 ** -11, f"rms(diff) / rms(ref) = {rel:.3e} > {ulps * 2.0 ** -11:.3e}"
+        flat_g, flat_r = got.reshape(-1), ref.reshape(-1)
+        nblk = flat_r.size // 16
+        if nblk >= 4:
+            eb = np.sqrt(np.mean((flat_g[:nblk * 16] - flat_r[:nblk * 16]).reshape(nblk, 16) ** 2, axis=1))
+            rb = np.sqrt(np.mean(flat_r[:nblk * 16].reshape(nblk, 16) ** 2, axis=1))
+            bad = eb > 8.0 * ulps * 2.0 ** -11 * np.maximum(rb, rms_ref / 8.0)
+            assert not bad.any(), f"{int(bad.sum())} of {nblk} 16-element blocks off (first: block {int(np.argmax(bad))})"
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -542,14 +556,16 @@ def test_q4_attn_fused(ce, dim, heads, kvh, act, gs):
     assert not kc[:, :, :past].any() and not kc[:, :, past + 1:].any()
 
 
-def test_q4_attn_2_and_mlp_fused(ce):
-    dim, inter, gs = 512, 1408, 128
+@pytest.mark.parametrize("dim,inter,gs,act", [(512, 1408, 128, True), (4096, 11008, 128, False), (5120, 13824, 32, False)])
+def test_q4_attn_2_and_mlp_fused(ce, dim, inter, gs, act):
+    """q4_attn_2 / q4_mlp (reference: q4_attn.cu:206-228, q4_mlp.cu:100-199) at a small shape and at the 7B / 13B layer shapes."""
     keep = _prep_buffers(ce, 2, dim, inter)
     gen = torch.Generator().manual_seed(2)
-    lo, _ = _lin(dim, dim, gs, True, seed=31, std=0.03)
-    lg, _ = _lin(dim, inter, gs, True, seed=32, std=0.03)
-    lu, _ = _lin(dim, inter, gs, False, seed=33, std=0.03)
-    ld, _ = _lin(inter, dim, gs, True, seed=34, std=0.02)
+    std = 0.03 * (512.0 / dim) ** 0.5
+    lo, _ = _lin(dim, dim, gs, act, seed=31, std=std)
+    lg, _ = _lin(dim, inter, gs, act, seed=32, std=std)
+    lu, _ = _lin(dim, inter, gs, False, seed=33, std=std)
+    ld, _ = _lin(inter, dim, gs, act, seed=34, std=0.02 * (1408.0 / inter) ** 0.5)
     ho, _d0 = _handle(ce, lo)
     hg, _d1 = _handle(ce, lg)
     hu, _d2 = _handle(ce, lu)
