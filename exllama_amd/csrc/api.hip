@@ -234,6 +234,10 @@ extern "C" int exl_q4_layout(void* handle, int* layout)
 
 static int q4_gemv(Q4Matrix* m, const void* x, int rows, void* out, int no_zero, hipStream_t s)
 {
+    if (!q4_gemv_covers(m)) {                                // K beyond the decode kernel's reach: the MFMA GEMM takes any K
+        DeviceBuffers* b = exl_buffers(m->device);
+        return launch_q4_gemm(m, (const f16*) x, rows, (f16*) out, no_zero, b->temp_state, b->temp_state_numel, s);
+    }
     float* ws = nullptr;
     EXL_TRY(exl_workspace(m->device, 0, &ws));
     return launch_q4_gemv(m, (const f16*) x, rows, (f16*) out, no_zero, ws, exl_buffers(m->device)->workspace_floats, s);

@@ -87,6 +87,7 @@ struct GemvArgs {
 };
 int launch_q4_gemv(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_zero, float* ws, size_t ws_floats,
                    hipStream_t s);
+bool q4_gemv_covers(const Q4Matrix* w);          // false: in_features beyond what the decode GEMV stages -> use launch_q4_gemm
 int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_zero, f16* remap_tmp,
                    size_t remap_tmp_numel, hipStream_t s);
 int launch_q4_qkv_rope_cache(const Q4Matrix* wq, const Q4Matrix* wk, const Q4Matrix* wv, const f16* x, int rows, f16* q_out,

@@ -54,6 +54,7 @@ struct DecGemvArgs {
     int ablate;                   // measurement only (EXL_DEC_ABLATE): 1 = skip the dequant + MFMA work, 2 = also skip the norm
     int nblocks;                  // = gridDim.x (passed explicitly: the implicit-argument load is one more scalar round trip)
     int units_lo, units_rem;      // unit count per block: units_lo + (block < units_rem)
+    int early_weights;            // 1 (default): first weight batch issued before the activation has landed; 0: EXL_DEC_X_FIRST=1
 };
 
 // Every field of a matrix view the streaming loop touches, forced into SGPRs at the top of the kernel: the compiler
@@ -186,6 +187,8 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
     const f16* a_vec = dec_pin_ptr(a.vec); const f16* a_norm_w = dec_pin_ptr(a.norm_w); const int64_t* a_tok = dec_pin_ptr(a.tok);
     int te0 = a.tile_end[0], te1 = a.tile_end[1], te2 = a.tile_end[2], a_nmat = a.nmat;
     int a_rbw = a.rb_per_wave, a_images = a.xs_images, nb = a.nblocks, units_lo = a.units_lo, units_rem = a.units_rem;
+    int early_w = a.early_weights;
+    DEC_PIN_S(early_w);
     DEC_PIN_S(K); DEC_PIN_S(R);
     DEC_PIN_S(te0); DEC_PIN_S(te1); DEC_PIN_S(te2); DEC_PIN_S(a_nmat); DEC_PIN_S(a_rbw); DEC_PIN_S(a_images);
     DEC_PIN_S(nb); DEC_PIN_S(units_lo); DEC_PIN_S(units_rem);
@@ -259,7 +262,10 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
     describe(0, miA, tileA);
     mA = dec_pick(M0, M1, M2, miA); mB = mA;
     uA = dec_unit(mA, tileA, rb_lo, rb_hi);
-    dec_unit_issue<U, G16>(mA, uA, 0, lane, wv0, ep0);               // weights first: their addresses are scalar arithmetic + one VALU
+    // A/B (EXL_DEC_X_FIRST=1): wait for the activation to land before the weight stream starts.  Measured on 7B: slower
+    // (599 / 712 vs 619 / 731 tokens/s worst / best case), so the default issues the first weight batch right away.
+    if (!early_w) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    dec_unit_issue<U, G16>(mA, uA, 0, lane, wv0, ep0);               // addresses: scalar arithmetic + one VALU
     if constexpr (G16) dec_unit_entries<NSLOT>(mA, uA, lane, entA);
     if constexpr (EMODE == 1) { if (tid < 16) resA = (float) a.hid_io[tileA * 16 + tid]; }
 
@@ -835,7 +841,7 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     EXL_REQUIRE(head_dim == 128, EXL_E_UNSUPPORTED, "decoder: head_dim must be 128 (got %d)", head_dim);
     EXL_REQUIRE(hidden % 128 == 0 && hidden == heads * head_dim && heads % kv_heads == 0, EXL_E_UNSUPPORTED, "decoder: bad head geometry");
     EXL_REQUIRE(inter % 128 == 0, EXL_E_UNSUPPORTED, "decoder: intermediate size must be a multiple of 128 (got %d)", inter);
-    EXL_REQUIRE(hidden <= 8192 && inter <= 24576, EXL_E_UNSUPPORTED, "decoder: hidden (%d) / intermediate (%d) size too large", hidden, inter);
+    EXL_REQUIRE(hidden <= 8192 && inter <= 32768, EXL_E_UNSUPPORTED, "decoder: hidden (%d) / intermediate (%d) size too large", hidden, inter);
     // A decoder may be one STAGE of a layer-split model (reference: ExLlamaDeviceMap, model.py:636-668): embed == NULL ->
     // the step reads the residual stream the caller put into exl_decoder_hidden(); lm_head == NULL -> no final norm / head,
     // the residual stream is left there for the next stage.
@@ -976,7 +982,11 @@ static int launch_dec_gemv_cfg(bool g16, int rbw, dim3 grid, size_t smem, hipStr
     if (rbw <= 4)       DEC_LAUNCH(4, 1);
     else if (rbw <= 8)  DEC_LAUNCH(4, 2);
     else if (rbw <= 12) DEC_LAUNCH(6, 2);
-    else                DEC_LAUNCH(6, 4);
+    else if (rbw <= 24) DEC_LAUNCH(6, 4);
+    else {                                                           // K > 24576: only down_proj (K = intermediate size, e.g. 28672 of Llama-2-70B)
+        if constexpr (PNORM == 0 && EMODE == 1) DEC_LAUNCH(6, 6);
+        else EXL_FAIL(EXL_E_UNSUPPORTED, "decoder: in_features too large for this kernel class");
+    }
 #endif
 #undef DEC_LAUNCH
 #undef DEC_LAUNCH1
@@ -1009,7 +1019,7 @@ static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec,
     const int K = mats[0]->height, RB = K / 128;
     const int wpt = emode == 2 ? DEC_WAVES / 2 : DEC_WAVES;
     const int rbw = (RB + wpt - 1) / wpt;
-    EXL_REQUIRE(rbw <= 24, EXL_E_UNSUPPORTED, "decoder: in_features %d too large", K);
+    EXL_REQUIRE(rbw <= (pnorm == 0 && emode == 1 ? 36 : 24), EXL_E_UNSUPPORTED, "decoder: in_features %d too large", K);
     a.rb_per_wave = rbw;
     const bool g16 = mats[0]->groupsize % 128 == 0;
     for (int i = 1; i < nmat; ++i)
@@ -1017,6 +1027,8 @@ static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec,
     a.xs_images = any_map ? nmat : 1;                                // act-order: every matrix gathers x through its own map
     static const int ablate = getenv("EXL_DEC_ABLATE") ? atoi(getenv("EXL_DEC_ABLATE")) : 0;
     a.ablate = ablate;
+    static const int x_first = getenv("EXL_DEC_X_FIRST") ? atoi(getenv("EXL_DEC_X_FIRST")) : 0;
+    a.early_weights = !x_first;
     const size_t smem = (size_t) a.xs_images * (K / 8) * 16 + (2 * DEC_WAVES * 16 + DEC_WAVES) * sizeof(float) + (any_map ? (size_t) K * 2 : 0);
     EXL_REQUIRE(smem <= 160 * 1024, EXL_E_UNSUPPORTED, "decoder: activation stage (%zu bytes of LDS) exceeds the 160 KiB of a CU", smem);
     const int nv = (K / 8 + DEC_THREADS - 1) / DEC_THREADS;
@@ -1027,17 +1039,23 @@ static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec,
     a.nblocks = (int) grid.x;
     a.units_lo = tiles / (int) grid.x;
     a.units_rem = tiles % (int) grid.x;
+    // NV (8-half activation vectors per thread) instantiations by kernel class: the normed / merged inputs have K = hidden
+    // <= 8192 (NV <= 2; the merge fold only exists for hidden <= 4096), only o_proj / down_proj see K = intermediate size
+#define DEC_GO(P, E, N) launch_dec_gemv_cfg<P, E, N>(g16, rbw, grid, smem, s, a)
+    EXL_REQUIRE(nv <= 8, EXL_E_UNSUPPORTED, "decoder: in_features %d too large", K);
 #ifdef EXL_DEC_FAST_BUILD
-#define DEC_NV(P, E) (nv <= 1 ? launch_dec_gemv_cfg<P, E, 1>(g16, rbw, grid, smem, s, a) : launch_dec_gemv_cfg<P, E, 3>(g16, rbw, grid, smem, s, a))
+    if (pnorm == 1 && emode == 0) return DEC_GO(1, 0, 1);
+    if (pnorm == 1 && emode == 2) return DEC_GO(1, 2, 1);
+    if (pnorm == 0 && emode == 1) return nv <= 1 ? DEC_GO(0, 1, 1) : DEC_GO(0, 1, 3);
+    if (pnorm == 3 && emode == 1) return DEC_GO(3, 1, 1);
 #else
-#define DEC_NV(P, E) (nv <= 1 ? launch_dec_gemv_cfg<P, E, 1>(g16, rbw, grid, smem, s, a) : nv <= 2 ? launch_dec_gemv_cfg<P, E, 2>(g16, rbw, grid, smem, s, a) \
-                      : nv <= 3 ? launch_dec_gemv_cfg<P, E, 3>(g16, rbw, grid, smem, s, a) : launch_dec_gemv_cfg<P, E, 6>(g16, rbw, grid, smem, s, a))
+    if (pnorm == 1 && emode == 0) { EXL_REQUIRE(nv <= 2, EXL_E_UNSUPPORTED, "decoder: hidden size too large"); return nv <= 1 ? DEC_GO(1, 0, 1) : DEC_GO(1, 0, 2); }
+    if (pnorm == 1 && emode == 2) { EXL_REQUIRE(nv <= 2, EXL_E_UNSUPPORTED, "decoder: hidden size too large"); return nv <= 1 ? DEC_GO(1, 2, 1) : DEC_GO(1, 2, 2); }
+    if (pnorm == 3 && emode == 1) { EXL_REQUIRE(nv <= 1, EXL_E_UNSUPPORTED, "decoder: the split merge folds only for hidden <= 4096"); return DEC_GO(3, 1, 1); }
+    if (pnorm == 0 && emode == 1)
+        return nv <= 1 ? DEC_GO(0, 1, 1) : nv <= 2 ? DEC_GO(0, 1, 2) : nv <= 3 ? DEC_GO(0, 1, 3) : nv <= 6 ? DEC_GO(0, 1, 6) : DEC_GO(0, 1, 8);
 #endif
-    if (pnorm == 1 && emode == 0) return DEC_NV(1, 0);
-    if (pnorm == 1 && emode == 2) return DEC_NV(1, 2);
-    if (pnorm == 0 && emode == 1) return DEC_NV(0, 1);
-    if (pnorm == 3 && emode == 1) return DEC_NV(3, 1);
-#undef DEC_NV
+#undef DEC_GO
     EXL_FAIL(EXL_E_INVALID, "decoder: unsupported kernel combination");
 }
 

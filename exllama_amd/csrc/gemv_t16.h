@@ -24,7 +24,7 @@
 #include "common.h"
 
 #define T16_MAGIC 0x64006400u
-#define T16_EH 6                    // entry slots per lane: up to 24 row-blocks per wave
+#define T16_EH 9                    // entry slots per lane: up to 36 row-blocks per wave (K <= 36864 with 8 waves)
 
 __device__ __forceinline__ f16x2 t16_h2(uint32_t v) { return __builtin_bit_cast(f16x2, v); }
 
@@ -76,7 +76,7 @@ __device__ __forceinline__ void t16_rowblock(const uint4& w, uint32_t e, uint32_
 {
     const f16x2 c960 = {(f16) 960.f, (f16) 960.f};
     const f16 sc = __builtin_bit_cast(f16, (uint16_t) (e & 0xFFFFu));
-    const f16 za = (f16) (float) (-(1024 + (int) (e >> 16)));
+    const f16 za = __builtin_bit_cast(f16, (uint16_t) (e >> 16));    // -(1024 + z), stored as fp16 bits by t16_load_entry
     const f16x2 zc0 = {za, za};
     const f16x2 zc1 = zc0 + c960;
     const uint4 x0 = xr[0], x1 = xr[1], x2 = xr[2], x3 = xr[3];
@@ -111,12 +111,15 @@ struct T16Matrix {                  // device-visible view of a Q4Matrix in T16 
 
 __device__ __forceinline__ int t16_group_of_row(const T16Matrix& m, int r) { return m.gshift >= 0 ? (r >> m.gshift) : (r / m.gprows); }
 
-// (scale bits) | (z + 1) << 16 for (group g, column n)
+// (scale bits) | fp16 bits of -(1024 + z) << 16 for (group g, column n), z = stored nibble + 1 (matrix.cuh:55-59).
+// 1024 + z (z = 1..16) is 0x6400 + z in fp16 (ulp 1 in [1024, 2048)), so the negated constant is 0xE400 + z: the
+// zero-point correction of the magic-number expansion costs no conversion instruction at the point of use.  An all-zero
+// entry (row-blocks past a wave's range) still means scale 0 -> contributes nothing.
 __device__ __forceinline__ uint32_t t16_load_entry(const T16Matrix& m, int g, int n)
 {
     const uint32_t zw = m.qzeros[(size_t) g * (m.N >> 3) + (n >> 3)];
     const uint16_t sb = ((const uint16_t*) m.scales)[(size_t) g * m.N + n];
-    return (uint32_t) sb | ((((zw >> ((n & 7) * 4)) & 0xFu) + 1) << 16);
+    return (uint32_t) sb | ((0xE401u + ((zw >> ((n & 7) * 4)) & 0xFu)) << 16);
 }
 
 // Per-wave streaming state.  U = 16-byte loads in flight per lane (one pass = U row-blocks), NP = max passes.

@@ -314,27 +314,50 @@ template <bool G16, int MR>
 static int launch_t16_cfg(int rbw, dim3 grid, size_t smem, hipStream_t s, const T16Matrix& m, const f16* x, f16* out, int rows,
                           int no_zero, int xstride)
 {
-#define T16_LAUNCH(U, NP) hipLaunchKernelGGL((q4_gemv_t16_kernel<U, NP, G16, MR>), grid, dim3(T16_WAVES * 64), smem, s, m, x, out, rows, no_zero, rbw, xstride)
+    // more than 64 KiB of dynamic LDS (in_features > ~28000, or several rows of a wide matrix) is a per-device opt-in
+#define T16_LAUNCH(U, NP) do { auto kfn = q4_gemv_t16_kernel<U, NP, G16, MR>;                                                  \
+        if (smem > 64 * 1024) {                                                                                               \
+            static bool big[EXL_MAX_DEVICES] = {};                                                                            \
+            int dev_ = 0;                                                                                                     \
+            EXL_HIP(hipGetDevice(&dev_));                                                                                     \
+            if (dev_ >= 0 && dev_ < EXL_MAX_DEVICES && !big[dev_]) {                                                          \
+                EXL_HIP(hipFuncSetAttribute((const void*) kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      \
+                big[dev_] = true;                                                                                             \
+            }                                                                                                                 \
+        }                                                                                                                     \
+        hipLaunchKernelGGL(kfn, grid, dim3(T16_WAVES * 64), smem, s, m, x, out, rows, no_zero, rbw, xstride); } while (0)
     if (rbw <= 4)       T16_LAUNCH(4, 1);
     else if (rbw <= 8)  T16_LAUNCH(8, 1);
     else if (rbw <= 12) T16_LAUNCH(6, 2);
-    else                T16_LAUNCH(6, 4);
+    else if (rbw <= 24) T16_LAUNCH(6, 4);
+    else                T16_LAUNCH(6, 6);
 #undef T16_LAUNCH
     EXL_LAUNCH_CHECK();
     return 0;
+}
+
+// Shapes the decode kernel covers: 8 waves x 36 row-blocks of K, one activation row staged in LDS.  Anything else (no
+// Llama shape: Llama-2-70B's down_proj, K = 28672, is covered) is routed to the MFMA GEMM by the callers (q4_gemv_covers).
+#define T16_MAX_RBW 36
+#define T16_LDS_BUDGET (160 * 1024)
+bool q4_gemv_covers(const Q4Matrix* w)
+{
+    if (w->layout != EXL_LAYOUT_T16) return true;                    // the generic split-K kernel takes any K
+    const int R = w->height / 8, RB = R / 16;
+    return (RB + T16_WAVES - 1) / T16_WAVES <= T16_MAX_RBW && (size_t) (R + 1) * 16 + 8 * 1024 <= T16_LDS_BUDGET;
 }
 
 static int launch_q4_gemv_t16(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_zero, hipStream_t s)
 {
     const T16Matrix m = t16_view(w);
     const int rbw = (m.RB + T16_WAVES - 1) / T16_WAVES;
-    EXL_REQUIRE(rbw <= 24, EXL_E_UNSUPPORTED, "q4 gemv: in_features %d too large for the decode kernel (max %d)", m.K, 24 * T16_WAVES * 128);
+    EXL_REQUIRE(rbw <= T16_MAX_RBW, EXL_E_UNSUPPORTED, "q4 gemv: in_features %d too large for the decode kernel (max %d)", m.K, T16_MAX_RBW * T16_WAVES * 128);
     const bool g16 = m.gprows % 16 == 0;
     const int ntiles = m.N / 16;
     // LDS budget: rows * xstride * 16 + reduction buffer <= 64 KiB (the default dynamic-LDS limit); more rows go in
     // several launches (this is the op-level path for 2..7 rows; single-token decode runs through decode_fused.hip)
     const int xstride = rows == 1 ? m.R : m.R + 1;
-    const int max_rows = (int) ((64 * 1024 - 8 * 1024) / ((size_t) (m.R + 1) * 16));
+    const int max_rows = (int) ((T16_LDS_BUDGET - 8 * 1024) / ((size_t) (m.R + 1) * 16));
     EXL_REQUIRE(max_rows >= 1, EXL_E_UNSUPPORTED, "q4 gemv: in_features %d does not fit the activation stage", m.K);
     for (int r0 = 0; r0 < rows; r0 += max_rows) {
         const int nr = rows - r0 < max_rows ? rows - r0 : max_rows;

@@ -103,6 +103,17 @@ def main(out_path):
     def f16(*shape, scale=1.0):
         return (torch.randn(*shape, generator=gen) * scale).half()
 
+    keep = []
+
+    def dv(t):
+        """Device copy that stays alive until main() returns: a temporary whose .data_ptr() is handed to a C call is freed
+        right after the expression, and the caching allocator gives the same block to the next temporary."""
+        if isinstance(t, np.ndarray):
+            t = torch.from_numpy(t)
+        d = t.to(DEV).clone()
+        keep.append(d)
+        return d
+
     # ---- q4 linears: make_sequential, reconstruct, column_remap, both matmul forms --------------------------------------
     shapes = {"a": (256, 128, 64, True), "b": (512, 96, 128, False), "c": (256, 64, 32, True), "d": (1024, 256, 128, True)}
     for tag, (K, N, gs, act) in shapes.items():
@@ -146,7 +157,7 @@ def main(out_path):
         if xm is not None:
             x = f16(5, K)
             xn = torch.empty_like(x, device=DEV)
-            _ok(lib.ref_column_remap(x.to(DEV).data_ptr(), xn.data_ptr(), 5, K, lib.ref_q4_x_map(r.h)), "column_remap")
+            _ok(lib.ref_column_remap(dv(x).data_ptr(), xn.data_ptr(), 5, K, lib.ref_q4_x_map(r.h)), "column_remap")
             out[f"lin_{tag}_remap_x"] = x.numpy()
             out[f"lin_{tag}_remap_y"] = xn.cpu().numpy()
     out["lin_tags"] = np.array(list(shapes.keys()))
@@ -159,7 +170,7 @@ def main(out_path):
         for no_half2 in (0, 1):
             tune(no_half2)
             y = torch.empty((rows, dim), dtype=torch.float16, device=DEV)
-            _ok(lib.ref_rms_norm(x.to(DEV).data_ptr(), w.to(DEV).data_ptr(), y.data_ptr(), eps, rows, dim, 0), "rms_norm")
+            _ok(lib.ref_rms_norm(dv(x).data_ptr(), dv(w).data_ptr(), y.data_ptr(), eps, rows, dim, 0), "rms_norm")
             out[f"rms_{n}_y{no_half2}"] = y.cpu().numpy()
         out[f"rms_{n}_x"], out[f"rms_{n}_w"], out[f"rms_{n}_eps"] = x.numpy(), w.numpy(), np.float32(eps)
         n += 1
@@ -167,13 +178,14 @@ def main(out_path):
 
     # ---- rope (both kernel variants) -------------------------------------------------------------------------------------
     n = 0
-    for hd, heads, tokens, past, bsz in ((128, 4, 1, 0, 1), (128, 8, 3, 17, 1), (64, 4, 5, 40, 2), (128, 2, 1, 2047, 1)):
+    # head_dim 128 only: the reference's half2 RoPE grid is head_dim / 32 / 2 / 2 blocks wide (rope.cu:100-125), i.e. zero for 64
+    for hd, heads, tokens, past, bsz in ((128, 4, 1, 0, 1), (128, 8, 3, 17, 1), (128, 4, 5, 40, 2), (128, 2, 1, 2047, 1), (256, 2, 2, 9, 1)):
         sin, cos = O.rope_tables(2048, hd)
         x = f16(bsz, tokens * heads * hd)
         for no_half2 in (0, 1):
             tune(no_half2)
-            xd = x.to(DEV).clone()
-            _ok(lib.ref_rope(xd.data_ptr(), torch.from_numpy(sin).to(DEV).data_ptr(), torch.from_numpy(cos).to(DEV).data_ptr(),
+            xd = dv(x)
+            _ok(lib.ref_rope(xd.data_ptr(), dv(sin).data_ptr(), dv(cos).data_ptr(),
                              bsz, tokens * heads, hd, heads, past), "rope")
             out[f"rope_{n}_y{no_half2}"] = xd.cpu().numpy()
         out[f"rope_{n}_x"] = x.numpy()
@@ -185,14 +197,14 @@ def main(out_path):
     x, w = f16(3, 256), f16(256, 96, scale=0.1)
     for name, fn in (("hm_kernel", lib.ref_half_matmul), ("hm_blas", lib.ref_half_matmul_blas)):
         y = torch.zeros((3, 96), dtype=torch.float16, device=DEV)
-        _ok(fn(x.to(DEV).data_ptr(), w.to(DEV).data_ptr(), y.data_ptr(), 3, 256, 96), name)
+        _ok(fn(dv(x).data_ptr(), dv(w).data_ptr(), y.data_ptr(), 3, 256, 96), name)
         out[name] = y.cpu().numpy()
     out["hm_x"], out["hm_w"] = x.numpy(), w.numpy()
 
     # ---- fused decode ops: q4_attn (norm + qkv + rope + cache scatter), q4_attn_2, q4_mlp -------------------------------------
     tune(0)
     n = 0
-    for dim, inter, heads, kvh, gs, act, past in ((512, 512, 4, 4, 128, False, 5), (512, 768, 8, 4, 64, True, 30)):
+    for dim, inter, heads, kvh, gs, act, past in ((512, 512, 4, 4, 128, False, 5), (512, 768, 4, 4, 64, True, 30)):
         hd = dim // heads
         kvd = kvh * hd
         mats = {}
@@ -203,7 +215,7 @@ def main(out_path):
             for k, v in lin.items():
                 out[f"fused_{n}_{name}_{k}"] = v.numpy()
         sin, cos = O.rope_tables(64, hd)
-        sd, cd = torch.from_numpy(sin).to(DEV), torch.from_numpy(cos).to(DEV)
+        sd, cd = dv(sin), dv(cos)
         x = f16(1, 1, dim)
         w1 = (1.0 + 0.1 * torch.randn(dim, generator=gen)).half()
         w2 = (1.0 + 0.1 * torch.randn(dim, generator=gen)).half()
@@ -213,17 +225,17 @@ def main(out_path):
         ks = torch.zeros((1, 1, kvd), dtype=torch.float16, device=DEV)
         vs = torch.zeros((1, 1, kvd), dtype=torch.float16, device=DEV)
         xd = x.to(DEV).clone()
-        _ok(lib.ref_q4_attn(xd.data_ptr(), w1.to(DEV).data_ptr(), 1e-6, qs.data_ptr(), ks.data_ptr(), vs.data_ptr(), mats["q"].h,
+        _ok(lib.ref_q4_attn(xd.data_ptr(), dv(w1).data_ptr(), 1e-6, qs.data_ptr(), ks.data_ptr(), vs.data_ptr(), mats["q"].h,
                             mats["k"].h, mats["v"].h, sd.data_ptr(), cd.data_ptr(), 1, 1, dim, hd, heads, kvh, past, kc.data_ptr(),
                             vc.data_ptr(), 64, 0), "q4_attn")
         out[f"fused_{n}_q"], out[f"fused_{n}_k"], out[f"fused_{n}_v"] = qs.cpu().numpy(), ks.cpu().numpy(), vs.cpu().numpy()
         out[f"fused_{n}_kc"], out[f"fused_{n}_vc"] = kc.cpu().numpy(), vc.cpu().numpy()
         ao = f16(1, 1, dim, scale=0.5)
         x2 = x.to(DEV).clone()
-        _ok(lib.ref_q4_attn_2(x2.data_ptr(), ao.to(DEV).data_ptr(), mats["o"].h, 1), "q4_attn_2")
+        _ok(lib.ref_q4_attn_2(x2.data_ptr(), dv(ao).data_ptr(), mats["o"].h, 1), "q4_attn_2")
         out[f"fused_{n}_attn_out"], out[f"fused_{n}_x_after_o"] = ao.numpy(), x2.cpu().numpy()
         x3 = x.to(DEV).clone()
-        _ok(lib.ref_q4_mlp(x3.data_ptr(), w2.to(DEV).data_ptr(), 1e-6, mats["gate"].h, mats["up"].h, mats["down"].h, 1, dim, 0), "q4_mlp")
+        _ok(lib.ref_q4_mlp(x3.data_ptr(), dv(w2).data_ptr(), 1e-6, mats["gate"].h, mats["up"].h, mats["down"].h, 1, dim, 0), "q4_mlp")
         out[f"fused_{n}_x_after_mlp"] = x3.cpu().numpy()
         out[f"fused_{n}_x"], out[f"fused_{n}_w1"], out[f"fused_{n}_w2"] = x.numpy(), w1.numpy(), w2.numpy()
         out[f"fused_{n}_params"] = np.array([dim, inter, heads, kvh, gs, int(act), past], dtype=np.int64)
