@@ -101,6 +101,8 @@ def layer_split_main(args, dims, L, S, G, rank, world, dev, dist):
     del tensors
     cache = ExLlamaCache(model)
     runner = LayerSplitRunner(model, cache, d, dims.hidden_size, dev)
+    if not args.no_graph:
+        runner.enable_decode_executor()                           # each rank: native executor stage, hipGraph replay per token
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234)                                         # every rank needs the same prompt SHAPE; values matter on rank 0
     ids = torch.randint(0, min(31999, dims.vocab_size - 1), (1, S), device=dev, generator=gen)
@@ -147,7 +149,8 @@ def layer_split_main(args, dims, L, S, G, rank, world, dev, dist):
             "data": "synthetic (seeded random GPTQ weights of the named architecture, random token ids)",
             "config": {"workload": f"Llama-{args.model.upper()} 4-bit GPTQ g{args.groupsize}, {S}-token prefill + {G}-token greedy decode, "
                                    f"ONE model split by layers over {world} rank(s)", "layers": L, "prompt_tokens": S, "gen_tokens": G,
-                       "parallelism": f"layer split x{world} (sequential stages, P2P hidden-state hand-off, op-by-op decode path)"},
+                       "parallelism": f"layer split x{world} (sequential stages, P2P hidden-state hand-off, "
+                                      + ("op-by-op decode path)" if args.no_graph else "one native executor stage + hipGraph per rank)")},
             "prefill_tokens_per_s": round(S / (pre / 1e3), 1), "decode_worst_tokens_per_s": round(G / (dec / 1e3), 2),
             "prefill_ms": round(pre, 3), "decode_worst_ms_per_token": round(dec / G, 4)}))
     if dist is not None:

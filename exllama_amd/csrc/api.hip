@@ -97,8 +97,13 @@ struct DeviceGuard {
 static std::vector<Q4Matrix*> g_matrices;
 static std::unordered_set<void*> g_live;
 
+// Registry state (handles, re-tiled buffers, device pool) is guarded by g_reg_mutex: the reference is single-threaded by
+// contract, a loader thread next to a serving thread must not corrupt the tables all the same.
+static std::mutex g_reg_mutex;
+
 Q4Matrix* q4_from_handle(void* h)
 {
+    std::lock_guard<std::mutex> lock(g_reg_mutex);
     if (!h || g_live.find(h) == g_live.end()) return nullptr;
     Q4Matrix* m = (Q4Matrix*) h;
     return m->magic == EXL_Q4_MAGIC ? m : nullptr;
@@ -120,10 +125,12 @@ static void free_matrix(Q4Matrix* m)
 
 extern "C" int exl_cleanup(void)
 {
+    std::lock_guard<std::mutex> lock(g_reg_mutex);
     for (Q4Matrix* m : g_matrices) free_matrix(m);
     g_matrices.clear();
     g_live.clear();
     for (int d = 0; d < EXL_MAX_DEVICES; ++d) {
+
         DeviceBuffers* b = &g_buffers[d];
         if (b->workspace) {
             int prev = 0;
@@ -164,6 +171,9 @@ extern "C" int exl_make_q4(int device, int height, int width, int groups, uint32
     m->scales = (f16*) scales;
     m->x_map = nullptr;
     m->layout = EXL_LAYOUT_GPTQ;
+    // NOTE: make_q4 re-tiles (and, with act-order, repacks -- as the reference does, q4_matrix.cu:159) `qweight` IN PLACE; a
+    // second make_q4 on the same tensor would re-tile re-tiled words.  It cannot be refused by address: handles live until
+    // cleanup() while the caller's allocator recycles the addresses of freed tensors.  include/exl_amd.h documents it.
 
     if (g_idx_host) {
         // stable counting sort of rows by group -> x_map (new row -> old row); integer-exact restatement of
@@ -181,7 +191,7 @@ extern "C" int exl_make_q4(int device, int height, int width, int groups, uint32
         if (e != hipSuccess) { delete m; EXL_FAIL((int) e, "make_q4: hipSetDevice(%d) failed: %s", device, hipGetErrorString(e)); }
         const int r = launch_make_sequential(m, x_map.data(), (hipStream_t) stream);
         (void) hipSetDevice(prev);
-        if (r) { delete m; return r; }
+        if (r) { free_matrix(m); return r; }
     }
     // Re-tile the packed weights in place into the streaming layout of the decode / prefill kernels (gemv_t16.h).
     // Needs whole 16-row blocks and 16-column tiles and groups that are whole 4-row pieces; every Llama shape qualifies.
@@ -191,8 +201,11 @@ extern "C" int exl_make_q4(int device, int height, int width, int groups, uint32
         const int r = launch_retile_t16(m, (hipStream_t) stream);
         if (r) { free_matrix(m); return r; }
     }
-    g_matrices.push_back(m);
-    g_live.insert(m);
+    {
+        std::lock_guard<std::mutex> lock(g_reg_mutex);
+        g_matrices.push_back(m);
+        g_live.insert(m);
+    }
     *out_handle = m;
     return 0;
 }
@@ -201,9 +214,12 @@ extern "C" int exl_free_q4(void* handle)
 {
     Q4Matrix* m = q4_from_handle(handle);
     EXL_REQUIRE(m, EXL_E_INVALID, "free_q4: invalid handle");
-    for (size_t i = 0; i < g_matrices.size(); ++i)
-        if (g_matrices[i] == m) { g_matrices.erase(g_matrices.begin() + i); break; }
-    g_live.erase(m);
+    {
+        std::lock_guard<std::mutex> lock(g_reg_mutex);
+        for (size_t i = 0; i < g_matrices.size(); ++i)
+            if (g_matrices[i] == m) { g_matrices.erase(g_matrices.begin() + i); break; }
+        g_live.erase(m);
+    }
     free_matrix(m);
     return 0;
 }

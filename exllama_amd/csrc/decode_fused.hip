@@ -51,7 +51,7 @@ struct DecGemvArgs {
     f16* hid_io;                  // EMODE 1: hid_io[n] = h(hid_io[n] + y)
     int rb_per_wave;
     int xs_images;                // 1, or 2 when gate and up carry different act-order maps (EMODE 2)
-    int ablate;                   // measurement only (EXL_DEC_ABLATE): 1 = skip the dequant + MFMA work, 2 = also skip the norm
+    int ablate;                   // measurement only (EXL_DEC_ABLATE): 1 = skip the dequant + MFMA work, 3 = also the scale / zero loads, 4 = also the activation loads
     int nblocks;                  // = gridDim.x (passed explicitly: the implicit-argument load is one more scalar round trip)
     int units_lo, units_rem;      // unit count per block: units_lo + (block < units_rem)
     int early_weights;            // 1 (default): first weight batch issued before the activation has landed; 0: EXL_DEC_X_FIRST=1
@@ -165,7 +165,7 @@ __device__ __forceinline__ f16 silu_mul_f16(f16 x, f16 y)
 // (loads return in order).
 // Phase attribution (probe builds only, scripts/probe_attn.sh): cycles since block start at 6 points, per kernel class.
 #ifdef EXL_ATTN_PROBE
-__device__ unsigned long long g_stream_probe[4 * 512 * 8];          // [class = PNORM * 2 + (EMODE == 2 ? 1 : EMODE)][block][point]
+__device__ unsigned long long g_stream_probe[8 * 512 * 8];          // [class = PNORM * 2 + (EMODE == 2 ? 1 : EMODE)][block][point]
 #define SP_CLK(i) sp_t[i] = __builtin_readcyclecounter()
 #else
 #define SP_CLK(i) do { } while (0)
@@ -187,11 +187,12 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
     const f16* a_vec = dec_pin_ptr(a.vec); const f16* a_norm_w = dec_pin_ptr(a.norm_w); const int64_t* a_tok = dec_pin_ptr(a.tok);
     int te0 = a.tile_end[0], te1 = a.tile_end[1], te2 = a.tile_end[2], a_nmat = a.nmat;
     int a_rbw = a.rb_per_wave, a_images = a.xs_images, nb = a.nblocks, units_lo = a.units_lo, units_rem = a.units_rem;
-    int early_w = a.early_weights;
-    DEC_PIN_S(early_w);
+    int early_w = a.early_weights, abl = a.ablate;
+    DEC_PIN_S(early_w); DEC_PIN_S(abl);
     DEC_PIN_S(K); DEC_PIN_S(R);
     DEC_PIN_S(te0); DEC_PIN_S(te1); DEC_PIN_S(te2); DEC_PIN_S(a_nmat); DEC_PIN_S(a_rbw); DEC_PIN_S(a_images);
     DEC_PIN_S(nb); DEC_PIN_S(units_lo); DEC_PIN_S(units_rem);
+    SP_CLK(5);                                                       // kernel arguments have arrived
     const int RB = M0.RB;
     uint4* xs = (uint4*) smem;                                       // [xs_images][R]
     float* red = (float*) (smem + (size_t) a_images * R * 16);       // [2][DEC_WAVES][16] + [DEC_WAVES]
@@ -247,6 +248,8 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + i * DEC_THREADS;
             const int ci = idx < nvec ? idx : 0;
+            xraw[i] = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u); wraw[i] = xraw[i];
+            if (abl >= 4) continue;                                  // measurement only: no dependent activation load
             xraw[i] = *(const uint4*) (src + ci * 8);
             if constexpr (PNORM == 1) wraw[i] = *(const uint4*) (a_norm_w + ci * 8);
         }
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
     // (599 / 712 vs 619 / 731 tokens/s worst / best case), so the default issues the first weight batch right away.
     if (!early_w) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     dec_unit_issue<U, G16>(mA, uA, 0, lane, wv0, ep0);               // addresses: scalar arithmetic + one VALU
-    if constexpr (G16) dec_unit_entries<NSLOT>(mA, uA, lane, entA);
+    if constexpr (G16) { if (abl < 3) dec_unit_entries<NSLOT>(mA, uA, lane, entA); }
     if constexpr (EMODE == 1) { if (tid < 16) resA = (float) a.hid_io[tileA * 16 + tid]; }
 
     SP_CLK(0);                                                       // prologue loads + first weight batch issued
@@ -365,11 +368,11 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
             if (p + 1 < NP) {                                                                                               \
                 if (uC.rb0 + (p + 1) * U < uC.rb1) dec_unit_issue<U, G16>(mC, uC, p + 1, lane, DEC_BUF(P * NP + p + 1), DEC_EP(P * NP + p + 1)); \
             } else if (have_next) {                                                                                         \
-                if constexpr (G16) dec_unit_entries<NSLOT>(mN, uN, lane, entN);                                             \
+                if constexpr (G16) { if (abl < 3) dec_unit_entries<NSLOT>(mN, uN, lane, entN); }                            \
                 if constexpr (EMODE == 1) { if (tid < 16) resN = (float) a.hid_io[tileN * 16 + tid]; }                      \
                 dec_unit_issue<U, G16>(mN, uN, 0, lane, DEC_BUF((P ^ 1) * NP), DEC_EP((P ^ 1) * NP));                       \
             }                                                                                                               \
-            if (a.ablate) { _Pragma("unroll") for (int q = 0; q < U; ++q) c[0] += __builtin_bit_cast(float, DEC_BUF(P * NP + p)[q].x ^ DEC_BUF(P * NP + p)[q].w); } \
+            if (abl) { _Pragma("unroll") for (int q = 0; q < U; ++q) c[0] += __builtin_bit_cast(float, DEC_BUF(P * NP + p)[q].x ^ DEC_BUF(P * NP + p)[q].w); } \
             else if (uC.rb0 + p * U < uC.rb1) dec_unit_consume<U, G16, NSLOT>(uC, p, lane, DEC_BUF(P * NP + p), entC, DEC_EP(P * NP + p), xrow, c); \
         }                                                                                                                   \
         if (i == 0) SP_CLK(2);                                                                                              \
@@ -401,6 +404,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
         unsigned long long* dst = g_stream_probe + ((size_t) (PNORM * 2 + (EMODE == 2 ? 1 : EMODE)) * 512 + b) * 8;
 #pragma unroll
         for (int q = 0; q < 5; ++q) dst[q] = sp_t[q] - sp_t0;
+        dst[6] = sp_t[5] - sp_t0;
         dst[5] = (unsigned long long) n_my;
         dst[7] = 1;
     }
@@ -1154,6 +1158,14 @@ extern "C" int exl_decoder_step(void* dec, const int64_t* token_dev, int32_t* po
     }
     if (prev != d->device) (void) hipSetDevice(prev);
     return rc;
+}
+
+extern "C" int exl_decoder_set_hidden(void* dec, void* hidden_dev)
+{
+    Decoder* d = dec_from(dec);
+    EXL_REQUIRE(d && hidden_dev, EXL_E_INVALID, "decoder_set_hidden: invalid argument");
+    d->hid = (f16*) hidden_dev;
+    return 0;
 }
 
 extern "C" int exl_decoder_hidden(void* dec, void** out)

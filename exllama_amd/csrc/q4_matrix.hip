@@ -33,16 +33,19 @@ int launch_make_sequential(Q4Matrix* m, const uint32_t* x_map_host, hipStream_t 
     const size_t wbytes = (size_t) (m->height / 8) * m->width * sizeof(uint32_t);
     uint32_t* tmp = nullptr;
     EXL_HIP(hipMalloc((void**) &tmp, wbytes));
-    EXL_HIP(hipMalloc((void**) &m->x_map, (size_t) m->height * sizeof(uint32_t)));
-    EXL_HIP(hipMemcpyAsync(m->x_map, x_map_host, (size_t) m->height * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    const int n4 = m->width / 4;
-    dim3 grid((n4 + 255) / 256, m->height / 8);
-    hipLaunchKernelGGL(make_sequential_kernel, grid, dim3(256), 0, s, (const uint4*) m->qweight, (uint4*) tmp,
-                       m->x_map, n4);
-    EXL_LAUNCH_CHECK();
-    EXL_HIP(hipMemcpyAsync(m->qweight, tmp, wbytes, hipMemcpyDeviceToDevice, s));
-    EXL_HIP(hipStreamSynchronize(s));
-    EXL_HIP(hipFree(tmp));
+    // every failure path below releases the temporary; m->x_map is released by the caller's free_matrix
+    hipError_t e = hipMalloc((void**) &m->x_map, (size_t) m->height * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(m->x_map, x_map_host, (size_t) m->height * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        const int n4 = m->width / 4;
+        dim3 grid((n4 + 255) / 256, m->height / 8);
+        hipLaunchKernelGGL(make_sequential_kernel, grid, dim3(256), 0, s, (const uint4*) m->qweight, (uint4*) tmp, m->x_map, n4);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(m->qweight, tmp, wbytes, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void) hipFree(tmp);
+    if (e != hipSuccess) EXL_FAIL((int) e, "make_sequential: %s", hipGetErrorString(e));
     return 0;
 }
 
@@ -138,13 +141,16 @@ int launch_retile_t16(Q4Matrix* m, hipStream_t s)
     const size_t wbytes = (size_t) R * m->width * sizeof(uint32_t);
     uint32_t* tmp = nullptr;
     EXL_HIP(hipMalloc((void**) &tmp, wbytes));
-    EXL_HIP(hipMemcpyAsync(tmp, m->qweight, wbytes, hipMemcpyDeviceToDevice, s));
+    hipError_t e = hipMemcpyAsync(tmp, m->qweight, wbytes, hipMemcpyDeviceToDevice, s);
     const size_t npieces = wbytes / 16;
-    hipLaunchKernelGGL(retile_t16_kernel, dim3((unsigned) ((npieces + 255) / 256)), dim3(256), 0, s, tmp, (uint4*) m->qweight,
-                       R / 16, m->width, npieces);
-    EXL_LAUNCH_CHECK();
-    EXL_HIP(hipStreamSynchronize(s));
-    EXL_HIP(hipFree(tmp));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(retile_t16_kernel, dim3((unsigned) ((npieces + 255) / 256)), dim3(256), 0, s, tmp, (uint4*) m->qweight,
+                           R / 16, m->width, npieces);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void) hipFree(tmp);
+    if (e != hipSuccess) EXL_FAIL((int) e, "retile_t16: %s", hipGetErrorString(e));
     m->layout = EXL_LAYOUT_T16;
     return 0;
 }

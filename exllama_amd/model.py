@@ -356,9 +356,12 @@ class ExLlamaCache:
         return ExLlamaCache(self.model, batch_size=self.batch_size, max_seq_len=self.max_seq_len, copy_from=self)
 
     def roll_left(self):
+        """Drop the oldest position (reference: model.py:601-607).  Rolled IN PLACE: the native decode executor and its
+        captured hipGraphs hold the raw addresses of these tensors (enable_decode_graph), so the tensors must not be
+        rebound to new storage."""
         for i in range(len(self.key_states)):
-            self.key_states[i] = torch.roll(self.key_states[i], shifts=-1, dims=2)
-            self.value_states[i] = torch.roll(self.value_states[i], shifts=-1, dims=2)
+            self.key_states[i].copy_(torch.roll(self.key_states[i], shifts=-1, dims=2))
+            self.value_states[i].copy_(torch.roll(self.value_states[i], shifts=-1, dims=2))
         self.current_seq_len -= 1
 
     def copy_states(self, target, from_column, from_columns, to_column, to_columns, from_row, from_rows, to_row, to_rows):
@@ -589,7 +592,7 @@ class ExLlama:
             output_device = input_ids.device
         st = self._decoder
         if (st is not None and cache is st["cache"] and bsz == 1 and seq_len == 1 and lora is None
-                and input_mask is None and not preprocess_only):
+                and input_mask is None and not preprocess_only and st["has_embed"] and st["has_head"]):
             return self._decode_step(input_ids, cache, str(output_device))
         devs = cfg.device_map.get_layers_devs()
 
@@ -650,102 +653,164 @@ class ExLlama:
         return torch.matmul(hidden, self.lm_head_weight.t()).float()
 
     # ---- native decode executor + hipGraph ---------------------------------------------------------------
-    def enable_decode_graph(self, cache, use_graph=True):
+    def _decode_stages(self):
+        """Contiguous runs of layers on one device = the stages of the native executor (the reference's device hops,
+        model.py:1053-1058).  config.decoder_stage_split (a list of layer indices, testing aid) forces extra stage
+        boundaries inside a device."""
+        cfg = self.config
+        cuts = set(getattr(cfg, "decoder_stage_split", None) or [])
+        stages = []
+        for i, dev in enumerate(cfg.device_map.layers):
+            if not str(dev).startswith("cuda"):
+                raise RuntimeError("the native decode executor needs every layer on a HIP device")
+            if stages and stages[-1]["dev"] == dev and i not in cuts:
+                stages[-1]["layers"].append(i)
+            else:
+                stages.append({"dev": dev, "layers": [i]})
+        return stages
+
+    def enable_decode_graph(self, cache, use_graph=True, first_stage=True, last_stage=True):
         """Route bsz = 1, q_len = 1 forwards on `cache` through the native decode executor (5 kernels per layer,
-        exllama_amd/csrc/decode_fused.hip) and, with use_graph, replay them as ONE captured hipGraph per token.
-        The position lives in device memory, so the same graph serves every context length."""
+        exllama_amd/csrc/decode_fused.hip) and, with use_graph, replay them as ONE captured hipGraph per token and device.
+        The position lives in device memory, so the same graph serves every context length.
+
+        A model whose layers sit on several devices (config.device_map / set_auto_map, the reference's layer split) runs as
+        one executor STAGE per device: the residual stream [hidden] fp16 is copied from stage to stage, one hop per device
+        boundary, exactly the reference's `_move_tensor` between layers (model.py:1053-1058).  first_stage / last_stage =
+        False make this model ONE LINK of a split across processes (exllama_amd/pipeline.py): without the embedding the
+        first stage starts from the hidden state handed to decode_stage_step(), without the head the last stage returns it."""
         import ctypes as C
         cfg = self.config
-        devs = cfg.device_map.get_all_devs()
-        if len(devs) != 1 or not devs[0].startswith("cuda"):
-            raise RuntimeError("the native decode executor needs the whole model on one HIP device")
         if cache.batch_size != 1:
             raise RuntimeError("the native decode executor handles batch size 1")
         if cache.max_seq_len > cfg.max_seq_len:
             raise RuntimeError("cache is longer than the RoPE tables (config.max_seq_len)")
-        dev = torch.device(devs[0])
+        stages = self._decode_stages()
+        if first_stage and str(cfg.device_map.embed_tokens) != stages[0]["dev"]:
+            raise RuntimeError("the native decode executor needs the embedding table on the first layer's device")
+        if last_stage and not (str(cfg.device_map.norm) == str(cfg.device_map.lm_head) == stages[-1]["dev"]):
+            raise RuntimeError("the native decode executor needs the final norm and lm_head on the last layer's device")
         self.disable_decode_graph()
         lib = ext._lib
-        sin, cos = self.sincos[devs[0]]
-        handle = C.c_void_p()
-        with cuda_ext._Guard(dev):
-            cuda_ext.check(lib.exl_decoder_create(dev.index, cfg.num_hidden_layers, cfg.hidden_size, cfg.intermediate_size,
-                                                  cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim,
-                                                  cfg.vocab_size, cache.max_seq_len, float(cfg.rms_norm_eps),
-                                                  self.embed_weight.data_ptr(), self.norm.weight.data_ptr(),
-                                                  self.lm_head_weight.data_ptr(), sin.data_ptr(), cos.data_ptr(),
-                                                  C.byref(handle)), "decoder_create")
-            for i, layer in enumerate(self.layers):
-                a, m = layer.self_attn, layer.mlp
-                cuda_ext.check(lib.exl_decoder_set_layer(handle, i, a.q_proj.q4, a.k_proj.q4, a.v_proj.q4, a.o_proj.q4,
-                                                         m.gate_proj.q4, m.up_proj.q4, m.down_proj.q4,
-                                                         layer.input_layernorm.weight.data_ptr(),
-                                                         layer.post_attention_layernorm.weight.data_ptr(),
-                                                         cache.key_states[i].data_ptr(), cache.value_states[i].data_ptr()),
-                               "decoder_set_layer")
+        for k, sg in enumerate(stages):
+            dev = torch.device(sg["dev"])
+            sin, cos = self.sincos[sg["dev"]]
+            emb = self.embed_weight.data_ptr() if (first_stage and k == 0) else None
+            head = last_stage and k == len(stages) - 1
+            handle = C.c_void_p()
+            sg["hid"] = torch.zeros((1, 1, cfg.hidden_size), dtype=torch.float16, device=dev)
+            sg["pos"] = torch.zeros((1,), dtype=torch.int32, device=dev)
+            with cuda_ext._Guard(dev):
+                cuda_ext.check(lib.exl_decoder_create(dev.index, len(sg["layers"]), cfg.hidden_size, cfg.intermediate_size,
+                                                      cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim,
+                                                      cfg.vocab_size, cache.max_seq_len, float(cfg.rms_norm_eps), emb,
+                                                      self.norm.weight.data_ptr() if head else None,
+                                                      self.lm_head_weight.data_ptr() if head else None, sin.data_ptr(), cos.data_ptr(),
+                                                      C.byref(handle)), "decoder_create")
+                cuda_ext.check(lib.exl_decoder_set_hidden(handle, sg["hid"].data_ptr()), "decoder_set_hidden")
+                for j, i in enumerate(sg["layers"]):
+                    layer = self.layers[i]
+                    a, m = layer.self_attn, layer.mlp
+                    cuda_ext.check(lib.exl_decoder_set_layer(handle, j, a.q_proj.q4, a.k_proj.q4, a.v_proj.q4, a.o_proj.q4,
+                                                             m.gate_proj.q4, m.up_proj.q4, m.down_proj.q4,
+                                                             layer.input_layernorm.weight.data_ptr(),
+                                                             layer.post_attention_layernorm.weight.data_ptr(),
+                                                             cache.key_states[i].data_ptr(), cache.value_states[i].data_ptr()),
+                                   "decoder_set_layer")
+            sg["handle"], sg["tdev"], sg["graphs"] = handle, dev, []
+        d0, dl = stages[0]["tdev"], stages[-1]["tdev"]
         st = {
-            "handle": handle, "cache": cache, "dev": dev, "graph": None, "graphs": [],
-            "tok": torch.zeros((1, 1), dtype=torch.int64, device=dev),
-            "pos": torch.zeros((1,), dtype=torch.int32, device=dev),
-            "logits": torch.zeros((1, 1, cfg.vocab_size), dtype=torch.float32, device=dev),
-            "dev_pos": -1,
+            "stages": stages, "handle": stages[0]["handle"], "cache": cache, "dev": dl, "graph": None, "graphs": [],
+            "has_embed": bool(first_stage), "has_head": bool(last_stage),
+            "tok": torch.zeros((1, 1), dtype=torch.int64, device=d0),
+            "logits": torch.zeros((1, 1, cfg.vocab_size), dtype=torch.float32, device=dl),
+            "pos": stages[0]["pos"], "dev_pos": -1,
+            "kv_ptrs": [(k.data_ptr(), v.data_ptr()) for k, v in zip(cache.key_states, cache.value_states)],
         }
         self._decoder = st
         if use_graph:
-            # one captured graph per context bucket: short contexts use fewer KV splits (1 split = nothing to merge)
-            st["graphs"] = []
+            # one captured graph per context bucket and stage: short contexts use fewer KV splits (1 split = nothing to merge)
             st["bucket_splits"] = []
             start = cache.current_seq_len
-            st["pos"].fill_(start)
+            self._set_positions(st, start)
             self._decoder_launch(st, advance=0)                 # eager dry run with the full split count (the K/V written
-            torch.cuda.synchronize(dev)                          # at the current slot are overwritten by the real token later)
+            for sg in stages:                                    # at the current slot are overwritten by the real token later)
+                torch.cuda.synchronize(sg["tdev"])
             for ns, bucket_limit in self.DECODE_BUCKETS:
                 lim = C.c_int()
-                rc = lib.exl_decoder_set_kv_splits(handle, ns, C.byref(lim))
-                if rc != 0:
+                if any(lib.exl_decoder_set_kv_splits(sg["handle"], ns, C.byref(lim)) != 0 for sg in stages):
                     continue                                    # more splits than this decoder has: covered by the last bucket
                 limit = lim.value if bucket_limit is None else min(lim.value, bucket_limit)
                 if st["graphs"] and limit <= st["graphs"][-1][0]:
                     continue
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):                        # capture only records: nothing runs at this position
-                    self._decoder_launch(st, advance=1)
-                st["graphs"].append((limit, g))
+                per_stage = []
+                for k, sg in enumerate(stages):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.device(sg["tdev"]), torch.cuda.graph(g):    # capture only records: nothing runs at this position
+                        self._stage_launch(st, k, advance=1)
+                    per_stage.append(g)
+                st["graphs"].append((limit, per_stage))
                 st["bucket_splits"].append(ns)
             st["graph"] = st["graphs"][-1][1]
-            st["pos"].fill_(start)
-            st["dev_pos"] = start
+            self._set_positions(st, start)
 
     DECODE_BUCKETS = ((1, 160), (4, 640), (0, None))                 # (KV splits, last context served); 0 = the decoder's maximum
+
+    @staticmethod
+    def _set_positions(st, position):
+        for sg in st["stages"]:
+            sg["pos"].fill_(position)
+        st["dev_pos"] = position
 
     def _set_eager_splits(self, st, position):
         """Eager (non-graph) launches pick the KV split count per step by the bucket table the graphs are captured with."""
         import ctypes as C
         for ns, limit in self.DECODE_BUCKETS:
             lim = C.c_int()
-            if ext._lib.exl_decoder_set_kv_splits(st["handle"], ns, C.byref(lim)) != 0:
+            if any(ext._lib.exl_decoder_set_kv_splits(sg["handle"], ns, C.byref(lim)) != 0 for sg in st["stages"]):
                 continue                                            # more splits than this decoder has
             if position <= (lim.value if limit is None else min(limit, lim.value)):
                 return
         raise RuntimeError(f"position {position} beyond the decoder's context limit")
 
-    def _decoder_launch(self, st, advance):
-        with cuda_ext._Guard(st["dev"]):
-            cuda_ext.check(ext._lib.exl_decoder_step(st["handle"], st["tok"].data_ptr(), st["pos"].data_ptr(),
-                                                     st["logits"].data_ptr(), int(advance),
-                                                     torch.cuda.current_stream(st["dev"]).cuda_stream), "decoder_step")
+    def _stage_launch(self, st, k, advance):
+        sg = st["stages"][k]
+        last = k == len(st["stages"]) - 1
+        with cuda_ext._Guard(sg["tdev"]):
+            cuda_ext.check(ext._lib.exl_decoder_step(sg["handle"], st["tok"].data_ptr() if (k == 0 and st["has_embed"]) else None,
+                                                     sg["pos"].data_ptr(), st["logits"].data_ptr() if (last and st["has_head"]) else None,
+                                                     int(advance), torch.cuda.current_stream(sg["tdev"]).cuda_stream), "decoder_step")
 
-    def _decode_step(self, input_ids, cache, output_device):
-        st = self._decoder
+    @staticmethod
+    def _hop(st, k):
+        """The one exchange per stage boundary: the residual stream [hidden] fp16, device to device (stream-ordered on both)."""
+        st["stages"][k]["hid"].copy_(st["stages"][k - 1]["hid"], non_blocking=True)
+
+    def _decoder_launch(self, st, advance, graphs=None):
+        for k in range(len(st["stages"])):
+            if k:
+                self._hop(st, k)
+            if graphs is not None:
+                graphs[k].replay()
+            else:
+                self._stage_launch(st, k, advance)
+
+    def _check_cache_storage(self, st, cache):
+        """The executor and its graphs hold raw K/V addresses: a cache whose tensors were rebound (not rolled / copied in
+        place) must not be used with them."""
+        if st["kv_ptrs"] != [(k.data_ptr(), v.data_ptr()) for k, v in zip(cache.key_states, cache.value_states)]:
+            raise RuntimeError("the cache's K/V tensors were replaced after enable_decode_graph(); call it again")
+
+    def _run_token(self, st, cache):
         if cache.current_seq_len + 1 > cache.max_seq_len:
             raise RuntimeError(f"sequence ({cache.current_seq_len} + 1) exceeds the cache length {cache.max_seq_len}")
-        st["tok"].copy_(input_ids.view(1, 1), non_blocking=True)
+        self._check_cache_storage(st, cache)
         if st["dev_pos"] != cache.current_seq_len:              # host rewound / advanced the cache outside the executor
-            st["pos"].fill_(cache.current_seq_len)
+            self._set_positions(st, cache.current_seq_len)
         if st["graph"] is not None:
-            for limit, g in st["graphs"]:                        # first bucket whose context limit covers this position
+            for limit, per_stage in st["graphs"]:                # first bucket whose context limit covers this position
                 if cache.current_seq_len <= limit:
-                    g.replay()
+                    self._decoder_launch(st, 1, graphs=per_stage)
                     break
             else:
                 raise RuntimeError(f"position {cache.current_seq_len} beyond the decoder's context limit")
@@ -754,7 +819,29 @@ class ExLlama:
             self._decoder_launch(st, advance=1)
         cache.current_seq_len += 1
         st["dev_pos"] = cache.current_seq_len
+
+    def _decode_step(self, input_ids, cache, output_device):
+        st = self._decoder
+        if not (st["has_embed"] and st["has_head"]):
+            raise RuntimeError("this model is one stage of a layer split: use decode_stage_step()")
+        st["tok"].copy_(input_ids.view(1, 1), non_blocking=True)
+        self._run_token(st, cache)
         return _move_tensor(st["logits"].clone(), output_device, "logits", self.config)
+
+    def decode_stage_step(self, cache, input_ids=None, hidden_in=None):
+        """One token through THIS process's part of a layer split (enable_decode_graph(..., first_stage / last_stage)):
+        the first link takes `input_ids` [1, 1], later links the hidden state [1, 1, hidden] fp16 of the previous one;
+        returns fp32 logits [1, 1, vocab] from the last link, the outgoing hidden state (the executor's own buffer: send or
+        copy it before the next step) from the others."""
+        st = self._decoder
+        if st is None or st["cache"] is not cache:
+            raise RuntimeError("decode_stage_step needs enable_decode_graph(cache) first")
+        if st["has_embed"]:
+            st["tok"].copy_(input_ids.view(1, 1), non_blocking=True)
+        else:
+            st["stages"][0]["hid"].copy_(hidden_in.view(1, 1, -1), non_blocking=True)
+        self._run_token(st, cache)
+        return st["logits"].clone() if st["has_head"] else st["stages"][-1]["hid"]
 
     def generate_greedy(self, first_token, cache, num_tokens):
         """num_tokens greedy steps entirely on the device: each replay of a captured hipGraph runs the decode kernels AND the
@@ -762,15 +849,17 @@ class ExLlama:
         loop does `torch.argmax(logits)` + forward per token (test_benchmark_inference.py:188-191).  `first_token` is the
         token at position cache.current_seq_len; returns the num_tokens tokens that follow it (LongTensor on the device) and
         leaves the last step's logits in the executor's buffer (self.last_decoder_logits()).  Needs
-        enable_decode_graph(cache, use_graph=True)."""
+        enable_decode_graph(cache, use_graph=True) on a model that sits on one device."""
         st = self._decoder
         if st is None or st["cache"] is not cache or st["graph"] is None:
             raise RuntimeError("generate_greedy needs enable_decode_graph(cache) with graph replay")
+        if len(st["stages"]) != 1 or not (st["has_embed"] and st["has_head"]):
+            raise RuntimeError("generate_greedy needs the whole model in one executor stage (one device)")
+        self._check_cache_storage(st, cache)
         start = cache.current_seq_len
         if start + num_tokens > cache.max_seq_len:
             raise RuntimeError(f"sequence ({start} + {num_tokens}) exceeds the cache length {cache.max_seq_len}")
         if "history" not in st:
-            import ctypes as C
             st["history"] = torch.zeros((cache.max_seq_len + 1,), dtype=torch.int64, device=st["dev"])
             st["ggraphs"] = []
             torch.cuda.synchronize(st["dev"])
@@ -788,7 +877,7 @@ class ExLlama:
             st["tok"].copy_(keep_tok); st["pos"].copy_(keep_pos)
         st["tok"].copy_(first_token.view(1, 1), non_blocking=True)
         if st["dev_pos"] != start:
-            st["pos"].fill_(start)
+            self._set_positions(st, start)
         for i in range(num_tokens):
             p = start + i
             for limit, g in st["ggraphs"]:
@@ -814,26 +903,37 @@ class ExLlama:
     def decoder_profile(self, input_ids, cache, steps=4):
         """Measurement aid for bench.py: per kernel class of the native executor, `steps` passes over all layers' launches
         of that class back to back between two hipEvents (include/exl_amd.h: exl_decoder_step_timed), at the cache's current
-        position (not advanced; the K/V slot there is overwritten).  Returns {class: ms per token} for DECODER_CLASSES."""
+        position (not advanced; the K/V slot there is overwritten).  Returns {class: ms per token} for DECODER_CLASSES,
+        summed over the executor's stages."""
         import ctypes as C
         st = self._decoder
         if st is None or st["cache"] is not cache:
             raise RuntimeError("decoder_profile needs enable_decode_graph(cache) first")
-        st["tok"].copy_(input_ids.view(1, 1))
-        st["pos"].fill_(cache.current_seq_len)
+        if st["has_embed"]:
+            st["tok"].copy_(input_ids.view(1, 1))
+        self._set_positions(st, cache.current_seq_len)
         st["dev_pos"] = -1
-        buf = (C.c_float * len(self.DECODER_CLASSES))()
-        with cuda_ext._Guard(st["dev"]):
-            stream = torch.cuda.current_stream(st["dev"]).cuda_stream
-            cuda_ext.check(ext._lib.exl_decoder_step_timed(st["handle"], st["tok"].data_ptr(), st["pos"].data_ptr(),
-                                                           st["logits"].data_ptr(), int(steps), stream, buf), "decoder_step_timed")
-        return {k: float(buf[j]) for j, k in enumerate(self.DECODER_CLASSES)}
+        out = {k: 0.0 for k in self.DECODER_CLASSES}
+        for k, sg in enumerate(st["stages"]):
+            buf = (C.c_float * len(self.DECODER_CLASSES))()
+            last = k == len(st["stages"]) - 1
+            with cuda_ext._Guard(sg["tdev"]):
+                stream = torch.cuda.current_stream(sg["tdev"]).cuda_stream
+                cuda_ext.check(ext._lib.exl_decoder_step_timed(sg["handle"], st["tok"].data_ptr() if (k == 0 and st["has_embed"]) else None,
+                                                               sg["pos"].data_ptr(), st["logits"].data_ptr() if (last and st["has_head"]) else None,
+                                                               int(steps), stream, buf), "decoder_step_timed")
+            for j, name in enumerate(self.DECODER_CLASSES):
+                out[name] += float(buf[j])
+        return out
 
     def disable_decode_graph(self):
         st = getattr(self, "_decoder", None)
         if st is not None:
             st["graph"] = None
-            ext._lib.exl_decoder_free(st["handle"])
+            st["graphs"] = []
+            st.pop("ggraphs", None)
+            for sg in st["stages"]:
+                ext._lib.exl_decoder_free(sg["handle"])
         self._decoder = None
 
     def free_unmanaged(self):

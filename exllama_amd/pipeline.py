@@ -54,9 +54,29 @@ class LayerSplitRunner:
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.hidden_size, self.device, self.dtype = hidden_size, device, dtype
 
+    def enable_decode_executor(self, use_graph=True):
+        """Single-token steps of this rank run through the native decode executor (exllama_amd.model.ExLlama.enable_decode_graph)
+        as one link of the split: rank 0 owns the embedding, the last rank the head, the fp16 hidden state [1, 1, hidden]
+        travels between them exactly as in forward()."""
+        self.stage.enable_decode_graph(self.cache, use_graph=use_graph, first_stage=self.rank == 0, last_stage=self.rank == self.world - 1)
+        self._executor = True
+
+    def _decode_token(self, input_ids):
+        hidden_in = None
+        if self.rank > 0:
+            hidden_in = torch.empty((1, 1, self.hidden_size), dtype=self.dtype, device=self.device)
+            self.dist.recv(hidden_in, src=self.rank - 1)
+        out = self.stage.decode_stage_step(self.cache, input_ids=input_ids if self.rank == 0 else None, hidden_in=hidden_in)
+        if self.rank < self.world - 1:
+            self.dist.send(out.contiguous(), dst=self.rank + 1)       # (the send completes before the next step overwrites the buffer)
+            return None
+        return out
+
     def forward(self, input_ids, last_id_only=True):
         """input_ids [bsz, q_len] must be the same on every rank (its VALUES are only read on rank 0)."""
         bsz, q_len = input_ids.shape
+        if getattr(self, "_executor", False) and bsz == 1 and q_len == 1:
+            return self._decode_token(input_ids)
         if self.rank == 0:
             hidden = self.stage.embed(input_ids)
         else:

@@ -74,7 +74,13 @@ int exl_cleanup(void);
 /* ---- Q4 matrix handle (reference: exllama_ext.cpp:157-194 make_q4, q4_matrix.cu:26-53, :104-168) ---- */
 /* height = in_features K, width = out_features N, groups = K / groupsize.
  * g_idx_host: int32 [K] in HOST memory or NULL (reference passes the CPU tensor, model.py:144).
- * Synchronises `stream` when g_idx_host != NULL (as the reference's cudaDeviceSynchronize, q4_matrix.cu:163). */
+ * Synchronises `stream` when g_idx_host != NULL (as the reference's cudaDeviceSynchronize, q4_matrix.cu:163).
+ * OWNERSHIP: the handle borrows the three tensors (the caller keeps them alive, as Ex4bitLinear does, model.py:141-143) and
+ * REWRITES `qweight` IN PLACE: act-order repack (the reference does the same, q4_matrix.cu:159) and, for every Llama shape
+ * (K % 128 == 0, N % 16 == 0, groupsize % 32 == 0), the re-tiling into the streaming layout -- so a tensor can back ONE handle,
+ * once: calling make_q4 again on an already re-tiled tensor (e.g. reloading a model from a cached tensor dict) computes
+ * garbage and cannot be detected by address (allocators recycle addresses of freed tensors while handles live until
+ * cleanup). */
 int exl_make_q4(int device, int height, int width, int groups, uint32_t* qweight, uint32_t* qzeros,
                 uint16_t* scales, const uint32_t* g_idx_host, void* stream, void** out_handle);
 int exl_free_q4(void* handle);
@@ -224,6 +230,10 @@ int exl_decoder_step_timed(void* decoder, const int64_t* token_dev, int32_t* pos
 /* The decoder's residual stream, fp16 [hidden] in device memory: input of a stage created without `embed`, output of a stage
  * created without `lm_head` (valid after the step's kernels have run on its stream). */
 int exl_decoder_hidden(void* decoder, void** out_hidden_dev);
+/* Makes the decoder use a CALLER-OWNED residual stream (fp16 [hidden], device memory that outlives the decoder and every graph
+ * captured from it) instead of its own: the hand-off buffer between the stages of a layer split -- the caller copies it from
+ * device to device or sends it to the next rank (RCCL point-to-point).  Call before the first step / capture. */
+int exl_decoder_set_hidden(void* decoder, void* hidden_dev);
 /* Test / measurement aid: which kernel configuration one step launches for kernel class `cls` with the current KV-split
  * setting, without launching anything.  out10: [0] launched (0 = this class is folded away), GEMV classes: [1] U (16-byte
  * loads in flight per lane), [2] NP (passes), [3] G16 (group size % 128 == 0), [4] PNORM, [5] EMODE, [6] NV (8-half

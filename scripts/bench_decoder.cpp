@@ -127,11 +127,11 @@ int main(int argc, char** argv)
                 for (int i = 0; i < 7; ++i) printf("  %s %.0f", ph[i], (double) pr[i] / (double) pr[7]);
                 printf("\n");
             }
-            static const char* cn[4] = {"o_proj/down (the LAST launched: down)", "-", "qkv", "gate_up"};
-            for (int cls = 0; cls < 4; ++cls) {
+            static const char* cn[8] = {"-", "plain vector + residual (the LAST launched: down)", "qkv", "gate_up", "-", "-", "-", "o_proj + split merge"};
+            for (int cls = 0; cls < 8; ++cls) {
                 if (exl_debug_stream_probe(cls, pr) != 0 || !pr[7]) continue;
-                printf("ctx %5d  stream kernel class %d [%s], mean cycles over %llu blocks (%.2f units/block): loads issued %.0f  image staged %.0f  unit 0 consumed %.0f  unit 0 reduced %.0f  all units done %.0f\n",
-                       p0, cls, cn[cls], pr[7], (double) pr[5] / pr[7], (double) pr[0] / pr[7], (double) pr[1] / pr[7], (double) pr[2] / pr[7], (double) pr[3] / pr[7], (double) pr[4] / pr[7]);
+                printf("ctx %5d  stream kernel class %d [%s], mean cycles over %llu blocks (%.2f units/block): args arrived %.0f  loads issued %.0f  image staged %.0f  unit 0 consumed %.0f  unit 0 reduced %.0f  all units done %.0f\n",
+                       p0, cls, cn[cls], pr[7], (double) pr[5] / pr[7], (double) pr[6] / pr[7], (double) pr[0] / pr[7], (double) pr[1] / pr[7], (double) pr[2] / pr[7], (double) pr[3] / pr[7], (double) pr[4] / pr[7]);
             }
         }
 #endif

@@ -16,7 +16,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int V, bool MFMA, int U, bool SYNC>
+template <int V, bool MFMA, int U, bool SYNC, bool ILV = false>
 __global__ __launch_bounds__(512) void tile_stream(const u32x4* __restrict__ w, int ntiles, int rbw, float* vec, _Float16* out)
 {
     __shared__ u32x4 xs[1024];                       // activation image (16 KB)
@@ -30,17 +30,20 @@ __global__ __launch_bounds__(512) void tile_stream(const u32x4* __restrict__ w, 
     const f16x2 k1 = {(_Float16) 0.0625f, (_Float16) 0.0625f};
     int par = 0;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x, par ^= 1) {
-        const u32x4* base = w + ((size_t) t * 8 + wave) * (size_t) rbw * 64 + lane;
+        // ILV: the 8 waves of a block read 8 CONSECUTIVE KiB per step (wave w takes row-blocks w, w + 8, ...) instead of 8
+        // separate 1 KiB pieces 8 KiB apart (wave w takes the contiguous slice [w * rbw, (w + 1) * rbw))
+        const u32x4* base = ILV ? w + ((size_t) t * 8 * rbw + wave) * 64 + lane : w + ((size_t) t * 8 + wave) * (size_t) rbw * 64 + lane;
+        constexpr int RS = ILV ? 8 * 64 : 64;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         u32x4 buf[2][U];
 #pragma unroll
-        for (int i = 0; i < U; ++i) buf[0][i] = __builtin_nontemporal_load(base + i * 64);
+        for (int i = 0; i < U; ++i) buf[0][i] = __builtin_nontemporal_load(base + i * RS);
         const int npass = rbw / U;
 #pragma unroll 2
         for (int p = 0; p < npass; ++p) {
             if (p + 1 < npass) {
 #pragma unroll
-                for (int i = 0; i < U; ++i) buf[(p + 1) & 1][i] = __builtin_nontemporal_load(base + ((p + 1) * U + i) * 64);
+                for (int i = 0; i < U; ++i) buf[(p + 1) & 1][i] = __builtin_nontemporal_load(base + ((p + 1) * U + i) * RS);
             }
 #pragma unroll
             for (int i = 0; i < U; ++i) {
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(512) void tile_stream(const u32x4* __restrict__ w, 
     if (blockIdx.x == 0) vec[tid * 4] = 1e-30f * (float) tid;
 }
 
-template <int V, bool MFMA, int U, bool SYNC>
+template <int V, bool MFMA, int U, bool SYNC, bool ILV = false>
 static void run(const char* name, const u32x4* w, float* vec, _Float16* out, int grid)
 {
     const int ntiles = 688, rbw = 8;                           // 688 tiles x 64 KB = 45.1 MB per kernel (the 7B gate_up launch)
@@ -86,7 +89,7 @@ static void run(const char* name, const u32x4* w, float* vec, _Float16* out, int
     const int n = 80;
     CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
     for (int i = 0; i < n; ++i)
-        hipLaunchKernelGGL((tile_stream<V, MFMA, U, SYNC>), dim3(grid), dim3(512), 0, s, w + (size_t) i * (pieces + 4096), ntiles, rbw, vec, out);
+        hipLaunchKernelGGL((tile_stream<V, MFMA, U, SYNC, ILV>), dim3(grid), dim3(512), 0, s, w + (size_t) i * (pieces + 4096), ntiles, rbw, vec, out);
     CK(hipStreamEndCapture(s, &g));
     CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -109,7 +112,9 @@ int main()
     printf("tile-structured stream, 45.1 MB per kernel, dependent chain in a hipGraph (us include the launch boundary)\n");
     run<0, false, 4, true>("loads only, U=4, barrier per tile", w, vec, out, 512);
     run<0, false, 4, false>("loads only, U=4, no barrier", w, vec, out, 512);
-    run<0, false, 8, true>("loads only, U=8 (whole slice in flight)", w, vec, out, 512);
+    run<0, false, 4, true, true>("loads only, U=4, waves interleaved in K", w, vec, out, 512);
+    run<0, false, 2, true>("loads only, U=2", w, vec, out, 512);
+    run<0, false, 2, true, true>("loads only, U=2, waves interleaved in K", w, vec, out, 512);
     run<0, false, 4, true>("loads only, U=4, 1 block per CU", w, vec, out, 256);
     run<0, false, 4, true>("loads only, U=4, one tile per block", w, vec, out, 688);
     run<0, true, 4, true>("4 MFMA per piece, no VALU", w, vec, out, 512);
@@ -118,6 +123,6 @@ int main()
     run<12, true, 4, true>("4 MFMA + 12 pk VALU per dword", w, vec, out, 512);
     run<16, true, 4, true>("4 MFMA + 16 pk VALU per dword", w, vec, out, 512);
     run<8, false, 4, true>("8 pk VALU per dword, no MFMA", w, vec, out, 512);
-    run<8, true, 8, true>("4 MFMA + 8 pk VALU, U=8", w, vec, out, 512);
+    run<8, true, 4, true, true>("4 MFMA + 8 pk VALU, waves interleaved in K", w, vec, out, 512);
     return 0;
 }

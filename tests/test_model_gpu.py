@@ -419,3 +419,70 @@ def test_native_decode_executor_at_real_layer_shapes(key):
                 assert got.tolist() == [t1, int(l2[0, -1].argmax())]
     assert len(seen) >= 3, seen                                      # 1 split, 4 splits and the decoder's maximum all ran
     model.free_unmanaged()
+
+
+def test_decode_executor_as_stages_matches_the_single_executor_bit_for_bit():
+    """The layer split of the reference (ExLlamaDeviceMap, model.py:636-668; hop at :1053-1058) on the native executor:
+    (a) ONE model whose executor is cut into three stages (config.decoder_stage_split stands in for a device boundary: the
+    test boxes have one GPU), residual stream handed over through the stages' buffers;
+    (b) TWO models, each holding half of the layers (pipeline.stage_tensors), driven as the two links of a split across
+    processes (decode_stage_step: hidden state out of link 0 into link 1).
+    Both must reproduce the single-executor logits BIT FOR BIT, eager and replayed, and keep working across KV-split buckets."""
+    from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
+    from exllama_amd.pipeline import stage_tensors
+    dims = synth.LLAMA_TINY_HD128
+    L = 4
+    tensors = synth.make_checkpoint(dims, groupsize=128, act_order=True, seed=17, device="cpu", zeros="rand", num_layers=L)
+
+    def build(t, n_layers, **over):
+        cfg = ExLlamaConfig(synth.config_dict(dims, n_layers))
+        cfg.max_seq_len = 256
+        for k, v in over.items():
+            setattr(cfg, k, v)
+        m = ExLlama(cfg, tensors={k: v.clone() for k, v in t.items()})
+        return m, ExLlamaCache(m)
+
+    ids = torch.randint(1, dims.vocab_size, (1, 150), generator=torch.Generator().manual_seed(6)).to("cuda:0")    # decode crosses the 160-key bucket
+    n_new = 14
+    whole, c_whole = build(tensors, L)
+    staged, c_staged = build(tensors, L, decoder_stage_split=[1, 3])
+    lo, c_lo = build(stage_tensors(tensors, 0, 2), 2)
+    hi, c_hi = build(stage_tensors(tensors, 2, 4), 2)
+    # prompt: whole model vs the two links run back to back (op path: embed -> layers | layers -> head)
+    ref_logits = whole.forward(ids, c_whole)
+    staged_logits = staged.forward(ids, c_staged)
+    h = lo.forward_layers(lo.embed(ids), c_lo)
+    c_lo.current_seq_len += ids.shape[1]
+    h = hi.forward_layers(h, c_hi)
+    c_hi.current_seq_len += ids.shape[1]
+    assert torch.equal(hi.head(h), ref_logits) and torch.equal(staged_logits, ref_logits)
+    for use_graph in (False, True):
+        for m, c in ((whole, c_whole), (staged, c_staged), (lo, c_lo), (hi, c_hi)):
+            c.current_seq_len = ids.shape[1]
+        whole.enable_decode_graph(c_whole, use_graph=use_graph)
+        staged.enable_decode_graph(c_staged, use_graph=use_graph)
+        assert len(staged._decoder["stages"]) == 3 and len(whole._decoder["stages"]) == 1
+        lo.enable_decode_graph(c_lo, use_graph=use_graph, last_stage=False)
+        hi.enable_decode_graph(c_hi, use_graph=use_graph, first_stage=False)
+        tok = ref_logits[0, -1].argmax().view(1, 1)
+        for i in range(n_new):
+            a = whole.forward(tok, c_whole)
+            b = staged.forward(tok, c_staged)
+            hid = lo.decode_stage_step(c_lo, input_ids=tok)
+            assert hid.shape == (1, 1, dims.hidden_size) and hid.dtype == torch.float16
+            c2 = hi.decode_stage_step(c_hi, hidden_in=hid.clone())
+            assert torch.equal(a, b), (use_graph, i)
+            assert torch.equal(a, c2), (use_graph, i)
+            tok = a[0, -1].argmax().view(1, 1)
+        assert c_lo.current_seq_len == c_hi.current_seq_len == c_whole.current_seq_len == ids.shape[1] + n_new
+        for l in range(L):                                            # and the caches the stages wrote are the whole model's
+            src = c_lo if l < 2 else c_hi
+            assert torch.equal(src.key_states[l % 2][:, :, :c_whole.current_seq_len], c_whole.key_states[l][:, :, :c_whole.current_seq_len])
+    with pytest.raises(RuntimeError):
+        staged.generate_greedy(tok, c_staged, 1)                      # device-side generation needs one stage
+    c_whole.roll_left()                                               # in place: the executor keeps working after a roll
+    c_whole.current_seq_len = ids.shape[1]
+    assert torch.isfinite(whole.forward(tok, c_whole)).all()
+    for m in (whole, staged, lo, hi):
+        m.disable_decode_graph()
+    whole.free_unmanaged()

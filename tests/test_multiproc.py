@@ -132,3 +132,93 @@ def test_layer_split_matches_single_process():
         assert p.exitcode == 0
     assert got_toks == toks
     assert torch.equal(got_logits, logits)
+
+
+# ---- the same split with CHECKPOINT-shaped stages: every rank builds its link from pipeline.stage_tensors() of a real GPTQ
+# checkpoint layout.  exllama_amd.model.ExLlama has no CPU path by design (the product fails loudly without a HIP device),
+# so on CPU the stage is the oracle model behind the same three-method interface (embed / forward_layers / head): what is
+# covered here is the cross-rank logic with real tensors -- layer re-indexing, per-rank caches, one fp16 hidden-state
+# hand-off per boundary, token broadcast -- against the unsplit model, bit for bit.
+class _OracleStage:
+    def __init__(self, cfg, tensors, n_layers):
+        import numpy as np
+        from oracle.model_oracle import OracleLlama
+        self.np = np
+        self.m = OracleLlama(cfg, tensors, max_seq_len=32, num_layers=n_layers)
+
+    def embed(self, ids):
+        return torch.from_numpy(self.m.embed[ids.numpy()])
+
+    def forward_layers(self, hidden, cache):
+        h = hidden.numpy()
+        for i in range(self.m.L):
+            h = self.m.layer_forward(i, h)
+        self.m.past += hidden.shape[1]
+        return torch.from_numpy(self.np.ascontiguousarray(h))
+
+    def head(self, hidden, last_id_only=True):
+        from oracle import exl_oracle as O
+        h = hidden.numpy()
+        if last_id_only:
+            h = h[:, -1:, :]
+        b, q, d = h.shape
+        hn = O.rms_norm(h.reshape(-1, d), self.m.norm_w, self.m.eps)
+        lg = (hn.astype(self.np.float32) @ self.m.lm_head.astype(self.np.float32).T).astype(self.np.float16).astype(self.np.float32)
+        return torch.from_numpy(lg.reshape(b, q, -1))
+
+
+def _ckpt():
+    from exllama_amd import synth
+    dims = synth.LLAMA_TINY
+    L = 4
+    return dims, L, synth.make_checkpoint(dims, groupsize=64, act_order=True, seed=31, device="cpu", zeros="rand", num_layers=L)
+
+
+def _oracle_pipe_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from exllama_amd import synth
+    from exllama_amd.pipeline import LayerSplitRunner, split_layers, stage_tensors
+    dims, L, tensors = _ckpt()
+    first, last = split_layers(L, world)[rank]
+    stage = _OracleStage(synth.config_dict(dims, last - first), stage_tensors(tensors, first, last), last - first)
+    runner = LayerSplitRunner(stage, None, dist, dims.hidden_size, "cpu")
+    ids = torch.tensor([[3, 7, 11, 13, 17]])
+    logits = runner.forward(ids)
+    toks = []
+    for _ in range(3):
+        tok = runner.next_token(logits)
+        toks.append(int(tok))
+        logits = runner.forward(tok)
+    if rank == world - 1:
+        out.put((toks, logits))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_layer_split_of_a_real_checkpoint_layout_matches_the_unsplit_model():
+    import numpy as np
+    from exllama_amd import synth
+    from oracle.model_oracle import OracleLlama
+    dims, L, tensors = _ckpt()
+    full = OracleLlama(synth.config_dict(dims, L), tensors, max_seq_len=32)
+    logits = full.forward(np.array([[3, 7, 11, 13, 17]]))
+    toks = []
+    for _ in range(3):
+        t = int(np.argmax(logits[0, -1]))
+        toks.append(t)
+        logits = full.forward(np.array([[t]]))
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_oracle_pipe_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got_toks, got_logits = out.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got_toks == toks
+    assert np.array_equal(got_logits.numpy(), logits)

@@ -1,0 +1,84 @@
+"""The north star's drop-in claim, executed: the reference's UNMODIFIED model.py (/root/reference/model.py, staged by
+scripts/stage_reference_py.sh into the git-ignored oracle/_ref/refpy/ so that it reaches the GPU box) builds ITS ExLlama
+class on a synthetic checkpoint, with `import cuda_ext` resolving to this repository's shim (cuda_ext.py at the repo root ->
+exllama_amd.cuda_ext -> the C ABI -> the HIP kernels), and its logits are compared with exllama_amd.model.ExLlama and with
+the CPU oracle model on the same tokens.  Skipped where the staged copy is absent."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from exllama_amd import synth
+from oracle.model_oracle import OracleLlama
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFPY = os.path.join(ROOT, "oracle", "_ref", "refpy")
+
+
+@pytest.fixture(scope="module")
+def ref_model_module():
+    if not os.path.exists(os.path.join(REFPY, "model.py")):
+        pytest.skip("reference model.py not staged (scripts/stage_reference_py.sh)")
+    for p in (REFPY, ROOT):                               # ROOT first: `import cuda_ext` must be OUR shim
+        if p in sys.path:
+            sys.path.remove(p)
+        sys.path.insert(0, p)
+    sys.modules.pop("model", None)
+    sys.modules.pop("cuda_ext", None)
+    mod = importlib.import_module("model")
+    assert os.path.samefile(os.path.dirname(mod.__file__), REFPY)
+    import cuda_ext
+    assert os.path.samefile(os.path.dirname(cuda_ext.__file__), ROOT)
+    return mod
+
+
+@pytest.mark.parametrize("name,gs,act", [("tiny_gqa", 128, True), ("tiny_hd128", 64, False)])
+def test_reference_model_py_runs_on_the_shim(ref_model_module, tmp_path, name, gs, act):
+    ref = ref_model_module
+    dims = synth.PRESETS[name]
+    cfg_path, st_path = synth.save_checkpoint(str(tmp_path), dims, groupsize=gs, act_order=act, seed=23, zeros="rand")
+    tensors = synth.make_checkpoint(dims, groupsize=gs, act_order=act, seed=23, device="cpu", zeros="rand")
+    ids = torch.randint(1, dims.vocab_size, (1, 21), generator=torch.Generator().manual_seed(5))
+
+    # ---- the reference's own classes (model.py:39-127 config, :721-1082 model), untouched
+    rcfg = ref.ExLlamaConfig(cfg_path)
+    rcfg.model_path = st_path
+    rcfg.max_seq_len = 64
+    rmodel = ref.ExLlama(rcfg)
+    rcache = ref.ExLlamaCache(rmodel)
+    r_logits = rmodel.forward(ids, rcache, last_id_only=False).float().cpu().numpy()     # rows >= 8: q4_matmul -> MFMA GEMM, SDPA
+    tok = torch.tensor([[int(np.argmax(r_logits[0, -1]))]])
+    r_step = rmodel.forward(tok, rcache).float().cpu().numpy()                             # rows == 1: q4_attn / q4_attn_2 / q4_mlp
+    short = rmodel.forward(ids[:, :3], ref.ExLlamaCache(rmodel), last_id_only=False).float().cpu().numpy()   # 2 < rows < 8: GEMV, matmul attention
+    assert rcache.current_seq_len == 22
+    rmodel.free_unmanaged()
+
+    # ---- this repository's model on the same checkpoint
+    from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
+    cfg = ExLlamaConfig(cfg_path)
+    cfg.model_path = st_path
+    cfg.max_seq_len = 64
+    model = ExLlama(cfg)
+    cache = ExLlamaCache(model)
+    o_logits = model.forward(ids.to("cuda:0"), cache, last_id_only=False).float().cpu().numpy()
+    o_step = model.forward(tok.to("cuda:0"), cache).float().cpu().numpy()
+    model.free_unmanaged()
+
+    # ---- oracle
+    orc = OracleLlama(synth.config_dict(dims), tensors, max_seq_len=64)
+    c_logits = orc.forward(ids.numpy(), last_id_only=False)
+    c_step = orc.forward(tok.numpy())
+    orc.reset()
+    c_short = orc.forward(ids[:, :3].numpy(), last_id_only=False)
+
+    scale = float(np.abs(c_logits).max())
+    for got, want in ((r_logits, c_logits), (r_step, c_step), (short, c_short), (r_logits, o_logits), (r_step, o_step)):
+        assert np.isfinite(got).all()
+        assert np.abs(got - want).max() <= 2e-2 * scale, (np.abs(got - want).max(), scale)
+    top2 = np.sort(c_step[0, -1])[-2:]
+    assert int(np.argmax(r_step[0, -1])) == int(np.argmax(c_step[0, -1])) or top2[1] - top2[0] < 4e-2 * scale
