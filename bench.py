@@ -300,6 +300,41 @@ def main():
     if args.layers is not None:
         result["config"]["INVALID"] = "truncated model (--layers): not a benchmark result"
 
+    # ---- further protocol points, measured after the timed region (not part of `value`) -----------------------------
+    # the reference's own `-p` lengths (test_benchmark_inference.py:157-180: S = max_seq_len - 128 = 1920 with -l 2048) and
+    # the 128-token prompt of BASELINE configs[0]; each: 2 warm-up passes, then the mean of 3
+    if rank == 0 and world == 1:
+        def timed_prefill(n_tok, reps=3):
+            for _ in range(2):
+                cache.current_seq_len = 0
+                model.forward(ids[:, :n_tok], cache)
+            torch.cuda.synchronize()
+            tot = 0.0
+            for _ in range(reps):
+                cache.current_seq_len = 0
+                a, b = ev(), ev()
+                a.record()
+                lg = model.forward(ids[:, :n_tok], cache)
+                b.record()
+                torch.cuda.synchronize()
+                tot += a.elapsed_time(b)
+            return tot / reps, lg
+        extra = {}
+        if S > 1920:
+            ms_1920, lg = timed_prefill(1920)
+            a, b = ev(), ev()
+            a.record()
+            decode(G, lg)                                         # the reference's worst case: 128 tokens from context 1920
+            b.record()
+            torch.cuda.synchronize()
+            extra["reference_protocol_S1920"] = {"prefill_tokens_per_s": round(1920 / (ms_1920 / 1e3), 1), "prefill_ms": round(ms_1920, 3),
+                                                 "decode_tokens_per_s": round(G / (a.elapsed_time(b) / 1e3), 2)}
+        if S >= 128:
+            ms_128, _ = timed_prefill(128)
+            extra["prompt_128_tokens"] = {"prefill_tokens_per_s": round(128 / (ms_128 / 1e3), 1), "prefill_ms": round(ms_128, 3),
+                                          "note": "BASELINE configs[0] prompt length (<= 512 rows: the un-specialised 128x128-tile GEMM)"}
+        result["other_lengths"] = extra
+
     # ---- whole-path roofline fractions (algorithmic bytes / flops) ------------------------------
     full = synth.LlamaDims(dims.hidden_size, dims.intermediate_size, L, dims.num_attention_heads, dims.num_key_value_heads,
                            dims.vocab_size)
@@ -320,9 +355,14 @@ def main():
             result["roofline"] = decoder_roofline_probe(model, cache, full, args.groupsize, S)
         else:
             result["roofline"] = gemv_roofline_probe(model, args.groupsize, dev)
+    if rank == 0 and not args.no_roofline_probe:
+        try:
+            result["prefill_roofline"] = prefill_gemm_probe(model, full, S, dev)
+        except Exception as exc:                                  # measurement aid only: never fail the benchmark line
+            result["prefill_roofline"] = {"error": str(exc)}
     # ---- CPU baseline: the oracle ("port") on a bounded sample of the same workload ----------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(dims, args.groupsize)
+        result["cpu_baseline"] = cpu_baseline(dims, args.groupsize, ctx=S)
 
     if rank == 0:
         print(json.dumps(result))
@@ -371,12 +411,43 @@ def decoder_roofline_probe(model, cache, dims, g, ctx, steps=6):
         traffic = None
     return {"bound": "hbm", "kernel": "dec_stream_kernel<PNORM=1, EMODE=2> (fused RMSNorm + gate/up projections + SiLU*mul, one launch per layer)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "launches": L * steps, "avg_launch_us": round(ms[dom] * 1e3 / L, 3),
+            "traffic": traffic,
+            "traffic_source": ("offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (scripts/pmc_traffic.sh), FETCH_SIZE doubled per "
+                               "MI355X_MICROARCH.md, committed as profiles/r01_pmc_traffic.json; not re-measured in this run") if traffic else None,
+            "launches": L * steps, "avg_launch_us": round(ms[dom] * 1e3 / L, 3),
             "algorithmic_bytes_per_launch": int(per_launch[dom]), "classes": classes,
             "token_ms_sum_of_classes": round(sum(ms.values()), 4),
             "note": "per class: %d passes over all %d layers' launches of that kernel, back to back between two HIP events on the "
                     "launch stream (kernel + launch boundary), context %d; peak = 8.0 TB/s spec (6.29 TB/s measured copy => "
                     "frac_of_measured = %.4f)" % (steps, L, ctx, achieved / 6290.0)}
+
+
+def prefill_gemm_probe(model, dims, S, dev, reps=2):
+    """Dominant PREFILL kernel: the fused gate+up projection of the prompt pass (q4_gemm_t16d_kernel: x @ Wgate and x @ Wup
+    from one activation tile, SiLU*mul in the epilogue).  Every layer's launch (different weights each), bracketed as a group
+    by two HIP events on the launch stream; flops per launch = 2 matmuls x 2 S h I."""
+    from exllama_amd.cuda_ext import exllama_ext as ext
+    h, I = dims.hidden_size, dims.intermediate_size
+    x = (torch.randn(S, h, device=dev) * 0.5).half()
+    out = torch.empty(S, I, dtype=torch.float16, device=dev)
+    mlps = [layer.mlp for layer in model.layers]
+    launched = ext.q4_matmul_dual(x, mlps[0].gate_proj.q4, mlps[0].up_proj.q4, out, None, True)
+    if not launched:
+        return {"error": "fused gate/up kernel not eligible for this shape"}
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        for m in mlps:
+            ext.q4_matmul_dual(x, m.gate_proj.q4, m.up_proj.q4, out, None, True)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (reps * len(mlps))
+    flops = 2 * 2.0 * S * h * I
+    tf = flops / us / 1e6
+    return {"bound": "mfma", "kernel": "q4_gemm_t16d_kernel (fused int4 dequant + gate/up MFMA GEMMs + SiLU*mul, one launch per layer)",
+            "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+            "launches": reps * len(mlps), "avg_launch_us": round(us, 2), "flops_per_launch": int(flops), "rows": S}
 
 
 def gemv_roofline_probe(model, groupsize, dev, tokens=3):
@@ -419,10 +490,12 @@ def gemv_roofline_probe(model, groupsize, dev, tokens=3):
                     "(6.29 TB/s measured copy => frac_of_measured = %.4f)" % (tokens, achieved / 6290.0)}
 
 
-def cpu_baseline(dims, groupsize, sample_layers=2, prompt=128, gen=4):
+def cpu_baseline(dims, groupsize, sample_layers=2, prompt=128, gen=4, ctx=2048):
     """The CPU oracle (a port: the reference has no CPU path) on a bounded sample: `sample_layers` layers of the same
-    architecture, a 128-token prompt (BASELINE configs[0]) and a few decode tokens, weights dequantised once up front.
-    Extrapolated linearly to the full depth: per-layer time x L + measured head time."""
+    architecture -- the op sequence of the reference's forward pass (oracle/model_oracle.py composes the oracle's
+    cuda_ext-shaped ops in model.py's order) -- a 128-token prompt (BASELINE configs[0]) and a few decode tokens AT THE
+    BENCHMARK'S CONTEXT (`ctx` keys already in the cache), weights dequantised once up front.  Extrapolated linearly to
+    the full depth: per-layer time x L + measured head time."""
     import numpy as np
     from exllama_amd import synth
     from oracle.model_oracle import OracleLlama
@@ -433,7 +506,7 @@ def cpu_baseline(dims, groupsize, sample_layers=2, prompt=128, gen=4):
         threads = os.cpu_count() or 1
     tensors = synth.make_checkpoint(dims, groupsize=groupsize, act_order=False, seed=0, device="cpu", zeros="sym",
                                     num_layers=sample_layers)
-    m = OracleLlama(synth.config_dict(dims, sample_layers), tensors, max_seq_len=prompt + gen)
+    m = OracleLlama(synth.config_dict(dims, sample_layers), tensors, max_seq_len=max(prompt, ctx) + gen)
     m.prepare()
     ids = np.random.RandomState(0).randint(0, min(31999, dims.vocab_size - 1), size=(1, prompt))
     t0 = time.perf_counter()
@@ -441,7 +514,11 @@ def cpu_baseline(dims, groupsize, sample_layers=2, prompt=128, gen=4):
     for i in range(sample_layers):
         hidden = m.layer_forward(i, hidden)
     t_layers_prefill = time.perf_counter() - t0
-    m.past = prompt
+    rs = np.random.RandomState(1)
+    for i in range(sample_layers):                                # a full-length context: the decode step reads `ctx` keys per layer
+        m.kc[i][:, :, :ctx] = (rs.standard_normal(m.kc[i][:, :, :ctx].shape) * 0.5).astype(np.float16)
+        m.vc[i][:, :, :ctx] = (rs.standard_normal(m.vc[i][:, :, :ctx].shape) * 0.5).astype(np.float16)
+    m.past = ctx
     t0 = time.perf_counter()
     for _ in range(gen):
         hd = m.embed[ids[:, :1]]
@@ -458,7 +535,8 @@ def cpu_baseline(dims, groupsize, sample_layers=2, prompt=128, gen=4):
     decode_s = t_layers_decode / sample_layers * Lfull + t_head
     return {"value": round(1.0 / decode_s, 3), "unit": "tokens/s", "cores": int(threads), "kind": "port",
             "prefill_tokens_per_s": round(prompt / prefill_s, 2),
-            "sample": f"{sample_layers} of {Lfull} layers of the same shapes, {prompt}-token prompt + {gen} decode tokens, "
+            "decode_context": ctx,
+            "sample": f"{sample_layers} of {Lfull} layers of the same shapes, {prompt}-token prompt, then {gen} decode tokens at context {ctx}, "
                       f"numpy/OpenBLAS fp32 GEMMs on weights dequantised once (untimed), extrapolated x{Lfull / sample_layers:.0f} "
                       f"layers + lm_head; CPU: {os.cpu_count()} logical cores visible"}
 

@@ -20,6 +20,18 @@ class ExlTuning(C.Structure):
         "rope_no_half2", "matmul_no_half2", "silu_no_half2", "concurrent_streams")]
 
 
+class ExlSampler(C.Structure):
+    """include/exl_amd.h: ExlSampler (defaults = the reference's ExLlamaGenerator.Settings, generator.py:9-22)."""
+    _fields_ = [("temperature", C.c_float), ("top_k", C.c_int32), ("top_p", C.c_float), ("min_p", C.c_float), ("typical", C.c_float),
+                ("rep_penalty_max", C.c_float), ("rep_sustain", C.c_int32), ("rep_decay", C.c_int32), ("banned_token", C.c_int32),
+                ("reserved", C.c_int32), ("seed", C.c_uint64)]
+
+    def __init__(self, temperature=0.95, top_k=40, top_p=0.65, min_p=0.0, typical=0.0, rep_penalty_max=1.15, rep_sustain=256,
+                 rep_decay=128, banned_token=-1, seed=0):
+        super().__init__(float(temperature), int(top_k), float(top_p), float(min_p), float(typical), float(rep_penalty_max),
+                         int(rep_sustain), int(rep_decay), int(banned_token), 0, int(seed))
+
+
 # name -> (restype, argtypes); every symbol include/exl_amd.h declares
 SIGNATURES = {
     "exl_last_error": (C.c_char_p, []),
@@ -62,6 +74,8 @@ SIGNATURES = {
     "exl_decoder_step_greedy": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "exl_decoder_step_timed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, C.POINTER(c_float)]),
     "exl_decoder_free": (c_int, [c_void_p]),
+    "exl_sample": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "exl_decoder_step_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "exl_decoder_hidden": (c_int, [c_void_p, C.POINTER(c_void_p)]),
     "exl_decoder_set_hidden": (c_int, [c_void_p, c_void_p]),
     "exl_decoder_plan": (c_int, [c_void_p, c_int, C.POINTER(c_int)]),

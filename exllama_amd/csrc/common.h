@@ -97,6 +97,8 @@ int launch_q4_gemm_dual(const Q4Matrix* w1, const Q4Matrix* w2, const f16* x, in
                         hipStream_t s);                     // 1 = not eligible (run the products separately)
 int launch_half_gemm(const f16* x, const f16* w, f16* out, int M, int K, int N, int no_zero, hipStream_t s);
 
+int launch_dec_sample(float* logits, float* probs, int64_t* history, int64_t* token_io, const int32_t* pos_dev, const float* uniforms,
+                      float* prob_out, int vocab, const ExlSampler* s, hipStream_t stream);
 int launch_rms_norm(const f16* x, const f16* w, f16* out, float eps, int rows, int dim, hipStream_t s);
 int launch_rope(f16* x, const f16* sin, const f16* cos, int bsz, int rows_per_batch, int head_dim, int num_heads,
                 int past_len, const int32_t* past_len_dev, hipStream_t s);

@@ -825,6 +825,7 @@ struct Decoder {
     f16 *hid, *qbuf, *kbuf, *vbuf, *attn_out, *act;
     float* partial;
     float2* head_best;            // (largest logit, row) per head-kernel block, for exl_decoder_step_greedy
+    float* probs;                 // [vocab] scratch of the sampler (exl_decoder_step_sample)
     bool separate_merge;          // EXL_DEC_SEPARATE_MERGE: run the split merge as its own kernel (A/B switch)
     int nsplit;                   // KV splits of the attention kernel in use (<= nsplit_max)
     int nsplit_max;
@@ -875,6 +876,7 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     const size_t o_ao = carve((size_t) hidden * 2), o_act = carve((size_t) inter * 2);
     const size_t o_p = carve((size_t) heads * ns * 130 * 4);
     const size_t o_hb = carve((size_t) ((vocab + 31) / 32) * sizeof(float2));
+    const size_t o_pr = carve((size_t) vocab * sizeof(float));
     int prev = 0;
     hipError_t e = hipGetDevice(&prev);
     if (e == hipSuccess) e = hipSetDevice(device);
@@ -888,6 +890,7 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     d->kbuf = (f16*) (b + o_k); d->vbuf = (f16*) (b + o_v); d->attn_out = (f16*) (b + o_ao); d->act = (f16*) (b + o_act);
     d->partial = (float*) (b + o_p);
     d->head_best = (float2*) (b + o_hb);
+    d->probs = (float*) (b + o_pr);
     d->separate_merge = getenv("EXL_DEC_SEPARATE_MERGE") != nullptr;
     int bpc = 2;
     if (const char* env = getenv("EXL_DEC_BLOCKS_PER_CU")) { bpc = atoi(env); if (bpc < 1) bpc = 1; if (bpc > 4) bpc = 4; }
@@ -1205,6 +1208,22 @@ extern "C" int exl_decoder_step_greedy(void* dec, int64_t* token_io_dev, int32_t
     if (prev != d->device) (void) hipSetDevice(prev);
     if (e != hipSuccess) EXL_FAIL((int) e, "decoder_step_greedy: %s", hipGetErrorString(e));
     return 0;
+}
+
+extern "C" int exl_decoder_step_sample(void* dec, int64_t* token_io_dev, int32_t* pos_dev, float* logits_out, int64_t* history_dev,
+                                       const ExlSampler* smp, const float* uniforms_dev, void* stream)
+{
+    Decoder* d = dec_from(dec);
+    EXL_REQUIRE(d && smp && history_dev, EXL_E_INVALID, "decoder_step_sample: invalid argument");
+    EXL_REQUIRE(d->has_head(), EXL_E_INVALID, "decoder_step_sample: this decoder stage has no lm_head");
+    const int rc = exl_decoder_step(dec, token_io_dev, pos_dev, logits_out, 1, stream);
+    if (rc) return rc;
+    int prev = 0;
+    EXL_HIP(hipGetDevice(&prev));
+    if (prev != d->device) EXL_HIP(hipSetDevice(d->device));
+    const int r2 = launch_dec_sample(logits_out, d->probs, history_dev, token_io_dev, pos_dev, uniforms_dev, nullptr, d->vocab, smp, (hipStream_t) stream);
+    if (prev != d->device) (void) hipSetDevice(prev);
+    return r2;
 }
 
 // Measurement aid: for each kernel class, `reps` passes over ALL layers' launches of that class back to back (so the

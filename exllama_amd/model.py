@@ -890,6 +890,64 @@ class ExLlama:
         st["dev_pos"] = cache.current_seq_len
         return st["history"][start + 1:start + num_tokens + 1].clone()
 
+    def generate_sample(self, sequence, cache, num_tokens, settings=None, uniforms=None):
+        """num_tokens SAMPLED steps entirely on the device: every replay of a captured hipGraph runs the decode kernels and the
+        sampler kernel (exllama_amd/csrc/sampler.hip: repetition penalty, temperature, top-k, top-p / min-p, typical, draw --
+        the reference's ExLlamaGenerator.sample / gen_single_token, generator.py:91-170, :344-381, which runs on the host
+        between two forward passes).  `sequence` [1, n] is the whole token sequence so far (prompt + generated): its last
+        token sits at position cache.current_seq_len and is the step's input, the earlier ones feed the repetition penalty.
+        `settings`: exllama_amd._lib.ExlSampler (defaults = the reference's Settings); `uniforms`: optional fp32 tensor
+        [>= max_seq_len + 1] of draws indexed by position (else Philox(settings.seed, position)).  Returns the new tokens."""
+        from ._lib import ExlSampler
+        import ctypes as C
+        st = self._decoder
+        if st is None or st["cache"] is not cache or st["graph"] is None:
+            raise RuntimeError("generate_sample needs enable_decode_graph(cache) with graph replay")
+        if len(st["stages"]) != 1 or not (st["has_embed"] and st["has_head"]):
+            raise RuntimeError("generate_sample needs the whole model in one executor stage (one device)")
+        self._check_cache_storage(st, cache)
+        settings = settings or ExlSampler()
+        start = cache.current_seq_len
+        seq = sequence.view(-1).to(st["dev"], dtype=torch.int64)
+        if seq.numel() != start + 1:
+            raise RuntimeError(f"sequence holds {seq.numel()} tokens, the cache position says {start} + 1")
+        if start + num_tokens > cache.max_seq_len:
+            raise RuntimeError(f"sequence ({start} + {num_tokens}) exceeds the cache length {cache.max_seq_len}")
+        if "history" not in st:
+            st["history"] = torch.zeros((cache.max_seq_len + 1,), dtype=torch.int64, device=st["dev"])
+        st["history"][:start + 1].copy_(seq)
+        key = (bytes(settings), None if uniforms is None else uniforms.data_ptr())
+        if st.get("sgraphs_key") != key:                             # the settings are kernel arguments: one set of graphs per setting
+            st["sgraphs"], st["sgraphs_key"], st["sampler"], st["uniforms"] = [], key, settings, uniforms
+            torch.cuda.synchronize(st["dev"])
+            keep_tok, keep_pos, keep_hist = st["tok"].clone(), st["pos"].clone(), st["history"].clone()
+            for ns, (limit, _) in zip(self._bucket_splits(st), st["graphs"]):
+                cuda_ext.check(ext._lib.exl_decoder_set_kv_splits(st["handle"], ns, None), "decoder_set_kv_splits")
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):                        # capture only records
+                    with cuda_ext._Guard(st["dev"]):
+                        cuda_ext.check(ext._lib.exl_decoder_step_sample(st["handle"], st["tok"].data_ptr(), st["pos"].data_ptr(),
+                                                                        st["logits"].data_ptr(), st["history"].data_ptr(),
+                                                                        C.byref(settings), None if uniforms is None else uniforms.data_ptr(),
+                                                                        torch.cuda.current_stream(st["dev"]).cuda_stream),
+                                       "decoder_step_sample")
+                st["sgraphs"].append((limit, g))
+            st["tok"].copy_(keep_tok); st["pos"].copy_(keep_pos); st["history"].copy_(keep_hist)
+        st["tok"].copy_(seq[-1:].view(1, 1), non_blocking=True)
+        if st["dev_pos"] != start:
+            self._set_positions(st, start)
+        for i in range(num_tokens):
+            p = start + i
+            for limit, g in st["sgraphs"]:
+                if p <= limit:
+                    g.replay()
+                    break
+            else:
+                raise RuntimeError(f"position {p} beyond the decoder's context limit")
+        cache.current_seq_len = start + num_tokens
+        st["dev_pos"] = cache.current_seq_len
+        return st["history"][start + 1:start + num_tokens + 1].clone()
+
     def last_decoder_logits(self):
         """fp32 logits [1, 1, vocab] of the most recent executor step (a copy)."""
         return self._decoder["logits"].clone()
@@ -932,6 +990,7 @@ class ExLlama:
             st["graph"] = None
             st["graphs"] = []
             st.pop("ggraphs", None)
+            st.pop("sgraphs", None)
             for sg in st["stages"]:
                 ext._lib.exl_decoder_free(sg["handle"])
         self._decoder = None

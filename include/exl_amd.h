@@ -213,6 +213,34 @@ int exl_decoder_set_kv_splits(void* decoder, int nsplit, int* max_context);
 int exl_decoder_step_greedy(void* decoder, int64_t* token_io_dev, int32_t* pos_dev, float* logits_out, int64_t* history_dev,
                             void* stream);
 
+/* ---- on-device sampler (reference: generator.py:91-170 sample(), :344-381 gen_single_token(),
+ * cpu_func/rep_penalty.cpp:36-74) ------------------------------------------------------------------------------ */
+typedef struct ExlSampler {
+    float   temperature;        /* > 0                                                            (Settings.temperature, 0.95) */
+    int32_t top_k;              /* 1 .. 1024 on the device (0 = whole-vocabulary sort: host path only)          (top_k, 40) */
+    float   top_p;              /* 0 disables                                                                  (top_p, 0.65) */
+    float   min_p;              /* cut inside the top-p loop (generator.py:128)                                 (min_p, 0.0) */
+    float   typical;            /* 0 disables locally typical sampling                                        (typical, 0.0) */
+    float   rep_penalty_max;    /* 1 disables                                          (token_repetition_penalty_max, 1.15) */
+    int32_t rep_sustain;        /* -1 = whole sequence                             (token_repetition_penalty_sustain, 256) */
+    int32_t rep_decay;          /*                                                   (token_repetition_penalty_decay, 128) */
+    int32_t banned_token;       /* logit forced to -10000 (gen_single_token bans BOS, generator.py:355); -1 = none          */
+    int32_t reserved;
+    uint64_t seed;              /* Philox4x32-10 key when no uniform numbers are supplied                                    */
+} ExlSampler;
+/* Samples ONE token from fp32 logits in device memory: repetition penalty over history[0 .. *pos_new - 1], ban, temperature,
+ * softmax, top-k, top-p / min-p, typical, then an inverse-CDF draw over the surviving list with u = uniforms[*pos_new]
+ * (uniforms_dev != NULL) or Philox(seed, *pos_new).  Writes the token to *token_out_dev and history_dev[*pos_new]; logits
+ * are modified in place (penalty, ban, temperature -- as the reference's in-place tensor ops do); probs_scratch_dev: vocab
+ * floats; prob_out_dev (may be NULL): the token's probability in the final distribution.  One kernel, no synchronisation. */
+int exl_sample(int device, float* logits_dev, float* probs_scratch_dev, int vocab, int64_t* history_dev, int64_t* token_out_dev,
+               const int32_t* pos_new_dev, const float* uniforms_dev, float* prob_out_dev, const ExlSampler* s, void* stream);
+/* exl_decoder_step(..., advance = 1) followed by the sampler: the sampled token lands in *token_io_dev (the next step's input)
+ * and in history_dev[position of that token]; history_dev [max_seq_len + 1] must hold the sequence so far (prompt included)
+ * at positions 0 .. *pos_dev.  Captured into a hipGraph, N replays generate N sampled tokens with no host work in between. */
+int exl_decoder_step_sample(void* decoder, int64_t* token_io_dev, int32_t* pos_dev, float* logits_out, int64_t* history_dev,
+                            const ExlSampler* s, const float* uniforms_dev, void* stream);
+
 /* Measurement aid (bench.py): for each kernel class, `reps` passes over all layers' launches of that class back to
  * back between two hipEvents on `stream` (the weights stream from HBM as in a real step); class_ms_host[c] (HOST memory,
  * EXL_DEC_NCLASS floats) = mean time of one pass = that class' share of one token.  Overwrites the K/V slot at *pos_dev,
