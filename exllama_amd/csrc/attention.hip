@@ -17,7 +17,7 @@ template <int LPK>   // lanes per key row = head_dim / 8 rounded up to a power o
 __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(
     const f16* __restrict__ q, const f16* __restrict__ kc, const f16* __restrict__ vc, const f16* __restrict__ mask,
     float* __restrict__ partial, f16* __restrict__ out, int q_len, int heads, int kv_heads, int hd, int max_seq,
-    int past_len, const int32_t* __restrict__ past_len_dev, int nsplit, float scale)
+    int past_len, const int32_t* __restrict__ past_len_dev, int nsplit, float scale, int bq_base)
 {
     constexpr int KPI = ATT_THREADS / LPK;                    // keys per block iteration
     __shared__ float sc[ATT_MAX_SPLIT_KEYS];
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(
 
     const int split = blockIdx.x;
     const int h = blockIdx.y;
-    const int bq = blockIdx.z;
+    const int bq = blockIdx.z + bq_base;                      // query rows are processed in chunks sized to the workspace
     const int b = bq / q_len;
     const int qi = bq - b * q_len;
     const int past = past_len_dev ? *past_len_dev : past_len;
@@ -115,11 +115,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(
         if (nsplit == 1) {
             out[((size_t) bq * heads + h) * hd + d] = (f16) (nkeys > 0 ? v / lsum : 0.f);
         } else {
-            partial[(((size_t) bq * heads + h) * nsplit + split) * (hd + 2) + d] = v;
+            partial[(((size_t) blockIdx.z * heads + h) * nsplit + split) * (hd + 2) + d] = v;
         }
     }
     if (nsplit > 1 && tid == 0) {
-        float* pp = partial + (((size_t) bq * heads + h) * nsplit + split) * (hd + 2) + hd;
+        float* pp = partial + (((size_t) blockIdx.z * heads + h) * nsplit + split) * (hd + 2) + hd;
         pp[0] = nkeys > 0 ? mx : -INFINITY;
         pp[1] = nkeys > 0 ? lsum : 0.f;
     }
@@ -173,24 +173,35 @@ int launch_attention(const f16* q, const f16* kc, const f16* vc, f16* out, const
     const int min_by_lds = (kv_max + ATT_MAX_SPLIT_KEYS - 16 - 1) / (ATT_MAX_SPLIT_KEYS - 16);
     if (nsplit < min_by_lds) nsplit = min_by_lds;
     if (nsplit < 1) nsplit = 1;
+    // The partials of all (row, head, split) triples of a launch live in the fixed workspace: long masked prompts (batched
+    // generation with padding, model.py:1014-1033) are processed in chunks of query rows that fit it, instead of failing
+    // (bsz 1 x 2048 masked tokens with 32 heads would need 25.5 M floats of a 16 M-float workspace in one go).
+    const int total_rows = bsz * q_len;
+    int chunk = total_rows;
     float* partial = nullptr;
     if (nsplit > 1) {
-        const size_t need = (size_t) base * nsplit * (hd + 2);
-        EXL_REQUIRE(ws && ws_floats >= need, EXL_E_TOO_SMALL, "attention: workspace too small (%zu < %zu floats)", ws_floats, need);
+        const size_t per_row = (size_t) heads * nsplit * (hd + 2);
+        EXL_REQUIRE(ws && ws_floats >= per_row, EXL_E_TOO_SMALL, "attention: workspace too small (%zu < %zu floats)", ws_floats, per_row);
+        const size_t fit = ws_floats / per_row;
+        if ((size_t) chunk > fit) chunk = (int) fit;
         partial = ws;
     }
+    if (chunk > 65535) chunk = 65535;                             // gridDim.z limit
     const float scale = 1.0f / sqrtf((float) hd);
-    dim3 grid(nsplit, heads, bsz * q_len);
     const int lpk = hd <= 64 ? 8 : hd <= 128 ? 16 : 32;
-#define ATT_ARGS q, kc, vc, mask, partial, out, q_len, heads, kv_heads, hd, max_seq, past_len, past_len_dev, nsplit, scale
-    if (lpk == 8)       hipLaunchKernelGGL(attn_decode_kernel<8>,  grid, dim3(ATT_THREADS), 0, s, ATT_ARGS);
-    else if (lpk == 16) hipLaunchKernelGGL(attn_decode_kernel<16>, grid, dim3(ATT_THREADS), 0, s, ATT_ARGS);
-    else                hipLaunchKernelGGL(attn_decode_kernel<32>, grid, dim3(ATT_THREADS), 0, s, ATT_ARGS);
+    for (int r0 = 0; r0 < total_rows; r0 += chunk) {
+        const int nr = total_rows - r0 < chunk ? total_rows - r0 : chunk;
+        dim3 grid(nsplit, heads, nr);
+#define ATT_ARGS q, kc, vc, mask, partial, out, q_len, heads, kv_heads, hd, max_seq, past_len, past_len_dev, nsplit, scale, r0
+        if (lpk == 8)       hipLaunchKernelGGL(attn_decode_kernel<8>,  grid, dim3(ATT_THREADS), 0, s, ATT_ARGS);
+        else if (lpk == 16) hipLaunchKernelGGL(attn_decode_kernel<16>, grid, dim3(ATT_THREADS), 0, s, ATT_ARGS);
+        else                hipLaunchKernelGGL(attn_decode_kernel<32>, grid, dim3(ATT_THREADS), 0, s, ATT_ARGS);
 #undef ATT_ARGS
-    EXL_LAUNCH_CHECK();
-    if (nsplit > 1) {
-        hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned) base), dim3(128), 0, s, partial, out, hd, nsplit);
         EXL_LAUNCH_CHECK();
+        if (nsplit > 1) {
+            hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned) (nr * heads)), dim3(128), 0, s, partial, out + (size_t) r0 * heads * hd, hd, nsplit);
+            EXL_LAUNCH_CHECK();
+        }
     }
     return 0;
 }

@@ -48,6 +48,7 @@ LLAMA_7B = LlamaDims(4096, 11008, 32, 32)
 LLAMA_13B = LlamaDims(5120, 13824, 40, 40)
 LLAMA_33B = LlamaDims(6656, 17920, 60, 52)
 LLAMA_65B = LlamaDims(8192, 22016, 80, 64)
+LLAMA2_70B = LlamaDims(8192, 28672, 80, 64, num_key_value_heads=8)             # GQA, the widest down_proj (K = 28672) of the family
 # Small shapes for tests (all kernel constraints hold: N % 32 == 0, K % groupsize == 0, kv_heads % 4 == 0).
 LLAMA_TINY = LlamaDims(256, 704, 2, 4, vocab_size=512)
 LLAMA_TINY_GQA = LlamaDims(512, 1408, 2, 8, num_key_value_heads=4, vocab_size=512)
@@ -55,7 +56,7 @@ LLAMA_TINY_GQA = LlamaDims(512, 1408, 2, 8, num_key_value_heads=4, vocab_size=51
 LLAMA_TINY_HD128 = LlamaDims(512, 1408, 3, 4, vocab_size=512)                       # head_dim 128 like the real models
 LLAMA_TINY_HD128_GQA = LlamaDims(1024, 2816, 2, 8, num_key_value_heads=2, vocab_size=640)
 
-PRESETS = {"7b": LLAMA_7B, "13b": LLAMA_13B, "33b": LLAMA_33B, "65b": LLAMA_65B,
+PRESETS = {"7b": LLAMA_7B, "13b": LLAMA_13B, "33b": LLAMA_33B, "65b": LLAMA_65B, "70b": LLAMA2_70B,
            "tiny": LLAMA_TINY, "tiny_gqa": LLAMA_TINY_GQA, "tiny_hd128": LLAMA_TINY_HD128,
            "tiny_hd128_gqa": LLAMA_TINY_HD128_GQA}
 

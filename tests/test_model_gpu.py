@@ -343,6 +343,8 @@ _REAL_SHAPES = {
     "13b": ("13b", 128, True, 1, (4, 2, 1, 1, 0, 2), (4, 2, 1, 0, 1, 2), (6, 2, 1, 1, 2, 2), (6, 4, 1, 0, 1, 6), True),
     "33b": ("33b", 32, True, 1, (4, 2, 0, 1, 0, 2), (4, 2, 0, 0, 1, 2), (6, 4, 0, 1, 2, 2), (6, 4, 0, 0, 1, 6), True),
     "65b": ("65b", 128, False, 1, (4, 2, 1, 1, 0, 2), (4, 2, 1, 0, 1, 2), (6, 4, 1, 1, 2, 2), (6, 4, 1, 0, 1, 6), True),
+    # Llama-2-70B: GQA (8 kv heads) and K = 28672 in down_proj -- 28 row-blocks per wave (U, NP) = (6, 6), 7 -> 8 vectors per thread
+    "70b": ("70b", 128, False, 1, (4, 2, 1, 1, 0, 2), (4, 2, 1, 0, 1, 2), (6, 4, 1, 1, 2, 2), (6, 6, 1, 0, 1, 8), True),
 }
 
 

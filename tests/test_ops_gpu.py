@@ -146,7 +146,9 @@ def test_column_remap_bit_exact(ce):
 # ---------------------------------------------------------------------------------------------------------
 GEMV_SHAPES = [(256, 128, 64, True), (512, 96, 128, False), (256, 64, 32, True), (704, 256, 64, False),
                (4096, 4096, 128, False), (4096, 11008, 128, False), (11008, 4096, 128, False),
-               (5120, 5120, 128, True), (6656, 6656, 32, True), (4096, 32000 // 32 * 32, 4096, False)]
+               (5120, 5120, 128, True), (6656, 6656, 32, True), (4096, 32000 // 32 * 32, 4096, False),
+               (28672, 256, 128, False),       # Llama-2-70B down_proj: 28 row-blocks per wave, > 64 KiB of LDS for 2+ rows
+               (40960, 128, 128, True)]        # beyond the decode kernel's reach: routed to the MFMA GEMM (q4_gemv_covers)
 
 
 @pytest.mark.parametrize("K,N,gs,act", GEMV_SHAPES)
@@ -154,6 +156,9 @@ GEMV_SHAPES = [(256, 128, 64, True), (512, 96, 128, False), (256, 64, 32, True),
 def test_q4_gemv_vs_oracle(ce, K, N, gs, act, rows):
     if rows != 1 and K * N > 4096 * 4096:
         pytest.skip("large shapes are covered at rows = 1")
+    keep = None
+    if K > 36864:
+        keep = _prep_buffers(ce, 8, K, K)                            # the GEMM fallback gathers act-order activations into temp_state (borrowed: keep it alive)
     lin, gen = _lin(K, N, gs, act, seed=K * 7 + N + rows, std=0.02 * (4096 / K) ** 0.5)
     h, d = _handle(ce, lin)
     ow = _oracle_w(lin)
@@ -470,6 +475,29 @@ def _attn_case(ce, bsz, q_len, heads, kvh, hd, past, max_seq, seed, with_mask=Fa
 @pytest.mark.parametrize("past", [0, 1, 63, 64, 300, 1919, 2047])
 def test_attention_decode(ce, past):
     _attn_case(ce, 1, 1, 32, 32, 128, past, 2048, seed=past)
+
+
+def test_attention_masked_long_prompt_in_workspace_chunks(ce):
+    """bsz 2 x 1024 masked tokens x 32 heads: 17 M floats of split partials against a 16 M-float workspace -- the launcher
+    walks the query rows in chunks that fit (it used to fail with 'workspace too small').  Checked on a few heads."""
+    keep = _prep_buffers(ce, 2, 256, 256)
+    gen = torch.Generator().manual_seed(77)
+    bsz, q_len, heads, hd = 2, 1024, 32, 128
+    q = torch.randn(bsz, q_len, heads * hd, generator=gen).half()
+    kc = torch.randn(bsz, heads, q_len, hd, generator=gen).half()
+    vc = torch.randn(bsz, heads, q_len, hd, generator=gen).half()
+    mask = torch.zeros(bsz, 1, q_len, q_len, dtype=torch.float16)
+    mask[0, :, :, :5] = -65504.0                                       # left padding of the first sequence
+    mask += torch.triu(torch.full((q_len, q_len), -65504.0), diagonal=1).half()
+    mask = mask.clamp(min=-65504.0)
+    out = torch.empty_like(q, device=DEV)
+    ce.exllama_ext.attention(q.to(DEV), kc.to(DEV), vc.to(DEV), out, 0, heads, mask=mask.to(DEV))
+    o = out.cpu().numpy().reshape(bsz, q_len, heads, hd)
+    for hsel in (0, 13, 31):
+        qn = q.numpy().reshape(bsz, q_len, heads, hd)[:, :, hsel][:, None]
+        ref = O.attention(qn, kc.numpy()[:, hsel:hsel + 1], vc.numpy()[:, hsel:hsel + 1], causal_past_len=0, mask=mask.numpy())
+        got = o[:, 8:, hsel]                                           # (rows whose every visible key is padding are undefined)
+        _close(got, ref[:, 0, 8:], ulps=4.0)
 
 
 def test_attention_decode_variants(ce):
