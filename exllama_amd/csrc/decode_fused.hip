@@ -55,6 +55,11 @@ struct DecGemvArgs {
     int nblocks;                  // = gridDim.x (passed explicitly: the implicit-argument load is one more scalar round trip)
     int units_lo, units_rem;      // unit count per block: units_lo + (block < units_rem)
     int early_weights;            // 1 (default): first weight batch issued before the activation has landed; 0: EXL_DEC_X_FIRST=1
+    // act-order (reference: column_remap.cu:7-36 gathers x through x_map before every matmul):
+    const uint16_t* map16[DEC_MAX_MATS];   // gather maps of the matrices of this launch as 16-bit indices (K < 65536), or NULL:
+                                           // NULL with an act-order matrix means its input arrives ALREADY gathered (out_perm below)
+    const uint16_t* out_perm;     // EMODE 0 (mat 0 only) / EMODE 2: the consumer's inverse gather map -- column n is stored at out_perm[n],
+                                  // so that the next kernel reads its activation linearly and gathers nothing
 };
 
 // Every field of a matrix view the streaming loop touches, forced into SGPRs at the top of the kernel: the compiler
@@ -107,6 +112,9 @@ template <int U, bool G16>
 __device__ __forceinline__ void dec_unit_issue(const T16Matrix& m, const DecUnit& u, int pass, uint32_t lane, uint4 (&wv)[U],
                                                uint32_t (&entp)[U])
 {
+    // Branch-free on purpose: a conditional load makes the compiler drain the whole queue (s_waitcnt vmcnt(0)) at every join and
+    // the pass-ahead pipelining is gone.  Slots past the wave's range re-read a valid row-block with scale 0 -- so the (U, NP)
+    // configuration is chosen per shape to have (almost) no such slots (launch_dec_gemv_cfg).
 #pragma unroll
     for (int i = 0; i < U; ++i) {
         const int rb = u.rb0 + pass * U + i;
@@ -134,6 +142,18 @@ __device__ __forceinline__ void dec_unit_consume(const DecUnit& u, int pass, int
         if constexpr (G16) e = (uint32_t) __shfl((int) ent[(li >> 2) < NSLOT ? (li >> 2) : 0], ((li & 3) << 4) | col, 64);
         else e = entp[i];
         t16_rowblock<G16>(wv[i], e, magic, xrow + rbc * 16 + rsub * 4, c);
+    }
+}
+// The (gathered) LDS image of the activation from its linear copy in LDS: packed row idx takes x[map[8 idx .. 8 idx + 7]]; the map
+// travels as 16-bit indices (one 16-byte load per packed row: half the L2 traffic of the 32-bit x_map, which every block reads).
+__device__ __forceinline__ void dec_stage_from_lds(const f16* xlin, const uint16_t* map, int R, uint4* xs, int tid, int nthreads)
+{
+    for (int idx = tid; idx < R; idx += nthreads) {
+        const uint4 m = *(const uint4*) (map + idx * 8);
+        f16x8 g;
+        g[0] = xlin[m.x & 0xFFFFu]; g[1] = xlin[m.x >> 16]; g[2] = xlin[m.y & 0xFFFFu]; g[3] = xlin[m.y >> 16];
+        g[4] = xlin[m.z & 0xFFFFu]; g[5] = xlin[m.z >> 16]; g[6] = xlin[m.w & 0xFFFFu]; g[7] = xlin[m.w >> 16];
+        xs[idx] = __builtin_bit_cast(uint4, g);
     }
 }
 __device__ __forceinline__ T16Matrix dec_pick(const T16Matrix& m0, const T16Matrix& m1, const T16Matrix& m2, int mi)
@@ -189,6 +209,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
     int a_rbw = a.rb_per_wave, a_images = a.xs_images, nb = a.nblocks, units_lo = a.units_lo, units_rem = a.units_rem;
     int early_w = a.early_weights, abl = a.ablate;
     DEC_PIN_S(early_w); DEC_PIN_S(abl);
+    const uint16_t* g0 = dec_pin_ptr(a.map16[0]); const uint16_t* g1 = dec_pin_ptr(a.map16[1]); const uint16_t* g2 = dec_pin_ptr(a.map16[2]);
     DEC_PIN_S(K); DEC_PIN_S(R);
     DEC_PIN_S(te0); DEC_PIN_S(te1); DEC_PIN_S(te2); DEC_PIN_S(a_nmat); DEC_PIN_S(a_rbw); DEC_PIN_S(a_images);
     DEC_PIN_S(nb); DEC_PIN_S(units_lo); DEC_PIN_S(units_rem);
@@ -331,7 +352,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
 #pragma unroll
         for (int i = 0; i < NV; ++i) xv[i] = __builtin_bit_cast(f16x8, xraw[i]);
     }
-    const bool gather = M0.x_map != nullptr;                         // all matrices of a launch agree (checked on the host)
+    const bool gather = g0 != nullptr;                               // all matrices of a launch agree (checked on the host)
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = tid + i * DEC_THREADS;
@@ -344,10 +365,10 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
     if (gather) {                                                    // act-order: one image per matrix (each has its own x_map)
         if constexpr (EMODE == 2) {                                  // gate image built by waves 0-3, up image by waves 4-7
             const int mi = wave / WPT;
-            t16_stage_from_lds(xlin, mi ? M1.x_map : M0.x_map, R, xs + (size_t) mi * R, tid % (WPT * 64), WPT * 64);
+            dec_stage_from_lds(xlin, mi ? g1 : g0, R, xs + (size_t) mi * R, tid % (WPT * 64), WPT * 64);
         } else {
             for (int k = 0; k < a_images; ++k)
-                t16_stage_from_lds(xlin, k == 0 ? M0.x_map : k == 1 ? M1.x_map : M2.x_map, R, xs + (size_t) k * R, tid, DEC_THREADS);
+                dec_stage_from_lds(xlin, k == 0 ? g0 : k == 1 ? g1 : g2, R, xs + (size_t) k * R, tid, DEC_THREADS);
         }
         __syncthreads();
     }
@@ -385,7 +406,7 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
             if constexpr (EMODE == 2) {                                                                                     \
                 float g = 0.f, u = 0.f;                                                                                     \
                 _Pragma("unroll") for (int k = 0; k < WPT; ++k) { g += rp[k * 16 + tid]; u += rp[(WPT + k) * 16 + tid]; }   \
-                a.out[0][n] = silu_mul_f16((f16) g, (f16) u);                                                               \
+                a.out[0][a.out_perm ? (int) a.out_perm[n] : n] = silu_mul_f16((f16) g, (f16) u);                           \
             } else {                                                                                                        \
                 float v = 0.f;                                                                                              \
                 _Pragma("unroll") for (int k = 0; k < DEC_WAVES; ++k) v += rp[k * 16 + tid];                                \
@@ -421,8 +442,8 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
 // splits -- are requested for K AND V before anything else happens, so the kernel pays ONE memory latency, not two
 // (scores -> softmax -> PV with the V rows already in registers).  Longer splits loop over further chunks.
 // ---------------------------------------------------------------------------------------------------------------
-#define DEC_ATT_UN 10
-#define DEC_ATT_AHEAD 5          // rows per thread in flight during the score phase (8 waves x 5 KiB per CU)
+#define DEC_ATT_CHUNK 160        // keys per pass of a block
+#define DEC_ATT_AHEAD 5          // rows per thread in flight during the score phase
 // Phase attribution (probe builds only, scripts/probe_attn.sh): cycles summed over blocks at 7 points of the kernel.
 #ifdef EXL_ATTN_PROBE
 __device__ unsigned long long g_attn_probe[512 * 8];                // [block][point]; read out by exl_debug_attn_probe
@@ -432,18 +453,22 @@ __device__ unsigned long long g_attn_probe[512 * 8];                // [block][p
 #endif
 // SHORT (the one-split bucket, context <= 160): rows past the context are skipped with block-uniform branches; in the long
 // buckets every split is full and the same branches only break up the load / score interleave (measured: 9.5 -> 11.7 us).
-template <bool SHORT>
-__global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q, const f16* __restrict__ k_new,
+// NW = waves per block (EXL_DEC_ATTN_WAVES): 4 -> 16 key rows per step, 10 rows per thread and chunk, 5 in flight;
+//                                            8 -> 32 key rows per step,  5 rows per thread and chunk, all 5 K rows in flight
+// (twice the waves per CU at the same bytes in flight per thread).
+template <bool SHORT, int NW>
+__global__ __launch_bounds__(NW * 64) void dec_attn_kernel(const f16* __restrict__ q, const f16* __restrict__ k_new,
                                                        const f16* __restrict__ v_new, f16* __restrict__ kc,
                                                        f16* __restrict__ vc, const f16* __restrict__ sin,
                                                        const f16* __restrict__ cos, float* __restrict__ partial,
                                                        const int32_t* __restrict__ pos_dev, int heads, int kv_heads,
-                                                       int max_seq, int nsplit, float scale, f16* __restrict__ direct_out)
+                                                       int max_seq, int nsplit, float scale, f16* __restrict__ direct_out,
+                                                       const uint16_t* __restrict__ out_perm)
 {
-    constexpr int HD = 128, LPK = 16, KPI = 16, UN = DEC_ATT_UN;
+    constexpr int HD = 128, LPK = 16, KPI = NW * 4, UN = DEC_ATT_CHUNK / KPI, NT = NW * 64;
     __shared__ float sc[DEC_ATT_MAX_KEYS];
     __shared__ float red[KPI][HD + 1];
-    __shared__ float stat[8];
+    __shared__ float stat[2 * NW];
 
     // 1-D grid; block id -> (head, split) such that every split of head h runs on XCD h % 8 (block b runs on XCD b % 8,
     // observed, speed only): the merge block of head h (XCD h % 8 as well) then finds the partials in its own L2.
@@ -570,19 +595,23 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
     if ((tid & 63) == 0) stat[tid >> 6] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(stat[0], stat[1]), fmaxf(stat[2], stat[3]));
+    mx = stat[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, stat[w]);
     __syncthreads();
     float lsum = 0.f;
-    for (int j = tid; j < nkeys; j += 256) {
+    for (int j = tid; j < nkeys; j += NT) {
         const float p = __expf(sc[j] - mx);
         sc[j] = p;
         lsum += p;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off, 64);
-    if ((tid & 63) == 0) stat[4 + (tid >> 6)] = lsum;
+    if ((tid & 63) == 0) stat[NW + (tid >> 6)] = lsum;
     __syncthreads();
-    lsum = stat[4] + stat[5] + stat[6] + stat[7];
+    lsum = stat[NW];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) lsum += stat[NW + w];
 
     AP_CLK(4);                                                       // softmax done
     // ---- P V ------------------------------------------------------------------------------------------------------
@@ -623,7 +652,8 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const f16* __restrict__ q
 #pragma unroll
         for (int s = 0; s < KPI; ++s) v += red[s][tid];
         const f16 r = (f16) (nkeys > 0 ? v / lsum : 0.f);
-        if (direct_out) direct_out[h * HD + tid] = r;                   // a single split: this IS the attention output
+        if (direct_out) direct_out[out_perm ? (int) out_perm[h * HD + tid] : h * HD + tid] = r;   // a single split: this IS the attention output
+                                                                        // (stored where an act-order o_proj reads it linearly)
         else po[tid] = r;
     }
     if (tid == 0 && !direct_out) {
@@ -664,7 +694,8 @@ extern "C" int exl_debug_attn_probe(unsigned long long* out8)         // sums ov
 // K2b: merge the split-KV partials of one head -> fp16 attention output (the value the reference's ATen attention
 // rounds to fp16 before o_proj, model.py:407-409)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void dec_attn_merge_kernel(const float* __restrict__ partial, f16* __restrict__ out, int nsplit, int heads)
+__global__ __launch_bounds__(128) void dec_attn_merge_kernel(const float* __restrict__ partial, f16* __restrict__ out, int nsplit, int heads,
+                                                             const uint16_t* __restrict__ out_perm)
 {
     const int h = blockIdx.x, d = threadIdx.x;
     const f16* po = (const f16*) partial + (size_t) h * nsplit * 128;
@@ -688,7 +719,18 @@ __global__ __launch_bounds__(128) void dec_attn_merge_kernel(const float* __rest
         L += w;
         o = fmaf((float) os[s], w, o);
     }
-    out[h * 128 + d] = (f16) (o / L);
+    out[out_perm ? (int) out_perm[h * 128 + d] : h * 128 + d] = (f16) (o / L);
+}
+
+// act-order maps of one matrix as 16-bit indices: map16 = x_map (gather: x'[c] = x[x_map[c]]), inv16 = its inverse (a producer
+// that stores column n at inv16[n] hands the consumer an already gathered vector)
+__global__ void dec_map16_kernel(const uint32_t* __restrict__ x_map, uint16_t* __restrict__ map16, uint16_t* __restrict__ inv16, int K)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= K) return;
+    const uint32_t src = x_map[c];
+    map16[c] = (uint16_t) src;
+    inv16[src] = (uint16_t) c;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -814,6 +856,8 @@ struct DecLayer {
     const f16 *in_norm, *post_norm;
     f16 *kc, *vc;
     bool set;
+    // act-order: 16-bit gather maps (and their inverses) of the seven matrices, in the decoder's own memory; NULL = no act-order
+    const uint16_t *map_q, *map_k, *map_v, *map_o, *map_gate, *map_up, *map_down, *inv_o, *inv_down;
 };
 
 struct Decoder {
@@ -831,6 +875,7 @@ struct Decoder {
     int nsplit_max;
     int max_blocks;               // persistent GEMV grid: blocks per CU x CUs
     void* block;                  // one hipMalloc
+    uint16_t* maps;               // act-order maps of all layers: per layer 2 x (6 hidden + inter) entries
     bool has_embed() const { return embed != nullptr; }
     bool has_head() const { return lm_head != nullptr; }
 };
@@ -877,6 +922,8 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     const size_t o_p = carve((size_t) heads * ns * 130 * 4);
     const size_t o_hb = carve((size_t) ((vocab + 31) / 32) * sizeof(float2));
     const size_t o_pr = carve((size_t) vocab * sizeof(float));
+    const size_t maps_per_layer = 2 * ((size_t) 6 * hidden + inter);                 // map + inverse of q, k, v, o, gate, up (K = hidden) and down (K = inter)
+    const size_t o_maps = carve(maps_per_layer * n_layers * sizeof(uint16_t));
     int prev = 0;
     hipError_t e = hipGetDevice(&prev);
     if (e == hipSuccess) e = hipSetDevice(device);
@@ -891,6 +938,7 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     d->partial = (float*) (b + o_p);
     d->head_best = (float2*) (b + o_hb);
     d->probs = (float*) (b + o_pr);
+    d->maps = (uint16_t*) (b + o_maps);
     d->separate_merge = getenv("EXL_DEC_SEPARATE_MERGE") != nullptr;
     int bpc = 2;
     if (const char* env = getenv("EXL_DEC_BLOCKS_PER_CU")) { bpc = atoi(env); if (bpc < 1) bpc = 1; if (bpc > 4) bpc = 4; }
@@ -930,6 +978,32 @@ extern "C" int exl_decoder_set_layer(void* dec, int index, void* q, void* k, voi
     EXL_REQUIRE(in_norm && post_norm && key_cache && value_cache, EXL_E_INVALID, "decoder_set_layer: null pointer");
     l.in_norm = (const f16*) in_norm; l.post_norm = (const f16*) post_norm;
     l.kc = (f16*) key_cache; l.vc = (f16*) value_cache;
+    // act-order: every gather map once more as 16-bit indices, plus its inverse (decoder-owned; built on the default stream)
+    {
+        EXL_REQUIRE(d->h < 65536 && d->inter < 65536, EXL_E_UNSUPPORTED, "decoder: act-order maps are 16-bit");
+        uint16_t* base = d->maps + (size_t) index * 2 * ((size_t) 6 * d->h + d->inter);
+        Q4Matrix* ms[7] = {l.q, l.k, l.v, l.o, l.gate, l.up, l.down};
+        const uint16_t** mp[7] = {&l.map_q, &l.map_k, &l.map_v, &l.map_o, &l.map_gate, &l.map_up, &l.map_down};
+        const uint16_t* inv[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        int prev = 0;
+        EXL_HIP(hipGetDevice(&prev));
+        if (prev != d->device) EXL_HIP(hipSetDevice(d->device));
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < 7 && e == hipSuccess; ++i) {
+            const int K = ms[i]->height;
+            uint16_t* m16 = base; uint16_t* i16 = base + K;
+            base += 2 * (size_t) K;
+            *mp[i] = nullptr;
+            if (!ms[i]->x_map) continue;
+            hipLaunchKernelGGL(dec_map16_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t) 0, ms[i]->x_map, m16, i16, K);
+            e = hipGetLastError();
+            *mp[i] = m16; inv[i] = i16;
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t) 0);
+        if (prev != d->device) (void) hipSetDevice(prev);
+        if (e != hipSuccess) EXL_FAIL((int) e, "decoder_set_layer: %s", hipGetErrorString(e));
+        l.inv_o = inv[3]; l.inv_down = inv[6];
+    }
     l.set = true;
     return 0;
 }
@@ -981,18 +1055,44 @@ static int launch_dec_gemv_cfg(bool g16, int rbw, dim3 grid, size_t smem, hipStr
         }                                                                                                                     \
         hipLaunchKernelGGL(kfn, grid, dim3(DEC_THREADS), smem, s, a); } while (0)
 #define DEC_LAUNCH(U, NP) do { if (g16) DEC_LAUNCH1(U, NP, true); else DEC_LAUNCH1(U, NP, false); } while (0)
+    // Row-blocks per wave -> (U, NP): U 16-byte loads in flight per lane and pass, NP passes, U * NP >= rbw with as few idle slots
+    // as possible.  Idle slots are not free: the branch-free stream re-reads a valid row-block for each (dec_unit_issue), so the
+    // old four-entry table cost 13B 37 % extra weight traffic in qkv (5 row-blocks in 8 slots), 33B 46 % in gate/up (13 in 24).
+    // The candidates a kernel class can meet are bounded by its K (NV = ceil(K / 4096)): only those are instantiated.
 #ifdef EXL_DEC_FAST_BUILD                                            /* ISA inspection builds: 7B instantiations only */
     if (rbw <= 4)       DEC_LAUNCH1(4, 1, true);
     else if (rbw <= 8)  DEC_LAUNCH1(4, 2, true);
     else                DEC_LAUNCH1(6, 2, true);
 #else
-    if (rbw <= 4)       DEC_LAUNCH(4, 1);
-    else if (rbw <= 8)  DEC_LAUNCH(4, 2);
-    else if (rbw <= 12) DEC_LAUNCH(6, 2);
-    else if (rbw <= 24) DEC_LAUNCH(6, 4);
-    else {                                                           // K > 24576: only down_proj (K = intermediate size, e.g. 28672 of Llama-2-70B)
-        if constexpr (PNORM == 0 && EMODE == 1) DEC_LAUNCH(6, 6);
-        else EXL_FAIL(EXL_E_UNSUPPORTED, "decoder: in_features too large for this kernel class");
+    if constexpr (PNORM == 3) {                                      // o_proj with the folded merge: hidden <= 4096
+        DEC_LAUNCH(4, 1);
+    } else if constexpr (NV <= 2) {                                  // K = hidden size <= 8192
+        if (rbw <= 4)       DEC_LAUNCH(4, 1);
+        else if (rbw == 5)  DEC_LAUNCH(5, 1);
+        else if (rbw == 6)  DEC_LAUNCH(6, 1);
+        else if (rbw <= 8)  DEC_LAUNCH(4, 2);                        // (7 loads at once and a single pass measured slower than one idle slot: 33B qkv 33 vs 27 us)
+        else {
+            if constexpr (EMODE == 2) {                              // gate/up: 4 waves per tile, up to 16 row-blocks per wave
+                if (rbw <= 10)      DEC_LAUNCH(5, 2);
+                else if (rbw <= 12) DEC_LAUNCH(6, 2);
+                else if (rbw <= 14) DEC_LAUNCH(7, 2);
+                else if (rbw <= 16) DEC_LAUNCH(4, 4);
+                else EXL_FAIL(EXL_E_UNSUPPORTED, "decoder: hidden size too large for the gate/up kernel");
+            } else EXL_FAIL(EXL_E_UNSUPPORTED, "decoder: in_features too large for this kernel class");
+        }
+    } else {                                                         // down_proj: K = intermediate size (> 8192)
+        if constexpr (PNORM == 0 && EMODE == 1) {
+            if (rbw <= 10)      DEC_LAUNCH(5, 2);
+            else if (rbw <= 12) DEC_LAUNCH(6, 2);
+            else if (rbw <= 14) DEC_LAUNCH(7, 2);
+            else if (rbw <= 16) DEC_LAUNCH(4, 4);
+            else if (rbw <= 18) DEC_LAUNCH(6, 3);
+            else if (rbw <= 20) DEC_LAUNCH(5, 4);
+            else if (rbw <= 24) DEC_LAUNCH(6, 4);
+            else if (rbw <= 28) DEC_LAUNCH(7, 4);
+            else if (rbw <= 30) DEC_LAUNCH(6, 5);
+            else                DEC_LAUNCH(6, 6);
+        } else EXL_FAIL(EXL_E_UNSUPPORTED, "decoder: in_features too large for this kernel class");
     }
 #endif
 #undef DEC_LAUNCH
@@ -1002,9 +1102,12 @@ static int launch_dec_gemv_cfg(bool g16, int rbw, dim3 grid, size_t smem, hipStr
 }
 
 // pnorm / emode as in dec_gemv_kernel.  mats: nmat matrices sharing K (emode 2: gate, up).
+// maps: the 16-bit gather map of every matrix (NULL entries / NULL array: the activation is read linearly -- no act-order, or a
+// producer already stored it gathered); out_perm: inverse gather map of the CONSUMER of this launch's output (EMODE 2).
 static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec, const int64_t* tok, const f16* norm_w, float eps, f16* hid_copy,
                            int nmat, Q4Matrix* const* mats, f16* const* outs, f16* hid_io, hipStream_t s,
-                           const float* att_ml = nullptr, int att_nsplit = 0)
+                           const float* att_ml = nullptr, int att_nsplit = 0, const uint16_t* const* maps = nullptr,
+                           const uint16_t* out_perm = nullptr)
 {
     DecGemvArgs a;
     a.vec = vec; a.tok = tok; a.norm_w = norm_w; a.eps = eps; a.hid_copy = hid_copy; a.nmat = nmat; a.hid_io = hid_io;
@@ -1016,10 +1119,12 @@ static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec,
             a.mat[i] = t16_view(mats[i]);
             a.out[i] = outs ? outs[i] : nullptr;
             if (emode != 2 || i == 0) tiles += mats[i]->width / 16;
-            any_map = any_map || mats[i]->x_map != nullptr;
+            a.map16[i] = maps ? maps[i] : nullptr;
+            any_map = any_map || a.map16[i] != nullptr;
         } else {
             a.mat[i] = a.mat[0];
             a.out[i] = nullptr;
+            a.map16[i] = a.map16[0];
         }
         a.tile_end[i] = tiles;
     }
@@ -1040,8 +1145,9 @@ static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec,
     EXL_REQUIRE(smem <= 160 * 1024, EXL_E_UNSUPPORTED, "decoder: activation stage (%zu bytes of LDS) exceeds the 160 KiB of a CU", smem);
     const int nv = (K / 8 + DEC_THREADS - 1) / DEC_THREADS;
     for (int i = 1; i < nmat; ++i)
-        EXL_REQUIRE((mats[i]->x_map == nullptr) == (mats[0]->x_map == nullptr), EXL_E_UNSUPPORTED,
+        EXL_REQUIRE((a.map16[i] == nullptr) == (a.map16[0] == nullptr), EXL_E_UNSUPPORTED,
                     "decoder: matrices fused into one launch must agree on act-order");
+    a.out_perm = out_perm;
     dim3 grid(tiles < max_blocks ? tiles : max_blocks);
     a.nblocks = (int) grid.x;
     a.units_lo = tiles / (int) grid.x;
@@ -1086,17 +1192,22 @@ static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int3
         const f16* xin = emb ? d->embed : d->hid;
         const int64_t* tk = emb ? token_dev : nullptr;
         f16* hc = emb ? d->hid : nullptr;
-        return launch_dec_gemv(d->max_blocks, 1, 0, xin, tk, l.in_norm, d->eps, hc, 3, qkv, qkv_out, nullptr, s);
+        const uint16_t* maps[3] = {l.map_q, l.map_k, l.map_v};
+        return launch_dec_gemv(d->max_blocks, 1, 0, xin, tk, l.in_norm, d->eps, hc, 3, qkv, qkv_out, nullptr, s, nullptr, 0, maps);
     }
     case EXL_DEC_ATTN: {
         const float scale = 1.0f / sqrtf((float) d->hd);
         if (g_plan) { g_plan[0] = 1; g_plan[1] = d->nsplit; g_plan[7] = d->nsplit * d->heads; return 0; }
-        if (d->nsplit == 1)
-            hipLaunchKernelGGL(dec_attn_kernel<true>, dim3(d->heads), dim3(256), 0, s, d->qbuf, d->kbuf, d->vbuf, l.kc, l.vc, d->sin, d->cos,
-                               d->partial, pos_dev, d->heads, d->kv_heads, d->max_seq, 1, scale, d->attn_out);
-        else
-            hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(d->nsplit * d->heads), dim3(256), 0, s, d->qbuf, d->kbuf, d->vbuf, l.kc, l.vc, d->sin,
-                               d->cos, d->partial, pos_dev, d->heads, d->kv_heads, d->max_seq, d->nsplit, scale, (f16*) nullptr);
+        static const int attn_waves = getenv("EXL_DEC_ATTN_WAVES") ? atoi(getenv("EXL_DEC_ATTN_WAVES")) : 4;
+#define DEC_ATTN_LAUNCH(SH, NWV, GRID, NS, OUT) hipLaunchKernelGGL((dec_attn_kernel<SH, NWV>), dim3(GRID), dim3(NWV * 64), 0, s, d->qbuf, d->kbuf, \
+            d->vbuf, l.kc, l.vc, d->sin, d->cos, d->partial, pos_dev, d->heads, d->kv_heads, d->max_seq, NS, scale, OUT, l.inv_o)
+        if (d->nsplit == 1) {
+            if (attn_waves == 8) DEC_ATTN_LAUNCH(true, 8, d->heads, 1, d->attn_out); else DEC_ATTN_LAUNCH(true, 4, d->heads, 1, d->attn_out);
+        } else {
+            if (attn_waves == 8) DEC_ATTN_LAUNCH(false, 8, d->nsplit * d->heads, d->nsplit, (f16*) nullptr);
+            else DEC_ATTN_LAUNCH(false, 4, d->nsplit * d->heads, d->nsplit, (f16*) nullptr);
+        }
+#undef DEC_ATTN_LAUNCH
         EXL_LAUNCH_CHECK();
         return 0;
     }
@@ -1104,20 +1215,25 @@ static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int3
         // the split merge runs inside the o_proj kernel's prologue (PNORM 3); the stand-alone kernel is the A/B reference
         if (d->nsplit == 1 || dec_folds_merge(d)) return 0;
         if (g_plan) { g_plan[0] = 1; g_plan[1] = d->nsplit; g_plan[7] = d->heads; return 0; }
-        hipLaunchKernelGGL(dec_attn_merge_kernel, dim3(d->heads), dim3(128), 0, s, d->partial, d->attn_out, d->nsplit, d->heads);
+        hipLaunchKernelGGL(dec_attn_merge_kernel, dim3(d->heads), dim3(128), 0, s, d->partial, d->attn_out, d->nsplit, d->heads, l.inv_o);
         EXL_LAUNCH_CHECK();
         return 0;
     case EXL_DEC_O: {
         Q4Matrix* om[1] = {l.o};
-        if (d->nsplit > 1 && dec_folds_merge(d))
+        if (d->nsplit > 1 && dec_folds_merge(d)) {                   // merged in this kernel's prologue, then gathered through o_proj's own map
+            const uint16_t* maps[1] = {l.map_o};
             return launch_dec_gemv(d->max_blocks, 3, 1, (const f16*) d->partial, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s,
-                                   d->partial + (size_t) d->heads * d->nsplit * 64, d->nsplit);
+                                   d->partial + (size_t) d->heads * d->nsplit * 64, d->nsplit, maps);
+        }
+        // the attention (one split) / merge kernel stored its output through inv_o: already in o_proj's row order, nothing to gather
         return launch_dec_gemv(d->max_blocks, 0, 1, d->attn_out, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s);
     }
     case EXL_DEC_GATE_UP: {
         Q4Matrix* gu[2] = {l.gate, l.up};
         f16* gu_out[2] = {d->act, nullptr};
-        return launch_dec_gemv(d->max_blocks, 1, 2, d->hid, nullptr, l.post_norm, d->eps, nullptr, 2, gu, gu_out, nullptr, s);
+        const uint16_t* maps[2] = {l.map_gate, l.map_up};
+        return launch_dec_gemv(d->max_blocks, 1, 2, d->hid, nullptr, l.post_norm, d->eps, nullptr, 2, gu, gu_out, nullptr, s, nullptr, 0, maps,
+                               l.inv_down);                          // the activation is stored in down_proj's row order
     }
     case EXL_DEC_DOWN: {
         Q4Matrix* dm[1] = {l.down};

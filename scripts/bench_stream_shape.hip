@@ -16,7 +16,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int V, bool MFMA, int U, bool SYNC, bool ILV = false>
+template <int V, bool MFMA, int U, bool SYNC, bool ILV = false, bool RBMAJOR = false>
 __global__ __launch_bounds__(512) void tile_stream(const u32x4* __restrict__ w, int ntiles, int rbw, float* vec, _Float16* out)
 {
     __shared__ u32x4 xs[1024];                       // activation image (16 KB)
@@ -32,8 +32,11 @@ __global__ __launch_bounds__(512) void tile_stream(const u32x4* __restrict__ w, 
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x, par ^= 1) {
         // ILV: the 8 waves of a block read 8 CONSECUTIVE KiB per step (wave w takes row-blocks w, w + 8, ...) instead of 8
         // separate 1 KiB pieces 8 KiB apart (wave w takes the contiguous slice [w * rbw, (w + 1) * rbw))
-        const u32x4* base = ILV ? w + ((size_t) t * 8 * rbw + wave) * 64 + lane : w + ((size_t) t * 8 + wave) * (size_t) rbw * 64 + lane;
-        constexpr int RS = ILV ? 8 * 64 : 64;
+        // RBMAJOR: the pieces of one row-block of ALL tiles are contiguous in memory ([rb][tile] instead of [tile][rb]); with the
+        // interleaved wave assignment one step of the whole grid then reads one contiguous 4 MB window, like a grid-strided sweep
+        const u32x4* base = RBMAJOR ? w + ((size_t) wave * ntiles + t) * 64 + lane
+                          : ILV ? w + ((size_t) t * 8 * rbw + wave) * 64 + lane : w + ((size_t) t * 8 + wave) * (size_t) rbw * 64 + lane;
+        const size_t RS = RBMAJOR ? (size_t) 8 * ntiles * 64 : ILV ? 8 * 64 : 64;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         u32x4 buf[2][U];
 #pragma unroll
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(512) void tile_stream(const u32x4* __restrict__ w, 
     if (blockIdx.x == 0) vec[tid * 4] = 1e-30f * (float) tid;
 }
 
-template <int V, bool MFMA, int U, bool SYNC, bool ILV = false>
+template <int V, bool MFMA, int U, bool SYNC, bool ILV = false, bool RBMAJOR = false>
 static void run(const char* name, const u32x4* w, float* vec, _Float16* out, int grid)
 {
     const int ntiles = 688, rbw = 8;                           // 688 tiles x 64 KB = 45.1 MB per kernel (the 7B gate_up launch)
@@ -89,7 +92,7 @@ static void run(const char* name, const u32x4* w, float* vec, _Float16* out, int
     const int n = 80;
     CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
     for (int i = 0; i < n; ++i)
-        hipLaunchKernelGGL((tile_stream<V, MFMA, U, SYNC, ILV>), dim3(grid), dim3(512), 0, s, w + (size_t) i * (pieces + 4096), ntiles, rbw, vec, out);
+        hipLaunchKernelGGL((tile_stream<V, MFMA, U, SYNC, ILV, RBMAJOR>), dim3(grid), dim3(512), 0, s, w + (size_t) i * (pieces + 4096), ntiles, rbw, vec, out);
     CK(hipStreamEndCapture(s, &g));
     CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -113,6 +116,9 @@ int main()
     run<0, false, 4, true>("loads only, U=4, barrier per tile", w, vec, out, 512);
     run<0, false, 4, false>("loads only, U=4, no barrier", w, vec, out, 512);
     run<0, false, 4, true, true>("loads only, U=4, waves interleaved in K", w, vec, out, 512);
+    run<0, false, 4, true, true, true>("loads only, U=4, row-block-major layout", w, vec, out, 512);
+    run<0, false, 4, true, true, true>("loads only, U=4, row-block-major, 688 blocks", w, vec, out, 688);
+    run<8, true, 4, true, true, true>("4 MFMA + 8 pk VALU, row-block-major layout", w, vec, out, 512);
     run<0, false, 2, true>("loads only, U=2", w, vec, out, 512);
     run<0, false, 2, true, true>("loads only, U=2, waves interleaved in K", w, vec, out, 512);
     run<0, false, 4, true>("loads only, U=4, 1 block per CU", w, vec, out, 256);
