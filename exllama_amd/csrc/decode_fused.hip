@@ -190,8 +190,13 @@ __device__ unsigned long long g_stream_probe[8 * 512 * 8];          // [class = 
 #else
 #define SP_CLK(i) do { } while (0)
 #endif
+// Register budget: two blocks per CU (4 waves per SIMD) need <= 128 VGPRs.  Most streams meet that on their own; the ones named
+// here are a few registers above it and are capped (a handful of spills outside the inner loop; measured: 13B gate/up 22.8 ->
+// 19.4 us, 65B 46.5 -> 43.5).  Capping the 6- and 7-deep streams costs 100+ bytes of scratch per lane and loses (65B down_proj
+// 26.8 -> 34.6 us): those run one block per CU and are only chosen where the grid has no more blocks than CUs.
+#define DEC_MIN_WAVES(U, NP, G16, PNORM, EMODE) ((((EMODE) == 2 && (G16) && (U) <= 5) || ((PNORM) == 0 && (U) == 4)) ? 4 : 2)
 template <int U, int NP, bool G16, int PNORM, int EMODE, int NV>
-__global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvArgs a)
+__global__ __launch_bounds__(DEC_THREADS, DEC_MIN_WAVES(U, NP, G16, PNORM, EMODE)) void dec_stream_kernel(const DecGemvArgs a)
 {
 #ifdef EXL_ATTN_PROBE
     unsigned long long sp_t[6] = {0, 0, 0, 0, 0, 0};
@@ -207,8 +212,14 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
     const f16* a_vec = dec_pin_ptr(a.vec); const f16* a_norm_w = dec_pin_ptr(a.norm_w); const int64_t* a_tok = dec_pin_ptr(a.tok);
     int te0 = a.tile_end[0], te1 = a.tile_end[1], te2 = a.tile_end[2], a_nmat = a.nmat;
     int a_rbw = a.rb_per_wave, a_images = a.xs_images, nb = a.nblocks, units_lo = a.units_lo, units_rem = a.units_rem;
-    int early_w = a.early_weights, abl = a.ablate;
-    DEC_PIN_S(early_w); DEC_PIN_S(abl);
+    int early_w = a.early_weights;
+    DEC_PIN_S(early_w);
+#ifdef EXL_DEC_ABLATE_BUILD                                           // measurement builds only (-DEXL_DEC_ABLATE_BUILD): run-time ablation levels
+    int abl = a.ablate;
+    DEC_PIN_S(abl);
+#else
+    constexpr int abl = 0;
+#endif
     const uint16_t* g0 = dec_pin_ptr(a.map16[0]); const uint16_t* g1 = dec_pin_ptr(a.map16[1]); const uint16_t* g2 = dec_pin_ptr(a.map16[2]);
     DEC_PIN_S(K); DEC_PIN_S(R);
     DEC_PIN_S(te0); DEC_PIN_S(te1); DEC_PIN_S(te2); DEC_PIN_S(a_nmat); DEC_PIN_S(a_rbw); DEC_PIN_S(a_images);
@@ -262,8 +273,27 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
 #pragma unroll
         for (int sp2 = 0; sp2 < MS; ++sp2) praw[sp2] = base[min(sp2, a.att_nsplit - 1) * 16];
     };
+    // PNORM 0 without a gather (o_proj after the merge kernel, down_proj): the image is a plain copy of the vector -> LDS-DMA
+    // (global_load_lds_dwordx4: 1 KiB per wave instruction straight into LDS, no VGPR round trip).  The K = intermediate-size
+    // kernels held 2 x NV x 4 registers for this copy, which pushed them over 128 VGPRs = one block per CU, i.e. a second
+    // round for the 320-512 tile o_proj / down_proj of the 13B-65B models.
+    // (PNORM 0 never gathers: its producers store the vector in the consumer's row order -- launch_dec_gemv checks.)
+    constexpr bool dma_image = PNORM == 0;
     if constexpr (PNORM == 3) {
         load_splits(0);
+    } else if constexpr (PNORM == 0) {
+        {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int idx0 = wave * 64 + i * DEC_THREADS;        // first packed row of this wave's 1 KiB piece (uniform)
+                if (idx0 < nvec) {
+                    const int idx = idx0 + lane;
+                    const int ci = idx < nvec ? idx : 0;             // lanes past the end copy row 0 into the reduction scratch: harmless
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (src + ci * 8),
+                                                     (__attribute__((address_space(3))) unsigned char*) (xs + idx0), 16, 0, 0);
+                }
+            }
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -325,9 +355,10 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
     } else if constexpr (PNORM == 3) {
         // log-sum-exp merge of the attention splits (what the stand-alone dec_attn_merge_kernel does), per head inside its
         // 16-lane group: lane s holds (m_s, l_s); coefficient of split s = l_s e^(m_s - M) / sum of those.  One 8-dim vector
-        // at a time: 16 x 16 bytes of split outputs per thread are the register budget (hidden > 4096: 2 vectors per thread).
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
+        // at a time: 16 x 16 bytes of split outputs per thread are the register budget.  With two vectors per thread (hidden >
+        // 4096) the loop stays ROLLED and each merged vector goes straight to LDS: unrolled, hipcc keeps both vectors' 32 split
+        // loads live and spills under the 128-register cap of two blocks per CU.
+        auto merge_one = [&]() {
             float M = pml.x;
 #pragma unroll
             for (int off = 1; off < 16; off <<= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
@@ -344,21 +375,37 @@ __global__ __launch_bounds__(DEC_THREADS) void dec_stream_kernel(const DecGemvAr
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] = fmaf((float) o8[j], cf, acc[j]);
             }
+            f16x8 r;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xv[i][j] = (f16) acc[j];
-            if (i + 1 < NV) { asm volatile("" ::: "memory"); load_splits(i + 1); asm volatile("" ::: "memory"); }   // not hoisted above the merge of vector i
+            for (int j = 0; j < 8; ++j) r[j] = (f16) acc[j];
+            return r;
+        };
+        if constexpr (NV == 1) {
+            xv[0] = merge_one();
+        } else {
+#pragma unroll 1
+            for (int i = 0; i < NV; ++i) {
+                if (i) load_splits(i);                               // (vector 0 was requested in the prologue)
+                const f16x8 r = merge_one();
+                const int idx = tid + i * DEC_THREADS;
+                if (idx < nvec) {
+                    if (g0 != nullptr) *(f16x8*) (xlin + idx * 8) = r;
+                    else               xs[idx] = __builtin_bit_cast(uint4, r);
+                }
+            }
         }
-    } else {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) xv[i] = __builtin_bit_cast(f16x8, xraw[i]);
     }
-    const bool gather = g0 != nullptr;                               // all matrices of a launch agree (checked on the host)
+    const bool gather = PNORM != 0 && g0 != nullptr;                 // all matrices of a launch agree (checked on the host)
+    if constexpr (!(PNORM == 3 && NV > 1) && !dma_image) {
+        {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int idx = tid + i * DEC_THREADS;
-        if (idx < nvec) {
-            if (gather) *(f16x8*) (xlin + idx * 8) = xv[i];
-            else        xs[idx] = __builtin_bit_cast(uint4, xv[i]);
+            for (int i = 0; i < NV; ++i) {
+                const int idx = tid + i * DEC_THREADS;
+                if (idx < nvec) {
+                    if (gather) *(f16x8*) (xlin + idx * 8) = xv[i];
+                    else        xs[idx] = __builtin_bit_cast(uint4, xv[i]);
+                }
+            }
         }
     }
     __syncthreads();
@@ -1038,7 +1085,7 @@ static thread_local int* g_plan = nullptr;
 
 // (U, NP) by row-blocks per wave; G16 by group size; NV by K
 template <int PNORM, int EMODE, int NV>
-static int launch_dec_gemv_cfg(bool g16, int rbw, dim3 grid, size_t smem, hipStream_t s, const DecGemvArgs& a)
+static int launch_dec_gemv_cfg(bool g16, int rbw, dim3 grid, size_t smem, hipStream_t s, const DecGemvArgs& a, bool two_per_cu)
 {
     // The opt-in for more than 64 KiB of dynamic LDS is a per-device function attribute: tracked per (kernel, device).
 #define DEC_LAUNCH1(U, NP, G) do { auto kfn = dec_stream_kernel<U, NP, G, PNORM, EMODE, NV>;                                   \
@@ -1064,9 +1111,7 @@ static int launch_dec_gemv_cfg(bool g16, int rbw, dim3 grid, size_t smem, hipStr
     else if (rbw <= 8)  DEC_LAUNCH1(4, 2, true);
     else                DEC_LAUNCH1(6, 2, true);
 #else
-    if constexpr (PNORM == 3) {                                      // o_proj with the folded merge: hidden <= 4096
-        DEC_LAUNCH(4, 1);
-    } else if constexpr (NV <= 2) {                                  // K = hidden size <= 8192
+    if constexpr (NV <= 2) {                                         // K = hidden size <= 8192
         if (rbw <= 4)       DEC_LAUNCH(4, 1);
         else if (rbw == 5)  DEC_LAUNCH(5, 1);
         else if (rbw == 6)  DEC_LAUNCH(6, 1);
@@ -1082,6 +1127,13 @@ static int launch_dec_gemv_cfg(bool g16, int rbw, dim3 grid, size_t smem, hipStr
         }
     } else {                                                         // down_proj: K = intermediate size (> 8192)
         if constexpr (PNORM == 0 && EMODE == 1) {
+            // More tiles than CUs (13B: 320, 65B / 70B: 512): two blocks per CU must be co-resident or the second round runs with a
+            // quarter of the chip -- that needs <= 128 VGPRs, which only the U = 4 streams meet (6 loads in flight: 138-179).
+            if (two_per_cu && g16 && rbw > 12 && rbw <= 16)      DEC_LAUNCH(4, 4);   // (groupsize 32 / 64 streams fit 128 VGPRs as they are)
+            else if (two_per_cu && g16 && rbw > 16 && rbw <= 20) DEC_LAUNCH(4, 5);
+            else if (two_per_cu && g16 && rbw > 20 && rbw <= 24) DEC_LAUNCH(4, 6);
+            else if (two_per_cu && g16 && rbw > 24 && rbw <= 28) DEC_LAUNCH(4, 7);
+            else
             if (rbw <= 10)      DEC_LAUNCH(5, 2);
             else if (rbw <= 12) DEC_LAUNCH(6, 2);
             else if (rbw <= 14) DEC_LAUNCH(7, 2);
@@ -1147,14 +1199,16 @@ static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec,
     for (int i = 1; i < nmat; ++i)
         EXL_REQUIRE((a.map16[i] == nullptr) == (a.map16[0] == nullptr), EXL_E_UNSUPPORTED,
                     "decoder: matrices fused into one launch must agree on act-order");
+    EXL_REQUIRE(pnorm != 0 || !any_map, EXL_E_INVALID, "decoder: a plain-vector launch takes its activation already in row order");
     a.out_perm = out_perm;
     dim3 grid(tiles < max_blocks ? tiles : max_blocks);
+    const bool two_per_cu = (int) grid.x > max_blocks / 2;            // max_blocks = 2 x CUs (EXL_DEC_BLOCKS_PER_CU)
     a.nblocks = (int) grid.x;
     a.units_lo = tiles / (int) grid.x;
     a.units_rem = tiles % (int) grid.x;
     // NV (8-half activation vectors per thread) instantiations by kernel class: the normed / merged inputs have K = hidden
     // <= 8192 (NV <= 2; the merge fold only exists for hidden <= 4096), only o_proj / down_proj see K = intermediate size
-#define DEC_GO(P, E, N) launch_dec_gemv_cfg<P, E, N>(g16, rbw, grid, smem, s, a)
+#define DEC_GO(P, E, N) launch_dec_gemv_cfg<P, E, N>(g16, rbw, grid, smem, s, a, two_per_cu)
     EXL_REQUIRE(nv <= 8, EXL_E_UNSUPPORTED, "decoder: in_features %d too large", K);
 #ifdef EXL_DEC_FAST_BUILD
     if (pnorm == 1 && emode == 0) return DEC_GO(1, 0, 1);
@@ -1164,7 +1218,7 @@ static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec,
 #else
     if (pnorm == 1 && emode == 0) { EXL_REQUIRE(nv <= 2, EXL_E_UNSUPPORTED, "decoder: hidden size too large"); return nv <= 1 ? DEC_GO(1, 0, 1) : DEC_GO(1, 0, 2); }
     if (pnorm == 1 && emode == 2) { EXL_REQUIRE(nv <= 2, EXL_E_UNSUPPORTED, "decoder: hidden size too large"); return nv <= 1 ? DEC_GO(1, 2, 1) : DEC_GO(1, 2, 2); }
-    if (pnorm == 3 && emode == 1) { EXL_REQUIRE(nv <= 1, EXL_E_UNSUPPORTED, "decoder: the split merge folds only for hidden <= 4096"); return DEC_GO(3, 1, 1); }
+    if (pnorm == 3 && emode == 1) { EXL_REQUIRE(nv <= 2, EXL_E_UNSUPPORTED, "decoder: hidden size too large"); return nv <= 1 ? DEC_GO(3, 1, 1) : DEC_GO(3, 1, 2); }
     if (pnorm == 0 && emode == 1)
         return nv <= 1 ? DEC_GO(0, 1, 1) : nv <= 2 ? DEC_GO(0, 1, 2) : nv <= 3 ? DEC_GO(0, 1, 3) : nv <= 6 ? DEC_GO(0, 1, 6) : DEC_GO(0, 1, 8);
 #endif
@@ -1177,7 +1231,14 @@ static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec,
 // vector's loads live and o_proj, which needs two blocks per CU from hidden 5120 on, drops to one; a rolled loop under a
 // 128-register cap spills instead.  Same box, 13B: 177 tokens/s folded vs 193.5 with the merge kernel; 33B: 76.9 vs 81.1),
 // where the boundary is also a smaller share of the layer.
-static bool dec_folds_merge(const Decoder* d) { return !d->separate_merge && d->h <= DEC_THREADS * 8; }
+// (Round 2 re-test with a ROLLED merge loop writing straight to LDS, no spill: 13B o_proj 7.3 + 2.8 (merge kernel) -> 14.7 us
+// folded, 65B 10.0 + 3.0 -> 19.7: every one of the 320-512 o_proj blocks re-reads all split partials (two dependent round
+// trips of 16 x 16 bytes per thread).  EXL_DEC_FOLD_WIDE=1 keeps it reachable.)
+static bool dec_folds_merge(const Decoder* d)
+{
+    static const bool wide = getenv("EXL_DEC_FOLD_WIDE") != nullptr;
+    return !d->separate_merge && d->h <= (wide ? 2 : 1) * DEC_THREADS * 8;
+}
 
 // One kernel class of one layer (EXL_DEC_* in include/exl_amd.h); EXL_DEC_HEAD ignores `i`.
 static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int32_t* pos_dev, float* logits_out, int advance,

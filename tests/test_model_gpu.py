@@ -341,11 +341,12 @@ _REAL_SHAPES = {
     #        name   gs   act    L  qkv                    o_proj (>1 split)       gate_up                down                   merge kernel
     "7b":  ("7b", 128, False, 2, (4, 1, 1, 1, 0, 1), (4, 1, 1, 3, 1, 1), (4, 2, 1, 1, 2, 1), (6, 2, 1, 0, 1, 3), False),
     # (U, NP) fits the row-blocks per wave exactly where it can: 13B 5 / 10 / 14, 33B 7 / 13 / 18, 65B 8 / 16 / 22, 70B 8 / 16 / 28
-    "13b": ("13b", 128, True, 1, (5, 1, 1, 1, 0, 2), (5, 1, 1, 0, 1, 2), (5, 2, 1, 1, 2, 2), (7, 2, 1, 0, 1, 6), True),
+    # (down_proj of 13B / 65B / 70B has more tiles than the chip has CUs: the 4-deep streams that fit two blocks per CU)
+    "13b": ("13b", 128, True, 1, (5, 1, 1, 1, 0, 2), (5, 1, 1, 0, 1, 2), (5, 2, 1, 1, 2, 2), (4, 4, 1, 0, 1, 6), True),
     "33b": ("33b", 32, True, 1, (4, 2, 0, 1, 0, 2), (4, 2, 0, 0, 1, 2), (7, 2, 0, 1, 2, 2), (6, 3, 0, 0, 1, 6), True),
-    "65b": ("65b", 128, False, 1, (4, 2, 1, 1, 0, 2), (4, 2, 1, 0, 1, 2), (4, 4, 1, 1, 2, 2), (6, 4, 1, 0, 1, 6), True),
+    "65b": ("65b", 128, False, 1, (4, 2, 1, 1, 0, 2), (4, 2, 1, 0, 1, 2), (4, 4, 1, 1, 2, 2), (4, 6, 1, 0, 1, 6), True),
     # Llama-2-70B: GQA (8 kv heads) and K = 28672 in down_proj -- 28 row-blocks per wave, 7 -> 8 vectors per thread
-    "70b": ("70b", 128, False, 1, (4, 2, 1, 1, 0, 2), (4, 2, 1, 0, 1, 2), (4, 4, 1, 1, 2, 2), (7, 4, 1, 0, 1, 8), True),
+    "70b": ("70b", 128, False, 1, (4, 2, 1, 1, 0, 2), (4, 2, 1, 0, 1, 2), (4, 4, 1, 1, 2, 2), (4, 7, 1, 0, 1, 8), True),
 }
 
 
