@@ -954,6 +954,7 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     d->layers.resize(n_layers);
     for (auto& l : d->layers) l.set = false;
     int ns = (max_seq_len > 1280 ? 512 : 256) / heads;             // long contexts: 2 blocks per CU, <= 160 keys each
+    if (const char* env = getenv("EXL_DEC_NSPLIT")) ns = atoi(env);  // measurement aid
     if (ns < 1) ns = 1;
     if (ns > DEC_MAX_NSPLIT) ns = DEC_MAX_NSPLIT;
     while ((max_seq_len + ns - 1) / ns + 16 > DEC_ATT_MAX_KEYS) ++ns;
