@@ -332,7 +332,7 @@ def main():
         if S >= 128:
             ms_128, _ = timed_prefill(128)
             extra["prompt_128_tokens"] = {"prefill_tokens_per_s": round(128 / (ms_128 / 1e3), 1), "prefill_ms": round(ms_128, 3),
-                                          "note": "BASELINE configs[0] prompt length (<= 512 rows: the un-specialised 128x128-tile GEMM)"}
+                                          "note": "BASELINE configs[0] prompt length (<= 256 rows: the short-prompt GEMM, csrc/q4_gemm_skinny.hip; op-by-op eager launches)"}
         result["other_lengths"] = extra
 
     # ---- whole-path roofline fractions (algorithmic bytes / flops) ------------------------------

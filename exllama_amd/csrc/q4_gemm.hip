@@ -1165,6 +1165,8 @@ static int launch_gemm_t16m(const Q4Matrix* w, const f16* xin, int rows, f16* ou
     return 0;
 }
 
+int launch_gemm_t16s(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_zero, hipStream_t s);
+
 int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_zero, f16* remap_tmp,
                    size_t remap_tmp_numel, hipStream_t s)
 {
@@ -1179,6 +1181,12 @@ int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
                     remap_tmp_numel, (size_t) rows * K);
         EXL_TRY(launch_column_remap(x, remap_tmp, rows, K, w->x_map, s));
         xin = remap_tmp;
+    }
+    // short prompts: the decode-shaped kernel, 32 rows x (16 .. 64) columns per block, waves split K (q4_gemm_skinny.hip)
+    static const int skinny_max = getenv("EXL_GEMM_SKINNY_MAX") ? atoi(getenv("EXL_GEMM_SKINNY_MAX")) : 256;
+    if (w->layout == EXL_LAYOUT_T16 && rows <= skinny_max && !getenv("EXL_GEMM_REGISTER_B")) {
+        const int r = launch_gemm_t16s(w, xin, rows, out, no_zero, s);
+        if (r != 1) return r;
     }
     int gshift = -1;
     if ((w->groupsize & (w->groupsize - 1)) == 0) { gshift = 0; while ((1 << gshift) < w->groupsize) ++gshift; }

@@ -29,6 +29,12 @@ int main(int argc, char** argv)
     CK(hipSetDevice(0));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     double tot_flop = 0, tot_ms = 0;
+    {   // scratch the short-prompt path re-tiles the activations into (the reference's temp_state)
+        const size_t ts = (size_t) 2048 * 11008, tm = 1024;
+        void *t0, *t1, *t2, *t3;
+        CK(hipMalloc(&t0, ts * 2)); CK(hipMalloc(&t1, tm * 2)); CK(hipMalloc(&t2, 1024 * 4)); CK(hipMalloc(&t3, 1024 * 2));
+        EX(exl_prepare_buffers(0, t0, ts, t1, tm, t2, 1024, t3, 1024));
+    }
     for (auto& sh : shapes) {
         const int K = sh[0], N = sh[1], gs = 128, G = K / gs, NB = 6;     // NB weight copies: beyond the 256 MB cache together
         std::vector<void*> hs(NB);

@@ -190,6 +190,10 @@ def test_q4_gemv_is_deterministic(ce):
 GEMM_SHAPES = [(256, 128, 64, True, 16), (512, 96, 128, False, 33), (704, 256, 64, True, 130), (256, 64, 32, True, 8),
                (4096, 4096, 128, False, 128), (4096, 11008, 128, False, 96), (11008, 4096, 128, True, 200),
                (6656, 6656, 32, True, 64),
+               # <= 256 rows: the short-prompt kernel (q4_gemm_skinny.hip) -- two 64-row groups, a ragged row group and a ragged
+               # column group, K shorter than the 8 waves, one group for the whole K (odd K), an odd group size (tile-kernel fallback)
+               (4096, 4096, 128, False, 256), (512, 96, 128, False, 250), (256, 352, 32, True, 70), (1408, 256, 1408, False, 50),
+               (1408, 128, 352, False, 50), (5120, 13824, 128, True, 17),
                # > 512 rows: the 256-row pipelined tile, ragged last m-tile
                (4096, 4096, 128, False, 600), (1408, 512, 64, True, 530), (512, 11008, 32, False, 777)]
 
