@@ -50,6 +50,9 @@ def parse_args():
     p.add_argument("--layer-split", action="store_true",
                    help="ONE model split by layers across the ranks (hidden states handed off by RCCL send/recv, exllama_amd/pipeline.py) "
                         "instead of one replica per rank; capacity mode: the stages run one after the other at batch 1")
+    p.add_argument("--tensor-parallel", action="store_true",
+                   help="ONE model split by heads / intermediate columns across the ranks (exllama_amd/tp.py): every rank streams 1/N of "
+                        "the weights per token, two all-reduces of the residual stream per layer over RCCL")
     return p.parse_args()
 
 
@@ -158,6 +161,87 @@ def layer_split_main(args, dims, L, S, G, rank, world, dev, dist):
         dist.destroy_process_group()
 
 
+def tensor_parallel_main(args, dims, L, S, G, rank, world, dev, dist):
+    """--tensor-parallel: every rank builds ITS shard of ONE model (exllama_amd/tp.py: its heads, its intermediate columns;
+    the same seeded checkpoint on every rank, cut locally), two collectives per layer on the residual stream.  Same protocol
+    and timing rules as the replica mode; the job's rate is the one model's rate ("strong" scaling)."""
+    from exllama_amd import synth, tp
+    from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
+
+    cfg_dict = synth.config_dict(dims, L)
+    full = synth.make_checkpoint(dims, groupsize=args.groupsize, act_order=args.act_order, seed=100, device=dev, zeros="sym", num_layers=L)
+    local, plan = tp.shard_tensors(full, cfg_dict, rank, world)
+    del full
+    cfg = ExLlamaConfig(tp.shard_config_dict(cfg_dict, plan))
+    cfg.max_seq_len = S + G
+    cfg.max_input_len = S
+    cfg.device_map.layers = [dev] * L
+    cfg.device_map.embed_tokens = cfg.device_map.norm = cfg.device_map.lm_head = dev
+    cfg.tp = tp.TensorParallel(plan, dist)
+    model = ExLlama(cfg, tensors=local)
+    del local
+    cache = ExLlamaCache(model)
+    gather_mode = any(l.self_attn.o_gather or l.mlp.down_gather for l in model.layers)
+    if not gather_mode:
+        model.enable_decode_graph(cache, use_graph=not args.no_graph)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)                                         # the same prompt on every rank (replicated residual stream)
+    ids = torch.randint(0, min(31999, dims.vocab_size - 1), (1, S), device=dev, generator=gen)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+
+    def step(record):
+        e = [ev() for _ in range(3)]
+        cache.current_seq_len = 0
+        e[0].record()
+        logits = model.forward(ids, cache)
+        e[1].record()
+        for _ in range(G):
+            tok = logits[0, -1].argmax().view(1, 1)               # identical logits on every rank: no token broadcast needed
+            logits = model.forward(tok, cache)
+        e[2].record()
+        if record is not None:
+            record.append(e)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(None)
+    barrier()
+    events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(events)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    mean = lambda v: sum(v) / len(v)
+    pre = mean([e[0].elapsed_time(e[1]) for e in events])
+    dec = mean([e[1].elapsed_time(e[2]) for e in events])
+    elapsed, pre, dec = reduce_over_ranks([elapsed, pre, dec], dist, dev)
+    if rank == 0:
+        st = model._decoder
+        mode = ("op-by-op path (act-order o_proj / down_proj shards: gather mode)" if gather_mode else
+                "native executor in half-layer pieces, " + ("captured in one hipGraph per token" if (st and st["graph"] is not None) else "eager launches"))
+        print(json.dumps({
+            "metric": "single-token decode tokens/s at full context (prefill tokens/s alongside), Llama GPTQ 4-bit",
+            "value": round(G / (dec / 1e3), 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "int4 weights (GPTQ) x fp16 activations, fp32 accumulate",
+            "data": "synthetic (seeded random GPTQ weights of the named architecture, random token ids)",
+            "config": {"workload": f"Llama-{args.model.upper()} 4-bit GPTQ g{args.groupsize}, {S}-token prefill + {G}-token greedy decode, "
+                                   f"ONE model, tensor parallel over {world} rank(s)", "layers": L, "prompt_tokens": S, "gen_tokens": G,
+                       "parallelism": f"tensor parallel x{world} (heads / intermediate columns per rank, 2 all-reduces of the residual stream "
+                                      f"per layer over RCCL; decode: {mode})"},
+            "prefill_tokens_per_s": round(S / (pre / 1e3), 1), "decode_worst_tokens_per_s": round(G / (dec / 1e3), 2),
+            "prefill_ms": round(pre, 3), "decode_worst_ms_per_token": round(dec / G, 4)}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def reduce_over_ranks(local_values, dist, device):
     """The contract's timing rule: every rank contributes its own timings, the job's timing is the MAX over ranks.
     `dist` is torch.distributed (initialised) or None for a single process."""
@@ -197,6 +281,8 @@ def main():
     S, G = args.prompt, args.gen
     if args.layer_split:
         return layer_split_main(args, dims, L, S, G, rank, world, dev, dist)
+    if args.tensor_parallel:
+        return tensor_parallel_main(args, dims, L, S, G, rank, world, dev, dist)
     tensors = synth.make_checkpoint(dims, groupsize=args.groupsize, act_order=args.act_order, seed=0, device=dev,
                                     zeros="sym", num_layers=L)
     cfg = ExLlamaConfig(synth.config_dict(dims, L))

@@ -48,7 +48,8 @@ struct DecGemvArgs {
     int tile_end[DEC_MAX_MATS];   // cumulative tile counts (EMODE 2: tiles of mat[0]; mat[1] is walked in lock-step)
     // ---- epilogue ----
     f16* out[DEC_MAX_MATS];       // EMODE 0: out[mi][n] = h(y);  EMODE 2: out[0][n] = silu(h(y_gate)) * h(y_up)
-    f16* hid_io;                  // EMODE 1: hid_io[n] = h(hid_io[n] + y)
+    f16* hid_io;                  // EMODE 1: hid_io[n] = h(res_in[n] + y)
+    const f16* res_in;            // EMODE 1: where the residual is read (= hid_io, or a zero vector on the tensor-parallel ranks that do not own it)
     int rb_per_wave;
     int xs_images;                // 1, or 2 when gate and up carry different act-order maps (EMODE 2)
     int ablate;                   // measurement only (EXL_DEC_ABLATE): 1 = skip the dequant + MFMA work, 3 = also the scale / zero loads, 4 = also the activation loads
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_MIN_WAVES(U, NP, G16, PNORM, EMODE
     if (!early_w) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     dec_unit_issue<U, G16>(mA, uA, 0, lane, wv0, ep0);               // addresses: scalar arithmetic + one VALU
     if constexpr (G16) { if (abl < 3) dec_unit_entries<NSLOT>(mA, uA, lane, entA); }
-    if constexpr (EMODE == 1) { if (tid < 16) resA = (float) a.hid_io[tileA * 16 + tid]; }
+    if constexpr (EMODE == 1) { if (tid < 16) resA = (float) a.res_in[tileA * 16 + tid]; }
 
     SP_CLK(0);                                                       // prologue loads + first weight batch issued
     // ---- 3. activation image (once per block) ---------------------------------------------------------------
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_MIN_WAVES(U, NP, G16, PNORM, EMODE
                 if (uC.rb0 + (p + 1) * U < uC.rb1) dec_unit_issue<U, G16>(mC, uC, p + 1, lane, DEC_BUF(P * NP + p + 1), DEC_EP(P * NP + p + 1)); \
             } else if (have_next) {                                                                                         \
                 if constexpr (G16) { if (abl < 3) dec_unit_entries<NSLOT>(mN, uN, lane, entN); }                            \
-                if constexpr (EMODE == 1) { if (tid < 16) resN = (float) a.hid_io[tileN * 16 + tid]; }                      \
+                if constexpr (EMODE == 1) { if (tid < 16) resN = (float) a.res_in[tileN * 16 + tid]; }                      \
                 dec_unit_issue<U, G16>(mN, uN, 0, lane, DEC_BUF((P ^ 1) * NP), DEC_EP((P ^ 1) * NP));                       \
             }                                                                                                               \
             if (abl) { _Pragma("unroll") for (int q = 0; q < U; ++q) c[0] += __builtin_bit_cast(float, DEC_BUF(P * NP + p)[q].x ^ DEC_BUF(P * NP + p)[q].w); } \
@@ -923,6 +924,9 @@ struct Decoder {
     int max_blocks;               // persistent GEMV grid: blocks per CU x CUs
     void* block;                  // one hipMalloc
     uint16_t* maps;               // act-order maps of all layers: per layer 2 x (6 hidden + inter) entries
+    f16* zero_res;                // [h] zeros: the residual a tensor-parallel rank that does not own it adds (exl_decoder_set_tp)
+    bool residual_owner;          // tensor parallel: only one rank adds the residual stream to its partial o_proj / down_proj sums
+    int qd() const { return heads * hd; }     // width of q / attention output: = h, or this rank's heads of a tensor-parallel shard
     bool has_embed() const { return embed != nullptr; }
     bool has_head() const { return lm_head != nullptr; }
 };
@@ -936,7 +940,8 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     *out = nullptr;
     EXL_REQUIRE(device >= 0 && device < EXL_MAX_DEVICES, EXL_E_INVALID, "decoder_create: invalid device %d", device);
     EXL_REQUIRE(head_dim == 128, EXL_E_UNSUPPORTED, "decoder: head_dim must be 128 (got %d)", head_dim);
-    EXL_REQUIRE(hidden % 128 == 0 && hidden == heads * head_dim && heads % kv_heads == 0, EXL_E_UNSUPPORTED, "decoder: bad head geometry");
+    // heads * head_dim < hidden: one rank's shard of a tensor-parallel model (exllama_amd/tp.py): its own heads, the full residual stream
+    EXL_REQUIRE(hidden % 128 == 0 && heads >= 1 && heads * head_dim <= hidden && heads % kv_heads == 0, EXL_E_UNSUPPORTED, "decoder: bad head geometry");
     EXL_REQUIRE(inter % 128 == 0, EXL_E_UNSUPPORTED, "decoder: intermediate size must be a multiple of 128 (got %d)", inter);
     EXL_REQUIRE(hidden <= 8192 && inter <= 32768, EXL_E_UNSUPPORTED, "decoder: hidden (%d) / intermediate (%d) size too large", hidden, inter);
     // A decoder may be one STAGE of a layer-split model (reference: ExLlamaDeviceMap, model.py:636-668): embed == NULL ->
@@ -972,12 +977,14 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     const size_t o_pr = carve((size_t) vocab * sizeof(float));
     const size_t maps_per_layer = 2 * ((size_t) 6 * hidden + inter);                 // map + inverse of q, k, v, o, gate, up (K = hidden) and down (K = inter)
     const size_t o_maps = carve(maps_per_layer * n_layers * sizeof(uint16_t));
+    const size_t o_zero = carve((size_t) hidden * 2);
     int prev = 0;
     hipError_t e = hipGetDevice(&prev);
     if (e == hipSuccess) e = hipSetDevice(device);
     int cus = 0;
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     if (e == hipSuccess) e = hipMalloc(&d->block, bytes);
+    if (e == hipSuccess) e = hipMemset((unsigned char*) d->block + o_zero, 0, (size_t) hidden * 2);
     (void) hipSetDevice(prev);
     if (e != hipSuccess) { delete d; EXL_FAIL((int) e, "decoder_create: %s", hipGetErrorString(e)); }
     unsigned char* b = (unsigned char*) d->block;
@@ -987,6 +994,8 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     d->head_best = (float2*) (b + o_hb);
     d->probs = (float*) (b + o_pr);
     d->maps = (uint16_t*) (b + o_maps);
+    d->zero_res = (f16*) (b + o_zero);
+    d->residual_owner = true;
     d->separate_merge = getenv("EXL_DEC_SEPARATE_MERGE") != nullptr;
     int bpc = 2;
     if (const char* env = getenv("EXL_DEC_BLOCKS_PER_CU")) { bpc = atoi(env); if (bpc < 1) bpc = 1; if (bpc > 4) bpc = 4; }
@@ -1013,8 +1022,8 @@ extern "C" int exl_decoder_set_layer(void* dec, int index, void* q, void* k, voi
     l.gate = q4_from_handle(gate); l.up = q4_from_handle(up); l.down = q4_from_handle(down);
     EXL_REQUIRE(l.q && l.k && l.v && l.o && l.gate && l.up && l.down, EXL_E_INVALID, "decoder_set_layer: invalid q4 handle");
     const int kvd = d->kv_heads * d->hd;
-    EXL_REQUIRE(l.q->height == d->h && l.q->width == d->h && l.k->height == d->h && l.k->width == kvd &&
-                l.v->height == d->h && l.v->width == kvd && l.o->height == d->h && l.o->width == d->h &&
+    EXL_REQUIRE(l.q->height == d->h && l.q->width == d->qd() && l.k->height == d->h && l.k->width == kvd &&
+                l.v->height == d->h && l.v->width == kvd && l.o->height == d->qd() && l.o->width == d->h &&
                 l.gate->height == d->h && l.gate->width == d->inter && l.up->height == d->h && l.up->width == d->inter &&
                 l.down->height == d->inter && l.down->width == d->h, EXL_E_INVALID, "decoder_set_layer: matrix shapes do not match the model");
     for (Q4Matrix* m : {l.q, l.k, l.v, l.o, l.gate, l.up, l.down}) {
@@ -1160,10 +1169,11 @@ static int launch_dec_gemv_cfg(bool g16, int rbw, dim3 grid, size_t smem, hipStr
 static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec, const int64_t* tok, const f16* norm_w, float eps, f16* hid_copy,
                            int nmat, Q4Matrix* const* mats, f16* const* outs, f16* hid_io, hipStream_t s,
                            const float* att_ml = nullptr, int att_nsplit = 0, const uint16_t* const* maps = nullptr,
-                           const uint16_t* out_perm = nullptr)
+                           const uint16_t* out_perm = nullptr, const f16* res_in = nullptr)
 {
     DecGemvArgs a;
     a.vec = vec; a.tok = tok; a.norm_w = norm_w; a.eps = eps; a.hid_copy = hid_copy; a.nmat = nmat; a.hid_io = hid_io;
+    a.res_in = res_in ? res_in : hid_io;
     a.att_ml = att_ml; a.att_nsplit = att_nsplit;
     int tiles = 0;
     bool any_map = false;
@@ -1238,7 +1248,7 @@ static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec,
 static bool dec_folds_merge(const Decoder* d)
 {
     static const bool wide = getenv("EXL_DEC_FOLD_WIDE") != nullptr;
-    return !d->separate_merge && d->h <= (wide ? 2 : 1) * DEC_THREADS * 8;
+    return !d->separate_merge && d->qd() <= (wide ? 2 : 1) * DEC_THREADS * 8;
 }
 
 // One kernel class of one layer (EXL_DEC_* in include/exl_amd.h); EXL_DEC_HEAD ignores `i`.
@@ -1282,13 +1292,15 @@ static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int3
         return 0;
     case EXL_DEC_O: {
         Q4Matrix* om[1] = {l.o};
+        const f16* res = d->residual_owner ? d->hid : d->zero_res;
         if (d->nsplit > 1 && dec_folds_merge(d)) {                   // merged in this kernel's prologue, then gathered through o_proj's own map
             const uint16_t* maps[1] = {l.map_o};
             return launch_dec_gemv(d->max_blocks, 3, 1, (const f16*) d->partial, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s,
-                                   d->partial + (size_t) d->heads * d->nsplit * 64, d->nsplit, maps);
+                                   d->partial + (size_t) d->heads * d->nsplit * 64, d->nsplit, maps, nullptr, res);
         }
         // the attention (one split) / merge kernel stored its output through inv_o: already in o_proj's row order, nothing to gather
-        return launch_dec_gemv(d->max_blocks, 0, 1, d->attn_out, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s);
+        return launch_dec_gemv(d->max_blocks, 0, 1, d->attn_out, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s, nullptr, 0, nullptr,
+                               nullptr, res);
     }
     case EXL_DEC_GATE_UP: {
         Q4Matrix* gu[2] = {l.gate, l.up};
@@ -1299,7 +1311,8 @@ static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int3
     }
     case EXL_DEC_DOWN: {
         Q4Matrix* dm[1] = {l.down};
-        return launch_dec_gemv(d->max_blocks, 0, 1, d->act, nullptr, nullptr, 0.f, nullptr, 1, dm, nullptr, d->hid, s);
+        return launch_dec_gemv(d->max_blocks, 0, 1, d->act, nullptr, nullptr, 0.f, nullptr, 1, dm, nullptr, d->hid, s, nullptr, 0, nullptr, nullptr,
+                               d->residual_owner ? d->hid : d->zero_res);
     }
     case EXL_DEC_HEAD: {
         if (!d->has_head()) return 0;
@@ -1339,6 +1352,47 @@ extern "C" int exl_decoder_step(void* dec, const int64_t* token_dev, int32_t* po
     }
     if (prev != d->device) (void) hipSetDevice(prev);
     return rc;
+}
+
+// Tensor parallel (exllama_amd/tp.py): a token step in pieces, so that the caller can all-reduce the residual stream between
+// them.  part 0 = attention half of `layer` (RMSNorm + q/k/v (+ embedding lookup for layer 0 of a first stage), attention,
+// o_proj); part 1 = MLP half (RMSNorm + gate/up + SiLU*mul, down_proj); part 2 = final norm + head (+ position advance).
+// After parts 0 and 1 every rank's residual stream (exl_decoder_hidden) holds ITS partial sum -- plus the incoming residual
+// on the one rank that owns it (exl_decoder_set_tp) -- and the sum over ranks is the new residual stream.
+extern "C" int exl_decoder_step_part(void* dec, int layer, int part, const int64_t* token_dev, int32_t* pos_dev, float* logits_out,
+                                     int advance, void* stream)
+{
+    Decoder* d = dec_from(dec);
+    EXL_REQUIRE(d, EXL_E_INVALID, "decoder_step_part: invalid decoder");
+    EXL_REQUIRE(part >= 0 && part <= 2, EXL_E_INVALID, "decoder_step_part: unknown part %d", part);
+    EXL_REQUIRE(part == 2 || (layer >= 0 && layer < d->L && d->layers[layer].set), EXL_E_INVALID, "decoder_step_part: layer %d not set", layer);
+    EXL_REQUIRE(pos_dev && (part != 0 || layer != 0 || token_dev || !d->has_embed()) && (part != 2 || logits_out || !d->has_head()),
+                EXL_E_INVALID, "decoder_step_part: null pointer");
+    hipStream_t s = (hipStream_t) stream;
+    int prev = 0;
+    EXL_HIP(hipGetDevice(&prev));
+    if (prev != d->device) EXL_HIP(hipSetDevice(d->device));
+    int rc = 0;
+    if (part == 0) for (int cls = EXL_DEC_QKV; cls <= EXL_DEC_O && rc == 0; ++cls) rc = dec_launch(d, cls, layer, token_dev, pos_dev, logits_out, advance, s);
+    else if (part == 1) for (int cls = EXL_DEC_GATE_UP; cls <= EXL_DEC_DOWN && rc == 0; ++cls) rc = dec_launch(d, cls, layer, token_dev, pos_dev, logits_out, advance, s);
+    else {
+        rc = dec_launch(d, EXL_DEC_HEAD, 0, token_dev, pos_dev, logits_out, advance, s);
+        if (rc == 0 && !d->has_head() && advance) {
+            hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(1), 0, s, pos_dev);
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { exl_set_error("decoder_step_part: %s", hipGetErrorString(e)); rc = (int) e; }
+        }
+    }
+    if (prev != d->device) (void) hipSetDevice(prev);
+    return rc;
+}
+
+extern "C" int exl_decoder_set_tp(void* dec, int residual_owner)
+{
+    Decoder* d = dec_from(dec);
+    EXL_REQUIRE(d, EXL_E_INVALID, "decoder_set_tp: invalid decoder");
+    d->residual_owner = residual_owner != 0;
+    return 0;
 }
 
 extern "C" int exl_decoder_set_hidden(void* dec, void* hidden_dev)

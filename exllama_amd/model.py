@@ -78,7 +78,8 @@ class ExLlamaConfig:
         self.num_key_value_heads = cfg.get("num_key_value_heads", self.num_attention_heads)
         self.num_key_value_groups = self.num_attention_heads // self.num_key_value_heads
         self.rotary_embedding_base = cfg.get("rope_theta", 10000.0)
-        self.head_dim = self.hidden_size // self.num_attention_heads
+        self.head_dim = cfg.get("head_dim", self.hidden_size // self.num_attention_heads)   # explicit for a tensor-parallel shard (tp.py)
+        self.tp = None              # exllama_amd.tp.TensorParallel when this model is one rank's shard
 
         self.groupsize = None       # autodetected
         self.act_order = False      # autodetected
@@ -199,7 +200,12 @@ class ExLlamaMLP:
         h, i = config.hidden_size, config.intermediate_size
         self.gate_proj = Ex4bitLinear(config, h, i, False, tensors, key + ".gate_proj")
         self.up_proj = Ex4bitLinear(config, h, i, False, tensors, key + ".up_proj")
-        self.down_proj = Ex4bitLinear(config, i, h, False, tensors, key + ".down_proj")
+        d_in, d_out = i, h
+        self.down_gather = False
+        if config.tp is not None and tensors[key + ".down_proj.qweight"].shape[1] != h:
+            self.down_gather = True                                  # act-order down_proj of a tensor-parallel shard (tp.py)
+            d_in, d_out = tensors[key + ".down_proj.qweight"].shape[0] * 8, tensors[key + ".down_proj.qweight"].shape[1]
+        self.down_proj = Ex4bitLinear(config, d_in, d_out, False, tensors, key + ".down_proj")
 
     def fused(self, x, buffer, post_attention_layernorm, lora):
         """rows <= fused_mlp_thd: one native call, residual added in place (reference: model.py:238-263)."""
@@ -226,7 +232,14 @@ class ExLlamaMLP:
 
     def forward_residual(self, normed, hidden, lora):
         """hidden += down(silu(gate(normed)) * up(normed)); residual fused in the down_proj epilogue."""
-        self.down_proj.forward(self._activation(normed, lora), lora, out=hidden, accumulate=True)
+        tp = self.config.tp
+        if tp is None:
+            self.down_proj.forward(self._activation(normed, lora), lora, out=hidden, accumulate=True)
+        elif self.down_gather:
+            act = tp.all_gather_last(self._activation(normed, lora), tp.plan.inter_sizes)
+            hidden.add_(tp.all_gather_last(self.down_proj.forward(act, lora), tp.plan.hidden_sizes))
+        else:
+            hidden.add_(tp.all_reduce(self.down_proj.forward(self._activation(normed, lora), lora)))
 
     def forward(self, x, buffer=None, lora=None):
         """Non-residual form of the reference (model.py:266-273)."""
@@ -241,7 +254,13 @@ class ExLlamaAttention:
         self.q_proj = Ex4bitLinear(config, h, config.num_attention_heads * hd, False, tensors, key + ".q_proj")
         self.k_proj = Ex4bitLinear(config, h, config.num_key_value_heads * hd, False, tensors, key + ".k_proj")
         self.v_proj = Ex4bitLinear(config, h, config.num_key_value_heads * hd, False, tensors, key + ".v_proj")
-        self.o_proj = Ex4bitLinear(config, config.num_attention_heads * hd, h, False, tensors, key + ".o_proj")
+        o_in, o_out = config.num_attention_heads * hd, h
+        self.o_gather = False
+        if config.tp is not None and tensors[key + ".o_proj.qweight"].shape[1] != h:
+            # act-order o_proj of a tensor-parallel shard: cut by output columns, needs the full attention output (tp.py)
+            self.o_gather = True
+            o_in, o_out = tensors[key + ".o_proj.qweight"].shape[0] * 8, tensors[key + ".o_proj.qweight"].shape[1]
+        self.o_proj = Ex4bitLinear(config, o_in, o_out, False, tensors, key + ".o_proj")
 
     def fused(self, hidden_states, cache, buffer, input_layernorm, lora):
         """rows == 1: q4_attn -> HIP attention -> q4_attn_2, all in place on hidden_states (reference: model.py:322-418)."""
@@ -290,7 +309,12 @@ class ExLlamaAttention:
         attn = torch.empty_like(q)
         mask = buffer.attn_mask if (buffer is not None and buffer.needs_mask) else None
         ext.attention(q, kc, vc, attn, past_len, cfg.num_attention_heads, mask=mask)
-        self.o_proj.forward(attn, lora, out=hidden, accumulate=True)
+        if cfg.tp is None:
+            self.o_proj.forward(attn, lora, out=hidden, accumulate=True)
+        elif self.o_gather:                                          # every rank: full input -> its output columns -> gathered
+            hidden.add_(cfg.tp.all_gather_last(self.o_proj.forward(cfg.tp.all_gather_last(attn), lora), cfg.tp.plan.hidden_sizes))
+        else:                                                        # partial sums over this rank's heads -> all-reduce
+            hidden.add_(cfg.tp.all_reduce(self.o_proj.forward(attn, lora)))
 
 
 def _rows(x):
@@ -313,6 +337,12 @@ class ExLlamaDecoderLayer:
         """In place on hidden_states; same branch conditions as the reference (model.py:524-552)."""
         cfg = self.config
         rows = _rows(hidden_states)
+        if cfg.tp is not None:                                       # a shard: the paths with the collectives (never the fused ops,
+            normed = self.input_layernorm.forward(hidden_states, buffer)      # which add their PARTIAL result into the residual stream)
+            self.self_attn.forward_residual(normed, hidden_states, cache, buffer, lora)
+            normed = self.post_attention_layernorm.forward(hidden_states, buffer)
+            self.mlp.forward_residual(normed, hidden_states, lora)
+            return hidden_states
         if cfg.fused_attn and rows == 1:
             self.self_attn.fused(hidden_states, cache, buffer, self.input_layernorm, lora)
         else:
@@ -454,7 +484,8 @@ class ExLlama:
         self.buffers = []
         for dev in cfg.device_map.get_layers_devs():
             b = {
-                "temp_state": torch.zeros((cfg.max_input_len, cfg.intermediate_size), dtype=torch.float16, device=dev),
+                "temp_state": torch.zeros((cfg.max_input_len, cfg.intermediate_size if cfg.tp is None else cfg.tp.plan.inter_full),
+                                          dtype=torch.float16, device=dev),
                 "temp_mlp": torch.zeros((max(cfg.fused_mlp_thd, 1) * 2, cfg.intermediate_size), dtype=torch.float16, device=dev),
                 "temp_zeros_float": torch.zeros((1, 65536), dtype=torch.float32, device=dev),
                 "temp_dq": torch.zeros((1, 64), dtype=torch.float16, device=dev),
@@ -686,6 +717,8 @@ class ExLlama:
         if cache.max_seq_len > cfg.max_seq_len:
             raise RuntimeError("cache is longer than the RoPE tables (config.max_seq_len)")
         stages = self._decode_stages()
+        if cfg.tp is not None and any(l.self_attn.o_gather or l.mlp.down_gather for l in self.layers):
+            raise RuntimeError("tensor parallel: act-order o_proj / down_proj shards (gather mode) run on the op-by-op path only")
         if first_stage and str(cfg.device_map.embed_tokens) != stages[0]["dev"]:
             raise RuntimeError("the native decode executor needs the embedding table on the first layer's device")
         if last_stage and not (str(cfg.device_map.norm) == str(cfg.device_map.lm_head) == stages[-1]["dev"]):
@@ -708,6 +741,8 @@ class ExLlama:
                                                       self.lm_head_weight.data_ptr() if head else None, sin.data_ptr(), cos.data_ptr(),
                                                       C.byref(handle)), "decoder_create")
                 cuda_ext.check(lib.exl_decoder_set_hidden(handle, sg["hid"].data_ptr()), "decoder_set_hidden")
+                if cfg.tp is not None:
+                    cuda_ext.check(lib.exl_decoder_set_tp(handle, int(cfg.tp.rank == 0)), "decoder_set_tp")
                 for j, i in enumerate(sg["layers"]):
                     layer = self.layers[i]
                     a, m = layer.self_attn, layer.mlp
@@ -744,14 +779,24 @@ class ExLlama:
                 if st["graphs"] and limit <= st["graphs"][-1][0]:
                     continue
                 per_stage = []
-                for k, sg in enumerate(stages):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.device(sg["tdev"]), torch.cuda.graph(g):    # capture only records: nothing runs at this position
-                        self._stage_launch(st, k, advance=1)
-                    per_stage.append(g)
+                try:
+                    for k, sg in enumerate(stages):
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.device(sg["tdev"]), torch.cuda.graph(g):    # capture only records: nothing runs at this position
+                            self._stage_launch(st, k, advance=1)
+                        per_stage.append(g)
+                except Exception as e:                            # noqa: BLE001
+                    if cfg.tp is None:
+                        raise
+                    # a tensor-parallel step contains the process group's collectives: if this backend cannot be captured,
+                    # the pieces run as eager launches (same results, more host time per token)
+                    import warnings
+                    warnings.warn(f"tensor parallel: hipGraph capture of the token step failed ({e}); decoding with eager launches")
+                    st["graphs"], st["bucket_splits"] = [], []
+                    break
                 st["graphs"].append((limit, per_stage))
                 st["bucket_splits"].append(ns)
-            st["graph"] = st["graphs"][-1][1]
+            st["graph"] = st["graphs"][-1][1] if st["graphs"] else None
             self._set_positions(st, start)
 
     DECODE_BUCKETS = ((1, 160), (4, 640), (0, None))                 # (KV splits, last context served); 0 = the decoder's maximum
@@ -776,6 +821,22 @@ class ExLlama:
     def _stage_launch(self, st, k, advance):
         sg = st["stages"][k]
         last = k == len(st["stages"]) - 1
+        tp = self.config.tp
+        if tp is not None:
+            # one rank's shard of a tensor-parallel model: the step in pieces, the residual stream all-reduced after each half
+            # layer (partial o_proj / down_proj sums; rank 0 carries the incoming residual: exl_decoder_set_tp)
+            tok = st["tok"].data_ptr() if (k == 0 and st["has_embed"]) else None
+            logits = st["logits"].data_ptr() if (last and st["has_head"]) else None
+            with cuda_ext._Guard(sg["tdev"]):
+                stream = torch.cuda.current_stream(sg["tdev"]).cuda_stream
+                for j in range(len(sg["layers"])):
+                    for part in (0, 1):
+                        cuda_ext.check(ext._lib.exl_decoder_step_part(sg["handle"], j, part, tok, sg["pos"].data_ptr(), logits, int(advance), stream),
+                                       "decoder_step_part")
+                        tp.all_reduce(sg["hid"])
+                cuda_ext.check(ext._lib.exl_decoder_step_part(sg["handle"], 0, 2, tok, sg["pos"].data_ptr(), logits, int(advance), stream),
+                               "decoder_step_part")
+            return
         with cuda_ext._Guard(sg["tdev"]):
             cuda_ext.check(ext._lib.exl_decoder_step(sg["handle"], st["tok"].data_ptr() if (k == 0 and st["has_embed"]) else None,
                                                      sg["pos"].data_ptr(), st["logits"].data_ptr() if (last and st["has_head"]) else None,
@@ -853,6 +914,8 @@ class ExLlama:
         st = self._decoder
         if st is None or st["cache"] is not cache or st["graph"] is None:
             raise RuntimeError("generate_greedy needs enable_decode_graph(cache) with graph replay")
+        if self.config.tp is not None:
+            raise RuntimeError("generate_greedy / generate_sample: not available on a tensor-parallel shard (use forward())")
         if len(st["stages"]) != 1 or not (st["has_embed"] and st["has_head"]):
             raise RuntimeError("generate_greedy needs the whole model in one executor stage (one device)")
         self._check_cache_storage(st, cache)
@@ -903,6 +966,8 @@ class ExLlama:
         st = self._decoder
         if st is None or st["cache"] is not cache or st["graph"] is None:
             raise RuntimeError("generate_sample needs enable_decode_graph(cache) with graph replay")
+        if self.config.tp is not None:
+            raise RuntimeError("generate_greedy / generate_sample: not available on a tensor-parallel shard (use forward())")
         if len(st["stages"]) != 1 or not (st["has_embed"] and st["has_head"]):
             raise RuntimeError("generate_sample needs the whole model in one executor stage (one device)")
         self._check_cache_storage(st, cache)

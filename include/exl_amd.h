@@ -267,6 +267,17 @@ int exl_decoder_set_hidden(void* decoder, void* hidden_dev);
  * loads in flight per lane), [2] NP (passes), [3] G16 (group size % 128 == 0), [4] PNORM, [5] EMODE, [6] NV (8-half
  * activation vectors per thread), [7] grid, [8] dynamic LDS bytes, [9] activation images; attention / merge: [1] KV splits. */
 int exl_decoder_plan(void* decoder, int cls, int* out10);
+/* Tensor parallelism (not in the reference: doc/TODO.md:19; exllama_amd/tp.py): a decoder built from ONE rank's shard --
+ * heads * head_dim < hidden (its own heads), its own intermediate columns, the full residual stream.  exl_decoder_step_part
+ * runs a token step in pieces so that the caller can all-reduce the residual stream (exl_decoder_hidden) between them:
+ * part 0 = attention half of `layer` (RMSNorm + q/k/v (+ embedding lookup in layer 0 of a first stage), attention, o_proj),
+ * part 1 = MLP half (RMSNorm + gate/up + SiLU*mul, down_proj), part 2 = final norm + head (+ position advance).  After parts
+ * 0 and 1 the residual stream of a rank holds its PARTIAL sum, plus the incoming residual on the one rank for which
+ * exl_decoder_set_tp(decoder, 1) was called (the default; call it with 0 on the others): the sum over ranks is the new
+ * residual stream.  Every call only enqueues on `stream` (capturable together with the collectives). */
+int exl_decoder_step_part(void* decoder, int layer, int part, const int64_t* token_dev, int32_t* pos_dev, float* logits_out,
+                          int advance, void* stream);
+int exl_decoder_set_tp(void* decoder, int residual_owner);
 int exl_decoder_free(void* decoder);
 
 /* ---- repetition penalty, HOST memory, fp32 (reference: exllama_ext.cpp:684-741, cpu_func/rep_penalty.cpp) */

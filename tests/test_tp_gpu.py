@@ -1,0 +1,85 @@
+"""Tensor parallelism (exllama_amd/tp.py): W rank models built from the shards of ONE checkpoint must
+reproduce the unsharded model -- prompt pass (op-by-op path with the collectives) and single-token decode (native executor in
+pieces, exl_decoder_step_part, residual stream all-reduced after every half layer).  The ranks are threads on this one GPU
+(tests/tp_emul.py); the collectives over RCCL are the same two calls on torch.distributed."""
+
+import numpy as np
+import pytest
+import torch
+
+from exllama_amd import synth, tp
+from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
+
+from tp_emul import LocalGroup
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _build(cfg_dict, tensors, tpobj=None, max_seq=256):
+    cfg = ExLlamaConfig(dict(cfg_dict))
+    cfg.max_seq_len = max_seq
+    cfg.max_input_len = max_seq
+    cfg.tp = tpobj
+    model = ExLlama(cfg, tensors={k: v.clone() for k, v in tensors.items()})
+    return model, ExLlamaCache(model)
+
+
+CASES = [
+    # dims preset, layers, groupsize, act_order, world
+    ("tiny_hd128", 3, 128, False, 2),          # 4 heads, intermediate 1408 = 11 blocks of 128: an uneven 6 + 5 split
+    ("tiny_hd128", 2, 128, False, 4),          # one head per rank
+    ("tiny_hd128_gqa", 2, 64, False, 2),       # GQA: one kv head per rank; groupsize 64
+    ("tiny_hd128", 2, 128, True, 2),           # act-order: o_proj / down_proj in gather mode (op path only)
+    ("7b", 2, 128, False, 2),                  # real shapes: o_proj K = 2048, gate/up N = down K = 5504
+]
+
+
+@pytest.mark.parametrize("preset,layers,gs,act,world", CASES)
+def test_tensor_parallel_ranks_reproduce_the_unsharded_model(preset, layers, gs, act, world):
+    dims = synth.PRESETS[preset]
+    cfg_dict = synth.config_dict(dims, num_layers=layers)
+    tensors = synth.make_checkpoint(dims, groupsize=gs, act_order=act, seed=11, num_layers=layers)
+    gen = torch.Generator().manual_seed(5)
+    prompt = torch.randint(3, dims.vocab_size, (1, 37), generator=gen)
+    steps = 6
+    # the unsharded model first: its greedy tokens drive every rank (teacher forcing: no divergence through a near-tie)
+    full, fcache = _build(cfg_dict, tensors)
+    ref = [full.forward(prompt.to(DEV), fcache, last_id_only=False).float().cpu()]
+    full.enable_decode_graph(fcache, use_graph=False)
+    tokens = [ref[0][0, -1].argmax().view(1, 1)]
+    for _ in range(steps):
+        lg = full.forward(tokens[-1].to(DEV), fcache).float().cpu()
+        ref.append(lg)
+        tokens.append(lg[0, -1].argmax().view(1, 1))
+
+    group = LocalGroup(world)
+    keep = []
+
+    def rank_program(r):
+        def run():
+            local, plan = tp.shard_tensors(tensors, cfg_dict, r, world)
+            model, cache = _build(tp.shard_config_dict(cfg_dict, plan), local, tp.TensorParallel(plan, group.comm(r)))
+            keep.append((model, cache))                                  # (free_unmanaged releases EVERY handle of the process: once, at the end)
+            outs = [model.forward(prompt.to(DEV), cache, last_id_only=False).float().cpu()]
+            if not act:
+                model.enable_decode_graph(cache, use_graph=False)        # executor in pieces; act-order shards stay on the op path
+            for i in range(steps):
+                outs.append(model.forward(tokens[i].to(DEV), cache).float().cpu())
+            return outs
+        return run
+
+    rank_outs = group.run([rank_program(r) for r in range(world)])
+    full.free_unmanaged()
+
+    for r in range(world):
+        assert len(rank_outs[r]) == len(ref)
+        for a, b in zip(rank_outs[r], ref):
+            # same weights, same fp32 accumulation inside each matmul; the partial sums are rounded to fp16 before they are added
+            # (one extra rounding per rank and half layer)
+            scale = float(b.abs().max())
+            err = float((a - b).abs().max())
+            assert err <= 0.02 * scale + 1e-3, (r, err, scale)
+    for r in range(1, world):                                            # the replicas of the residual stream agree exactly
+        for a, b in zip(rank_outs[r], rank_outs[0]):
+            assert torch.equal(a, b)
