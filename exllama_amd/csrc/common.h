@@ -38,6 +38,20 @@ void exl_set_error(const char* fmt, ...);
     exl_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); return (int) _e; } } while (0)
 #define EXL_TRY(expr) do { int _r = (expr); if (_r != 0) return _r; } while (0)
 
+// More than 64 KiB of dynamic LDS is an opt-in per kernel and PER DEVICE (hipFuncSetAttribute acts on the current device's
+// copy of the function): `done` is the caller's static per-device flag array for that kernel.
+#ifdef __HIPCC__
+static inline int exl_lds_opt_in(const void* kfn, bool (&done)[EXL_MAX_DEVICES])
+{
+    int dev = 0;
+    EXL_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < EXL_MAX_DEVICES && done[dev]) return 0;
+    EXL_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (dev >= 0 && dev < EXL_MAX_DEVICES) done[dev] = true;
+    return 0;
+}
+#endif
+
 // ---- Q4 matrix handle (reference: exllama_ext/cuda_func/q4_matrix.cuh:8-46) ---------------------------
 struct Q4Matrix {
     uint32_t magic;

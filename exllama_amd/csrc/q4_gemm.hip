@@ -857,12 +857,6 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
     }
 }
 
-static int gw_opt_in(const void* kfn)
-{
-    EXL_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    return 0;
-}
-
 static int launch_gemm_t16w(const Q4Matrix* w, const f16* xin, int rows, f16* out, int no_zero, int gshift, hipStream_t s)
 {
     const int K = w->height, N = w->width;
@@ -870,8 +864,8 @@ static int launch_gemm_t16w(const Q4Matrix* w, const f16* xin, int rows, f16* ou
     const int ntiles = (N + GT_BN - 1) / GT_BN;
     const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
     const size_t smem = 3 * (size_t) 256 * 128 + 2 * GT_BTILE_BYTES;
-    static bool big = false;
-    if (!big) { EXL_TRY(gw_opt_in((const void*) q4_gemm_t16w_kernel<0>)); big = true; }
+    static bool big[EXL_MAX_DEVICES] = {};
+    EXL_TRY(exl_lds_opt_in((const void*) q4_gemm_t16w_kernel<0>, big));
     GwQkv none = {};
     hipLaunchKernelGGL(q4_gemm_t16w_kernel<0>, dim3(grid), dim3((GW_CONS + GW_PROD) * 64), smem, s, xin, (const uint4*) w->qweight, w->qzeros,
                        w->scales, out, rows, K, N, gshift, no_zero, mtiles, ntiles, none);
@@ -910,8 +904,8 @@ int launch_q4_qkv_rope_cache(const Q4Matrix* wq, const Q4Matrix* wk, const Q4Mat
     const int mtiles = (rows + 255) / 256;
     const int grid = 8 * ((tiles + 7) / 8) * mtiles;
     const size_t smem = 3 * (size_t) 256 * 128 + 2 * GT_BTILE_BYTES;
-    static bool big = false;
-    if (!big) { EXL_TRY(gw_opt_in((const void*) q4_gemm_t16w_kernel<1>)); big = true; }
+    static bool big[EXL_MAX_DEVICES] = {};
+    EXL_TRY(exl_lds_opt_in((const void*) q4_gemm_t16w_kernel<1>, big));
     hipLaunchKernelGGL(q4_gemm_t16w_kernel<1>, dim3(grid), dim3((GW_CONS + GW_PROD) * 64), smem, s, x, (const uint4*) nullptr, (const uint32_t*) nullptr,
                        (const f16*) nullptr, (f16*) nullptr, rows, K, 0, gshift, 0, mtiles, tiles, e);
     EXL_LAUNCH_CHECK();
@@ -1129,12 +1123,9 @@ int launch_q4_gemm_dual(const Q4Matrix* w1, const Q4Matrix* w2, const f16* x, in
     const int ntiles = (N + GT_BN - 1) / GT_BN;
     const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
     const size_t smem = 2 * (size_t) 256 * 128 + 4 * GT_BTILE_BYTES;
-    static bool big = false;
-    if (!big) {
-        EXL_HIP(hipFuncSetAttribute((const void*) q4_gemm_t16d_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        EXL_HIP(hipFuncSetAttribute((const void*) q4_gemm_t16d_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        big = true;
-    }
+    static bool big_silu[EXL_MAX_DEVICES] = {}, big_pair[EXL_MAX_DEVICES] = {};
+    EXL_TRY(exl_lds_opt_in((const void*) q4_gemm_t16d_kernel<true>, big_silu));
+    EXL_TRY(exl_lds_opt_in((const void*) q4_gemm_t16d_kernel<false>, big_pair));
 #define GD_ARGS x, (const uint4*) w1->qweight, w1->qzeros, w1->scales, (const uint4*) w2->qweight, w2->qzeros, w2->scales, out1, out2, \
                 rows, K, N, gshift, w1->groupsize, mtiles, ntiles
     if (silu) hipLaunchKernelGGL(q4_gemm_t16d_kernel<true>, dim3(grid), dim3(512), smem, s, GD_ARGS);
@@ -1154,11 +1145,8 @@ static int launch_gemm_t16m(const Q4Matrix* w, const f16* xin, int rows, f16* ou
     const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
     const size_t smem = 3 * (size_t) TBM * 128 + 2 * GT_BTILE_BYTES;
     auto kfn = q4_gemm_t16m_kernel<WAVES_M, WAVES_N, TM, TN>;
-    static bool big = false;
-    if (smem > 64 * 1024 && !big) {
-        EXL_HIP(hipFuncSetAttribute((const void*) kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        big = true;
-    }
+    static bool big[EXL_MAX_DEVICES] = {};
+    if (smem > 64 * 1024) EXL_TRY(exl_lds_opt_in((const void*) kfn, big));
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(WAVES_M * WAVES_N * 64), smem, s, xin, (const uint4*) w->qweight, w->qzeros,
                        w->scales, out, rows, K, N, gshift, w->groupsize, no_zero, mtiles, ntiles);
     EXL_LAUNCH_CHECK();

@@ -223,15 +223,8 @@ static int launch_t16s_cfg(const T16Matrix& m, const f16* x, int rows, f16* out,
     const size_t slab = (size_t) MT * 4096, red = (size_t) MT * CT * 1024;
     const size_t smem = GS_WAVES * (slab > red ? slab : red);
     auto kfn = q4_gemm_t16s_kernel<MT, CT>;
-    if (smem > 64 * 1024) {                                                   // more than 64 KiB of dynamic LDS is a per-device opt-in
-        static bool big[EXL_MAX_DEVICES] = {};
-        int dev = 0;
-        EXL_HIP(hipGetDevice(&dev));
-        if (dev >= 0 && dev < EXL_MAX_DEVICES && !big[dev]) {
-            EXL_HIP(hipFuncSetAttribute((const void*) kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            big[dev] = true;
-        }
-    }
+    static bool big[EXL_MAX_DEVICES] = {};
+    if (smem > 64 * 1024) EXL_TRY(exl_lds_opt_in((const void*) kfn, big));
     hipLaunchKernelGGL(kfn, dim3((unsigned) (nrg * ncg)), dim3(GS_WAVES * 64), smem, s, m, x, out, rows, no_zero, rbw, nrg, ncg);
     EXL_LAUNCH_CHECK();
     return 0;
