@@ -82,3 +82,58 @@ def test_reference_model_py_runs_on_the_shim(ref_model_module, tmp_path, name, g
         assert np.abs(got - want).max() <= 2e-2 * scale, (np.abs(got - want).max(), scale)
     top2 = np.sort(c_step[0, -1])[-2:]
     assert int(np.argmax(r_step[0, -1])) == int(np.argmax(c_step[0, -1])) or top2[1] - top2[0] < 4e-2 * scale
+
+
+def test_reference_generator_py_on_the_shim_picks_the_device_samplers_tokens(ref_model_module, tmp_path):
+    """The reference's UNMODIFIED generator.py (ExLlamaGenerator.gen_begin / gen_single_token: forward, repetition penalty through
+    cuda_ext.ext_apply_rep_penalty_mask_cpu, BOS ban, sample; generator.py:178-186, :344-381) driving the reference's model.py on
+    this repository's shim, against this repository's own path for the same job: ExLlama.generate_sample, the decode kernels and
+    the sampler kernel replayed as one graph per token.  top_k = 1 makes the draw deterministic (one candidate survives, so
+    torch.multinomial and the inverse-CDF draw agree); everything before the draw -- penalty window, ban, temperature -- is live."""
+    ref = ref_model_module
+    sys.modules.pop("generator", None)
+    sys.modules.pop("lora", None)
+    gen_mod = importlib.import_module("generator")
+    assert os.path.samefile(os.path.dirname(gen_mod.__file__), REFPY)
+    from exllama_amd import _lib
+    from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
+
+    dims = synth.PRESETS["tiny_hd128"]
+    cfg_path, st_path = synth.save_checkpoint(str(tmp_path), dims, groupsize=128, act_order=False, seed=31, zeros="rand")
+    tensors = synth.make_checkpoint(dims, groupsize=128, act_order=False, seed=31, device="cpu", zeros="rand")
+    prompt = torch.randint(3, dims.vocab_size, (1, 40), generator=torch.Generator().manual_seed(12))
+    n = 12
+
+    # ---- reference generator + reference model, untouched
+    rcfg = ref.ExLlamaConfig(cfg_path)
+    rcfg.model_path = st_path
+    rcfg.max_seq_len = 128
+    rmodel = ref.ExLlama(rcfg)
+    rcache = ref.ExLlamaCache(rmodel)
+
+    class _Tok:                                                       # the three attributes gen_single_token reads (generator.py:355)
+        bos_token_id, eos_token_id, pad_token_id = 1, 2, 0
+    g = gen_mod.ExLlamaGenerator(rmodel, _Tok(), rcache)
+    g.settings.top_k = 1
+    g.settings.top_p = 0.0
+    g.settings.temperature = 0.8
+    g.settings.token_repetition_penalty_max = 1.3
+    g.settings.token_repetition_penalty_sustain = 16
+    g.settings.token_repetition_penalty_decay = 8
+    g.gen_begin(prompt.clone())
+    r_tokens = [int(g.gen_single_token()) for _ in range(n)]
+    assert g.sequence.shape[-1] == 40 + n and rcache.current_seq_len == 40 + n - 1
+    rmodel.free_unmanaged()
+
+    # ---- this repository: prompt pass, then decode + sampler inside the per-token graph
+    cfg = ExLlamaConfig(synth.config_dict(dims))
+    cfg.max_seq_len = 128
+    model = ExLlama(cfg, tensors=tensors)
+    cache = ExLlamaCache(model)
+    model.forward(prompt[:, :-1].to("cuda:0"), cache, preprocess_only=True)
+    model.enable_decode_graph(cache)
+    settings = _lib.ExlSampler(temperature=0.8, top_k=1, top_p=0.0, rep_penalty_max=1.3, rep_sustain=16, rep_decay=8, banned_token=1)
+    ours = model.generate_sample(prompt.to("cuda:0"), cache, n, settings=settings).cpu().tolist()
+    model.free_unmanaged()
+    assert ours == r_tokens, (ours, r_tokens)
+    assert len(set(r_tokens)) > 1                                     # (not a degenerate constant stream)
