@@ -186,7 +186,7 @@ __device__ __forceinline__ f16 silu_mul_f16(f16 x, f16 y)
 // (loads return in order).
 // Phase attribution (probe builds only, scripts/probe_attn.sh): cycles since block start at 6 points, per kernel class.
 #ifdef EXL_ATTN_PROBE
-__device__ unsigned long long g_stream_probe[8 * 512 * 8];          // [class = PNORM * 2 + (EMODE == 2 ? 1 : EMODE)][block][point]
+__device__ unsigned long long g_stream_probe[8 * 512 * 12];         // [class = PNORM * 2 + (EMODE == 2 ? 1 : EMODE)][block][point]
 #define SP_CLK(i) sp_t[i] = __builtin_readcyclecounter()
 #else
 #define SP_CLK(i) do { } while (0)
@@ -200,7 +200,7 @@ template <int U, int NP, bool G16, int PNORM, int EMODE, int NV>
 __global__ __launch_bounds__(DEC_THREADS, DEC_MIN_WAVES(U, NP, G16, PNORM, EMODE)) void dec_stream_kernel(const DecGemvArgs a)
 {
 #ifdef EXL_ATTN_PROBE
-    unsigned long long sp_t[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long sp_t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long sp_t0 = __builtin_readcyclecounter();
 #endif
     constexpr int NSLOT = G16 ? (U * NP + 3) / 4 : 1;
@@ -306,6 +306,7 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_MIN_WAVES(U, NP, G16, PNORM, EMODE
             if constexpr (PNORM == 1) wraw[i] = *(const uint4*) (a_norm_w + ci * 8);
         }
     }
+    SP_CLK(6);                                                       // activation / split loads issued
     // ---- 2. first unit's weight stream ----------------------------------------------------------------------
     uint4 wv0[U], wv1[U];
     uint32_t ep0[U], ep1[U];
@@ -317,10 +318,12 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_MIN_WAVES(U, NP, G16, PNORM, EMODE
     describe(0, miA, tileA);
     mA = dec_pick(M0, M1, M2, miA); mB = mA;
     uA = dec_unit(mA, tileA, rb_lo, rb_hi);
+    SP_CLK(7);                                                       // first unit described
     // A/B (EXL_DEC_X_FIRST=1): wait for the activation to land before the weight stream starts.  Measured on 7B: slower
     // (599 / 712 vs 619 / 731 tokens/s worst / best case), so the default issues the first weight batch right away.
     if (!early_w) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     dec_unit_issue<U, G16>(mA, uA, 0, lane, wv0, ep0);               // addresses: scalar arithmetic + one VALU
+    SP_CLK(8);                                                       // first weight batch issued (entries / residual loads follow)
     if constexpr (G16) { if (abl < 3) dec_unit_entries<NSLOT>(mA, uA, lane, entA); }
     if constexpr (EMODE == 1) { if (tid < 16) resA = (float) a.res_in[tileA * 16 + tid]; }
 
@@ -470,12 +473,13 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_MIN_WAVES(U, NP, G16, PNORM, EMODE
     SP_CLK(4);                                                       // all units done
 #ifdef EXL_ATTN_PROBE
     if (tid == 0 && b < 512) {
-        unsigned long long* dst = g_stream_probe + ((size_t) (PNORM * 2 + (EMODE == 2 ? 1 : EMODE)) * 512 + b) * 8;
+        unsigned long long* dst = g_stream_probe + ((size_t) (PNORM * 2 + (EMODE == 2 ? 1 : EMODE)) * 512 + b) * 12;
 #pragma unroll
         for (int q = 0; q < 5; ++q) dst[q] = sp_t[q] - sp_t0;
         dst[6] = sp_t[5] - sp_t0;
         dst[5] = (unsigned long long) n_my;
         dst[7] = 1;
+        dst[8] = sp_t[6] - sp_t0; dst[9] = sp_t[7] - sp_t0; dst[10] = sp_t[8] - sp_t0; dst[11] = 0;
     }
 #endif
 #undef DEC_UNIT_BODY
@@ -718,13 +722,13 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(const f16* __restrict
 #endif
 }
 #ifdef EXL_ATTN_PROBE
-extern "C" int exl_debug_stream_probe(int cls, unsigned long long* out8)     // sums over blocks; out8[7] = block count, out8[5] = units
+extern "C" int exl_debug_stream_probe(int cls, unsigned long long* out12)    // sums over blocks; out12[7] = block count, out12[5] = units
 {
-    static unsigned long long h[512 * 8];
+    static unsigned long long h[512 * 12];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stream_probe), sizeof(h), (size_t) cls * sizeof(h)) != hipSuccess) return -1;
-    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    for (int i = 0; i < 12; ++i) out12[i] = 0;
     for (int b = 0; b < 512; ++b)
-        for (int i = 0; i < 8; ++i) out8[i] += h[b * 8 + i];
+        for (int i = 0; i < 12; ++i) out12[i] += h[b * 12 + i];
     return 0;
 }
 extern "C" int exl_debug_attn_probe(unsigned long long* out8)         // sums over the blocks of the LAST launch; out8[7] = block count

@@ -12,7 +12,7 @@
 #include "exl_amd.h"
 #ifdef EXL_ATTN_PROBE
 extern "C" int exl_debug_attn_probe(unsigned long long* out8);
-extern "C" int exl_debug_stream_probe(int cls, unsigned long long* out8);
+extern "C" int exl_debug_stream_probe(int cls, unsigned long long* out12);
 #endif
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
@@ -120,7 +120,7 @@ int main(int argc, char** argv)
         printf("ctx %5d  graph replay: %.4f ms/token = %.1f tokens/s (x%d layers)\n", p0, tms / reps, 1e3 * reps / tms, L);
 #ifdef EXL_ATTN_PROBE
         {
-            unsigned long long pr[8];
+            unsigned long long pr[12];
             if (exl_debug_attn_probe(pr) == 0 && pr[7]) {
                 static const char* ph[7] = {"pos known", "loads issued", "rope done", "scores done", "softmax done", "PV done", "end"};
                 printf("ctx %5d  attention kernel, mean cycles since block start over %llu blocks:", p0, pr[7]);
@@ -130,8 +130,8 @@ int main(int argc, char** argv)
             static const char* cn[8] = {"-", "plain vector + residual (the LAST launched: down)", "qkv", "gate_up", "-", "-", "-", "o_proj + split merge"};
             for (int cls = 0; cls < 8; ++cls) {
                 if (exl_debug_stream_probe(cls, pr) != 0 || !pr[7]) continue;
-                printf("ctx %5d  stream kernel class %d [%s], mean cycles over %llu blocks (%.2f units/block): args arrived %.0f  loads issued %.0f  image staged %.0f  unit 0 consumed %.0f  unit 0 reduced %.0f  all units done %.0f\n",
-                       p0, cls, cn[cls], pr[7], (double) pr[5] / pr[7], (double) pr[6] / pr[7], (double) pr[0] / pr[7], (double) pr[1] / pr[7], (double) pr[2] / pr[7], (double) pr[3] / pr[7], (double) pr[4] / pr[7]);
+                printf("ctx %5d  stream kernel class %d [%s], mean cycles over %llu blocks (%.2f units/block): args arrived %.0f  activation loads issued %.0f  unit described %.0f  weights issued %.0f  entries issued %.0f  image staged %.0f  unit 0 consumed %.0f  unit 0 reduced %.0f  all units done %.0f\n",
+                       p0, cls, cn[cls], pr[7], (double) pr[5] / pr[7], (double) pr[6] / pr[7], (double) pr[8] / pr[7], (double) pr[9] / pr[7], (double) pr[10] / pr[7], (double) pr[0] / pr[7], (double) pr[1] / pr[7], (double) pr[2] / pr[7], (double) pr[3] / pr[7], (double) pr[4] / pr[7]);
             }
         }
 #endif
