@@ -681,7 +681,10 @@ class ExLlama:
         if cfg.device_map.lm_head == "cpu":
             hidden = hidden.float()
         hidden = _move_tensor(hidden, cfg.device_map.lm_head, "hidden_states", cfg)
-        return torch.matmul(hidden, self.lm_head_weight.t()).float()
+        logits = torch.matmul(hidden, self.lm_head_weight.t()).float()
+        if cfg.tp is not None and self.lm_head_weight.shape[0] != cfg.vocab_size:      # this rank's vocabulary rows (tp.py): gather the rest
+            logits = cfg.tp.all_gather_last(logits, cfg.tp.plan.vocab_sizes)
+        return logits
 
     # ---- native decode executor + hipGraph ---------------------------------------------------------------
     def _decode_stages(self):
@@ -736,7 +739,7 @@ class ExLlama:
             with cuda_ext._Guard(dev):
                 cuda_ext.check(lib.exl_decoder_create(dev.index, len(sg["layers"]), cfg.hidden_size, cfg.intermediate_size,
                                                       cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim,
-                                                      cfg.vocab_size, cache.max_seq_len, float(cfg.rms_norm_eps), emb,
+                                                      self.lm_head_weight.shape[0], cache.max_seq_len, float(cfg.rms_norm_eps), emb,
                                                       self.norm.weight.data_ptr() if head else None,
                                                       self.lm_head_weight.data_ptr() if head else None, sin.data_ptr(), cos.data_ptr(),
                                                       C.byref(handle)), "decoder_create")
@@ -759,6 +762,9 @@ class ExLlama:
             "has_embed": bool(first_stage), "has_head": bool(last_stage),
             "tok": torch.zeros((1, 1), dtype=torch.int64, device=d0),
             "logits": torch.zeros((1, 1, cfg.vocab_size), dtype=torch.float32, device=dl),
+            # tensor parallel with a split lm_head: the head kernel writes this rank's rows here, all-gathered into "logits"
+            "logits_local": (torch.zeros((1, 1, self.lm_head_weight.shape[0]), dtype=torch.float32, device=dl)
+                             if self.lm_head_weight.shape[0] != cfg.vocab_size else None),
             "pos": stages[0]["pos"], "dev_pos": -1,
             "kv_ptrs": [(k.data_ptr(), v.data_ptr()) for k, v in zip(cache.key_states, cache.value_states)],
         }
@@ -826,7 +832,8 @@ class ExLlama:
             # one rank's shard of a tensor-parallel model: the step in pieces, the residual stream all-reduced after each half
             # layer (partial o_proj / down_proj sums; rank 0 carries the incoming residual: exl_decoder_set_tp)
             tok = st["tok"].data_ptr() if (k == 0 and st["has_embed"]) else None
-            logits = st["logits"].data_ptr() if (last and st["has_head"]) else None
+            lbuf = st["logits_local"] if st["logits_local"] is not None else st["logits"]
+            logits = lbuf.data_ptr() if (last and st["has_head"]) else None
             with cuda_ext._Guard(sg["tdev"]):
                 stream = torch.cuda.current_stream(sg["tdev"]).cuda_stream
                 for j in range(len(sg["layers"])):
@@ -836,6 +843,8 @@ class ExLlama:
                         tp.all_reduce(sg["hid"])
                 cuda_ext.check(ext._lib.exl_decoder_step_part(sg["handle"], 0, 2, tok, sg["pos"].data_ptr(), logits, int(advance), stream),
                                "decoder_step_part")
+                if logits is not None and st["logits_local"] is not None:
+                    tp.all_gather_into(st["logits"].view(-1), st["logits_local"].view(-1), tp.plan.vocab_sizes)
             return
         with cuda_ext._Guard(sg["tdev"]):
             cuda_ext.check(ext._lib.exl_decoder_step(sg["handle"], st["tok"].data_ptr() if (k == 0 and st["has_embed"]) else None,

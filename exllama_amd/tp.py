@@ -13,7 +13,7 @@ Partitioning (Megatron-style, restated for GPTQ tensors):
     features, a row range holds ragged pieces of many groups.  They are cut by output columns instead; the rank then needs the
     FULL input (all-gather of the attention output / activation) and the outputs are all-gathered ("gather mode": two
     all-gathers instead of one all-reduce, op-by-op path only).
-  * embedding, norms and lm_head are replicated (lm_head is 0.26 of 3.5 GB at 7B; splitting its rows is the next step).
+  * lm_head is cut by vocabulary rows (the logits are all-gathered); embedding (one row read per token) and norms are replicated.
 The KV cache of a rank holds its own kv heads only.
 
 At batch 1 the win is HBM streaming time: every rank reads 1/W of the weights per token.  The price is two collectives per
@@ -67,6 +67,11 @@ class TPPlan:
         self.hidden_sizes = [hi - lo for lo, hi in self.hidden_cols_all]
         self.inter_sizes = [hi - lo for lo, hi in self.inter_all]
         self.inter_full = inter
+        vocab = config_dict["vocab_size"]
+        vunit = 32 if vocab % 32 == 0 and vocab // 32 >= world else 1       # lm_head rows per rank (the head kernel works on 32-row blocks)
+        self.vocab_all = [(lo * vunit, hi * vunit) for lo, hi in _even_bounds(vocab // vunit, world)]
+        self.vocab = self.vocab_all[rank]
+        self.vocab_sizes = [hi - lo for lo, hi in self.vocab_all]
 
 
 def _is_act_order(g_idx, groupsize):
@@ -140,7 +145,10 @@ def shard_tensors(tensors, config_dict, rank, world):
                 done.add(p + leaf + suffix)
     for k, v in tensors.items():
         if k not in done:
-            out[k] = v                                               # embedding, norms, lm_head: replicated
+            out[k] = v                                               # embedding, norms: replicated
+    # lm_head: this rank's vocabulary rows (0.26 of 3.6 GB per token at 7B, more than the layers' share at 8 ranks); the logits
+    # are all-gathered (ExLlama.head / the executor's last piece)
+    out["lm_head.weight"] = tensors["lm_head.weight"][plan.vocab[0]:plan.vocab[1]].contiguous()
     return out, plan
 
 
@@ -172,6 +180,20 @@ class TensorParallel:
             else:
                 self.dist.all_reduce(t, group=self.group)
         return t
+
+    def all_gather_into(self, out, t, sizes):
+        """out (1-D, sum(sizes) elements) = concatenation of the ranks' 1-D tensors t (sizes[r] elements each); capturable."""
+        if self.world == 1 and not self.always:
+            out.copy_(t)
+            return out
+        if len(set(sizes)) == 1 and hasattr(self.dist, "all_gather_into_tensor"):
+            if self.group is None:
+                self.dist.all_gather_into_tensor(out, t.contiguous())
+            else:
+                self.dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+            return out
+        out.copy_(self.all_gather_last(t, sizes))
+        return out
 
     def all_gather_last(self, t, sizes=None):
         """Concatenate the ranks' tensors along the last dimension (equal sizes unless `sizes` lists them)."""

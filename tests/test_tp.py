@@ -47,8 +47,9 @@ def test_shards_tile_the_full_matrices(preset, gs, act, world):
         axis = 1 if act else 0                                            # act-order: gather mode = cut by output columns
         assert np.array_equal(np.concatenate([_w(s, p + name) for s, _ in shards], axis=axis), full), name
     # replicated tensors are the same objects; the local config describes the local shapes
+    assert torch.equal(torch.cat([s["lm_head.weight"] for s, _ in shards], dim=0), t["lm_head.weight"])     # vocabulary rows
     for s, pl in shards:
-        assert s["lm_head.weight"] is t["lm_head.weight"]
+        assert s["model.embed_tokens.weight"] is t["model.embed_tokens.weight"]
         c = tp.shard_config_dict(cfg, pl)
         assert c["hidden_size"] == dims.hidden_size and c["head_dim"] == hd
         assert s[p + "self_attn.q_proj.qweight"].shape[1] == c["num_attention_heads"] * hd
