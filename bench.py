@@ -242,6 +242,28 @@ def tensor_parallel_main(args, dims, L, S, G, rank, world, dev, dist):
         dist.destroy_process_group()
 
 
+def device_state():
+    """Best effort, after the timed region: what the management interface says about this box (the same binaries measured 600-650
+    tokens/s on 7B and a wider spread on the big models across the boxes of one pool: the power cap and the clocks a box
+    grants are the first things to compare).  Never fails the run."""
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        out = subprocess.run([exe, "-d", "0", "--showmaxpower", "--showpower", "--showclocks", "--showperflevel", "--showmemuse", "--json"],
+                             capture_output=True, text=True, timeout=20).stdout
+        card = next(iter(json.loads(out).values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(t in kl for t in ("max graphics package power", "package power", "sclk", "mclk", "fclk", "performance level", "memory")):
+                keep[k] = v
+        keep["note"] = "sampled once after the timed steps (idle clocks; the cap and the levels are the comparable part)"
+        return keep
+    except Exception as e:                                            # noqa: BLE001
+        return {"unavailable": str(e)[:120]}
+
+
 def reduce_over_ranks(local_values, dist, device):
     """The contract's timing rule: every rank contributes its own timings, the job's timing is the MAX over ranks.
     `dist` is torch.distributed (initialised) or None for a single process."""
@@ -385,6 +407,8 @@ def main():
     }
     if args.layers is not None:
         result["config"]["INVALID"] = "truncated model (--layers): not a benchmark result"
+    if rank == 0:
+        result["device_state"] = device_state()
 
     # ---- further protocol points, measured after the timed region (not part of `value`) -----------------------------
     # the reference's own `-p` lengths (test_benchmark_inference.py:157-180: S = max_seq_len - 128 = 1920 with -l 2048) and
