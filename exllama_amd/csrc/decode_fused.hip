@@ -130,10 +130,11 @@ __device__ __forceinline__ void dec_unit_issue(const T16Matrix& m, const DecUnit
 template <int U, bool G16, int NSLOT>
 __device__ __forceinline__ void dec_unit_consume(const DecUnit& u, int pass, int lane, const uint4 (&wv)[U],
                                                  const uint32_t (&ent)[NSLOT], const uint32_t (&entp)[U], const uint4* xrow,
-                                                 f32x4& c)
+                                                 f32x4& c, const uint4* zpad)
 {
     const uint32_t magic = t16_magic();
     const int col = lane & 15, rsub = lane >> 4;
+    const bool live = col == 4 * rsub;                                  // group sizes 32 / 64: the lane that carries A row 4 * k-group (gemv_t16.h)
 #pragma unroll
     for (int i = 0; i < U; ++i) {
         const int li = pass * U + i;
@@ -142,7 +143,8 @@ __device__ __forceinline__ void dec_unit_consume(const DecUnit& u, int pass, int
         uint32_t e;
         if constexpr (G16) e = (uint32_t) __shfl((int) ent[(li >> 2) < NSLOT ? (li >> 2) : 0], ((li & 3) << 4) | col, 64);
         else e = entp[i];
-        t16_rowblock<G16>(wv[i], e, magic, xrow + rbc * 16 + rsub * 4, c);
+        if constexpr (G16) t16_rowblock<true>(wv[i], e, magic, xrow + rbc * 16 + rsub * 4, c);
+        else t16_rowblock_groups(wv[i], e, magic, live ? xrow + rbc * 16 + rsub * 4 : zpad, c);
     }
 }
 // The (gathered) LDS image of the activation from its linear copy in LDS: packed row idx takes x[map[8 idx .. 8 idx + 7]]; the map
@@ -229,7 +231,9 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_MIN_WAVES(U, NP, G16, PNORM, EMODE
     const int RB = M0.RB;
     uint4* xs = (uint4*) smem;                                       // [xs_images][R]
     float* red = (float*) (smem + (size_t) a_images * R * 16);       // [2][DEC_WAVES][16] + [DEC_WAVES]
-    constexpr int RED_FLOATS = 2 * DEC_WAVES * 16 + DEC_WAVES;
+    constexpr int RED_FLOATS = 2 * DEC_WAVES * 16 + DEC_WAVES + 16;   // + 64 zero bytes: the A rows of the lanes that carry nothing (group sizes 32 / 64)
+    const uint4* zpad = (const uint4*) (red + 2 * DEC_WAVES * 16 + DEC_WAVES);
+    if (threadIdx.x < 16) red[2 * DEC_WAVES * 16 + DEC_WAVES + threadIdx.x] = 0.f;   // (read only after the image barrier)
     f16* xlin = (f16*) (smem + (size_t) a_images * R * 16 + RED_FLOATS * sizeof(float));   // [K], act-order only
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -445,10 +449,11 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_MIN_WAVES(U, NP, G16, PNORM, EMODE
                 dec_unit_issue<U, G16>(mN, uN, 0, lane, DEC_BUF((P ^ 1) * NP), DEC_EP((P ^ 1) * NP));                       \
             }                                                                                                               \
             if (abl) { _Pragma("unroll") for (int q = 0; q < U; ++q) c[0] += __builtin_bit_cast(float, DEC_BUF(P * NP + p)[q].x ^ DEC_BUF(P * NP + p)[q].w); } \
-            else if (uC.rb0 + p * U < uC.rb1) dec_unit_consume<U, G16, NSLOT>(uC, p, lane, DEC_BUF(P * NP + p), entC, DEC_EP(P * NP + p), xrow, c); \
+            else if (uC.rb0 + p * U < uC.rb1) dec_unit_consume<U, G16, NSLOT>(uC, p, lane, DEC_BUF(P * NP + p), entC, DEC_EP(P * NP + p), xrow, c, zpad); \
         }                                                                                                                   \
         if (i == 0) SP_CLK(2);                                                                                              \
         float* rp = red + P * DEC_WAVES * 16;                                                                               \
+        if constexpr (!G16) { c[0] += __shfl_xor(c[0], 16, 64); c[0] += __shfl_xor(c[0], 32, 64); }   /* the four k-groups of a column */ \
         if (lane < 16) rp[wave * 16 + lane] = c[0];                                                                         \
         __syncthreads();                                                                                                    \
         if (i == 0) SP_CLK(3);                                                                                              \
@@ -1208,7 +1213,7 @@ static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec,
     a.ablate = ablate;
     static const int x_first = getenv("EXL_DEC_X_FIRST") ? atoi(getenv("EXL_DEC_X_FIRST")) : 0;
     a.early_weights = !x_first;
-    const size_t smem = (size_t) a.xs_images * (K / 8) * 16 + (2 * DEC_WAVES * 16 + DEC_WAVES) * sizeof(float) + (any_map ? (size_t) K * 2 : 0);
+    const size_t smem = (size_t) a.xs_images * (K / 8) * 16 + (2 * DEC_WAVES * 16 + DEC_WAVES + 16) * sizeof(float) + (any_map ? (size_t) K * 2 : 0);
     EXL_REQUIRE(smem <= 160 * 1024, EXL_E_UNSUPPORTED, "decoder: activation stage (%zu bytes of LDS) exceeds the 160 KiB of a CU", smem);
     const int nv = (K / 8 + DEC_THREADS - 1) / DEC_THREADS;
     for (int i = 1; i < nmat; ++i)

@@ -98,6 +98,30 @@ __device__ __forceinline__ void t16_rowblock(const uint4& w, uint32_t e, uint32_
     }
 }
 
+// Group sizes 32 / 64 with ONE activation row (the decode executor): the four k-groups of a row-block belong to different GPTQ
+// groups, so their sums must stay apart until the scale is applied.  Instead of folding the scale into every weight (13 VALU
+// per 8 weights), the A operand carries the activation in FOUR MASKED rows: row 4 g holds the 8 x 4 values of k-group g and
+// zeros elsewhere (the caller points every other lane at a zero pad).  Then D[4 g][col] -- element 0 of the lane (col,
+// k-group g), the lane that loaded the weights and the scale of exactly that group -- is the EXACT-integer sum
+// sum_{k in group g} x_k (q_k - z): one fp32 multiply-add with the lane's own scale finishes it, as in the group-size-128 path
+// (9 VALU per 8 weights).  acc[0] of the four lanes of a column are partial sums over their k-groups: the caller adds them once
+// per tile (two shuffles).
+__device__ __forceinline__ void t16_rowblock_groups(const uint4& w, uint32_t e, uint32_t magic, const uint4* xr, f32x4& acc)
+{
+    const f16x2 c960 = {(f16) 960.f, (f16) 960.f};
+    const f16 sc = __builtin_bit_cast(f16, (uint16_t) (e & 0xFFFFu));
+    const f16 za = __builtin_bit_cast(f16, (uint16_t) (e >> 16));
+    const f16x2 zc0 = {za, za};
+    const f16x2 zc1 = zc0 + c960;
+    const uint4 x0 = xr[0], x1 = xr[1], x2 = xr[2], x3 = xr[3];
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x0), t16_dequant_exact(w.x, magic, zc0, zc1), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x1), t16_dequant_exact(w.y, magic, zc0, zc1), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x2), t16_dequant_exact(w.z, magic, zc0, zc1), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x3), t16_dequant_exact(w.w, magic, zc0, zc1), c, 0, 0, 0);
+    acc[0] = fmaf((float) sc, c[0], acc[0]);
+}
+
 struct T16Matrix {                  // device-visible view of a Q4Matrix in T16 layout
     const uint4* qw;                // [N/16][RB][64] pieces
     const uint32_t* qzeros;         // [G][N/8]           (GPTQ layout)
