@@ -1,7 +1,8 @@
 """Times exl_q4_matmul_dual (gate/up + SiLU*mul of the prompt pass) at the 7B shape, M = 2048: HIP events around `reps` launches."""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os as _os
+sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 from exllama_amd import synth
 from exllama_amd import cuda_ext as ce
 
