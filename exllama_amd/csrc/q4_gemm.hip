@@ -1106,6 +1106,231 @@ __global__ __launch_bounds__(512) void q4_gemm_t16d_kernel(const f16* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The dual kernel with the software pipeline of q4_gemm_t16m_kernel.  SQ counters of its predecessor above
+// (profiles/r02_pmc_dual_gemm.txt): matrix pipes busy 48 % of a launch, a wave 37 % of its life in s_waitcnt / s_barrier
+// and only 4 % of it waiting for LDS -- both waves of a SIMD walk the same phases (fragment reads -> 64 MFMAs -> wait ->
+// dequantise + store -> barrier) at the same time, so the matrix pipe idles through every wait, store and barrier.
+// Here a K step is cut into 8 groups of 8 MFMAs (one weight fragment pair x 4 activation fragments x 2 matrices); the
+// fragments of group g + 1 are requested before group g is issued, the activation DMA / weight loads of tile t + 2, the
+// wait for tile t + 1 and its dequantisation + LDS stores sit BETWEEN the groups, and the LAST group of tile t is held
+// back across the barrier: it runs while the first fragments of tile t + 1 are on their way.  Registers: 128 accumulators
+// + 56 fragment registers (two activation sets, three weight pairs) -- the full P / Q double set of the single-matrix
+// kernel (96) does not fit next to 128 accumulators.  3-slot activation ring + 2 x 2 weight tiles = 160 KiB of LDS.
+// Same values, same order of accumulation: bit-identical to q4_gemm_t16d_kernel.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool SILU>
+__global__ __launch_bounds__(512) void q4_gemm_t16d2_kernel(const f16* __restrict__ x, const uint4* __restrict__ qw1,
+                                                            const uint32_t* __restrict__ qz1, const f16* __restrict__ sc1,
+                                                            const uint4* __restrict__ qw2, const uint32_t* __restrict__ qz2,
+                                                            const f16* __restrict__ sc2, f16* __restrict__ out1,
+                                                            f16* __restrict__ out2, int M, int K, int N, int gshift,
+                                                            int groupsize, int mtiles, int ntiles)
+{
+    constexpr int TBM = 256;
+    constexpr int A_BYTES = TBM * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [3][A] then [2][B1 | B2]
+    unsigned char* const ldsB = lds + 3 * A_BYTES;
+
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int idx = b >> 3;
+    const int nl = idx / mtiles;
+    const int mt = idx - nl * mtiles;
+    const int nt = nl * 8 + xcd;
+    if (nt >= ntiles) return;
+    const int m0 = mt * TBM;
+    const int n0 = nt * GT_BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int RB = K >> 7;
+    const int nk = K / GT_BK;                                         // even, >= 2
+
+    // Every address is (uniform base, advanced per K step by scalar arithmetic) + (fixed 32-bit byte offset per lane): saddr-form
+    // loads, no 64-bit address registers (the register file is full: 128 accumulators + 56 fragment registers).
+    uint32_t a_voff[4];                                                // byte offsets from x (M * K * 2 < 2^32 checked on the host)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = wave * 4 + i;
+        const int row = c * 8 + (lane >> 3);
+        const int slot = lane & 7;
+        const int grow = min(m0 + row, M - 1);
+        a_voff[i] = ((uint32_t) grow * (uint32_t) K + ((slot ^ (row & 7)) << 3)) * 2u;
+    }
+    const uint32_t lds_a0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned char*) lds + (uint32_t) (wave * 4 * 1024);
+    auto stage_a2 = [&](int pair, int slot3, int k0) {                 // pieces 2 * pair and 2 * pair + 1; M0 carries the LDS address
+        const f16* xk = x + k0;                                        // uniform
+        const uint32_t l = lds_a0 + (uint32_t) slot3 * A_BYTES + (uint32_t) pair * 2048;
+        asm volatile("s_mov_b32 m0, %[l]\n\t"
+                     "global_load_lds_dwordx4 %[v0], %[sb]\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\t"
+                     "global_load_lds_dwordx4 %[v1], %[sb]"
+                     :: [l] "s"(l), [sb] "s"(xk), [v0] "v"(a_voff[2 * pair]), [v1] "v"(a_voff[2 * pair + 1]) : "memory", "scc");
+    };
+
+    const int pid = tid >> 1, ph = tid & 1;                            // half a T16 piece of EACH matrix per thread per K step
+    const int b_tile = pid >> 5;
+    const int b_rs = (pid >> 4) & 1;
+    const int b_col = pid & 15;
+    const int b_nloc = b_tile * 16 + b_col;
+    const int b_n = min(n0 + b_nloc, N - 1);
+    // packed words of K step `it`: piece (n, rb = it / 2), sub-row (it & 1) * 2 + b_rs, words 2 ph, 2 ph + 1 -> uniform it * 512 bytes + lane part
+    const uint32_t w_voff = (uint32_t) (((size_t) (b_n >> 4) * RB * 64 + (b_n & 15)) * 16 + (size_t) b_rs * 256 + ph * 8);
+    // group of k = it * 64 + b_rs * 32 (groupsize a power of two >= 32): uniform (it * 64) >> gshift, + b_rs for groupsize 32
+    const int zs_lane_grp = gshift == 5 ? b_rs : 0;
+    const uint32_t z_voff = (uint32_t) ((zs_lane_grp * (N >> 3) + (b_n >> 3)) * 4);
+    const uint32_t s_voff = (uint32_t) ((zs_lane_grp * N + b_n) * 2);
+    const int b_zsh = (b_n & 7) * 4;
+    const uint32_t magic = t16_magic();
+    const uint32_t b_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned char*) ldsB;
+    uint32_t b_dst[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b_dst[j] = b_lds + (uint32_t) gt_off(b_nloc, b_rs * 4 + ph * 2 + j);
+
+    struct BRegs { u32x2 wa; uint32_t za, sa; u32x2 wb; uint32_t zb, sb; };
+    auto issue_w = [&](int it, BRegs& r) {
+        const size_t wo = (size_t) it * 512;                                                              // uniform
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r.wa) : "v"(w_voff), "s"((const unsigned char*) qw1 + wo) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r.wb) : "v"(w_voff), "s"((const unsigned char*) qw2 + wo) : "memory");
+    };
+    auto issue_zs = [&](int it, BRegs& r) {
+        const int grp = (it * GT_BK) >> gshift;
+        const size_t zo = (size_t) grp * (N >> 3), so = (size_t) grp * N;
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(r.za) : "v"(z_voff), "s"(qz1 + zo) : "memory");
+        asm volatile("global_load_ushort %0, %1, %2" : "=v"(r.sa) : "v"(s_voff), "s"(sc1 + so) : "memory");
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(r.zb) : "v"(z_voff), "s"(qz2 + zo) : "memory");
+        asm volatile("global_load_ushort %0, %1, %2" : "=v"(r.sb) : "v"(s_voff), "s"(sc2 + so) : "memory");
+    };
+#define GD2_WAIT(NSTR, r) asm volatile("s_waitcnt vmcnt(" NSTR ")" : "+v"(r.wa), "+v"(r.za), "+v"(r.sa), "+v"(r.wb), "+v"(r.zb), "+v"(r.sb) :: "memory")
+    // dequantise word j of matrix `which` of the landed register set and store its 8 halves (one 16-byte chunk of the [n][k] tile)
+    auto store_word = [&](int slot2, int which, const BRegs& r, int j) {
+        const uint32_t zw = which ? r.zb : r.za, scb = which ? r.sb : r.sa;
+        const int z = (int) ((zw >> b_zsh) & 0xFu) + 1;
+        const f16 za = (f16) (float) (-(1024 + z));
+        const f16 zb = (f16) (float) (-(64 + z));
+        const f16 bsc = __builtin_bit_cast(f16, (uint16_t) (scb & 0xFFFFu));
+        const f16x2 zc0 = {za, za}, zc1 = {zb, zb}, s2 = {bsc, bsc};
+        const f16x8 d = t16_dequant_exact(which ? r.wb[j] : r.wa[j], magic, zc0, zc1);
+        const uint4 u = __builtin_bit_cast(uint4, d);
+        const u32x4 ov = {__builtin_bit_cast(uint32_t, as_h2(u.x) * s2), __builtin_bit_cast(uint32_t, as_h2(u.y) * s2),
+                          __builtin_bit_cast(uint32_t, as_h2(u.z) * s2), __builtin_bit_cast(uint32_t, as_h2(u.w) * s2)};
+        asm volatile("ds_write_b128 %0, %1" :: "v"(b_dst[j] + (uint32_t) ((slot2 * 2 + which) * GT_BTILE_BYTES)), "v"(ov) : "memory");
+    };
+    auto block_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    f32x4 acc1[4][4], acc2[4][4];                                        // [n-tile][m-tile]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    const int fr = lane & 15, fk = lane >> 4;
+    // fragment byte offsets: row tiles are 16 rows = 2048 bytes apart and share r & 7, so ONE swizzled base per operand + immediates;
+    // kk = 1 flips bit 6 of the swizzled chunk
+    const int fx0 = gt_off(wm * 64 + fr, fk), fw0 = gt_off(wn * 64 + fr, fk);
+    struct Pair { f16x8 w1, w2; };
+    f16x8 X0[4], X1[4];
+    Pair PA, PB, PH;
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { X0[i] = zero8; X1[i] = zero8; }
+    PH.w1 = zero8; PH.w2 = zero8; PA = PH; PB = PH;
+#define GD2_RDX(X, at, kk) do { _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) X[i_] = *(const f16x8*) ((at) + (fx0 ^ ((kk) << 6)) + i_ * 2048); } while (0)
+#define GD2_RDW(P, b1, in, kk) do { P.w1 = *(const f16x8*) ((b1) + (fw0 ^ ((kk) << 6)) + (in) * 2048); P.w2 = *(const f16x8*) ((b1) + GT_BTILE_BYTES + (fw0 ^ ((kk) << 6)) + (in) * 2048); } while (0)
+#define GD2_MF(P, X, in) do { _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                         \
+        acc1[in][i_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(P.w1, X[i_], acc1[in][i_], 0, 0, 0);                       \
+        acc2[in][i_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(P.w2, X[i_], acc2[in][i_], 0, 0, 0); } } while (0)
+#define GD2_SB() __builtin_amdgcn_sched_barrier(0)
+
+    // ---- prologue: batches 0 and 1 in flight, B(0) dequantised --------------------------------------------------------
+    BRegs rX, rY;
+    stage_a2(0, 0, 0); stage_a2(1, 0, 0);
+    issue_w(0, rX); issue_zs(0, rX);
+    stage_a2(0, 1, GT_BK); stage_a2(1, 1, GT_BK);                        // nk >= 2 always
+    issue_w(1, rY); issue_zs(1, rY);
+    GD2_WAIT("10", rX);                                                   // batch 0 landed (batch 1 may still fly)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { store_word(0, 0, rX, j); store_word(0, 1, rX, j); }
+    block_barrier();
+
+    int a_slot = 0;
+    auto ring = [](int s, int d) { const int v = s + d; return v >= 3 ? v - 3 : v; };
+    // one K step; rI receives the packed weights of tile t + 2, rW holds tile t + 1 (landing), bcur = LDS slot of B(t)
+    auto step = [&](int t, BRegs& rI, BRegs& rW, int bcur) {
+        const int tf = min(t + 2, nk - 1);                                // the last two steps re-fetch the last tile (never read)
+        const int adma = ring(a_slot, 2);
+        const unsigned char* at = lds + (size_t) a_slot * A_BYTES;
+        const unsigned char* b1 = ldsB + (size_t) (bcur * 2) * GT_BTILE_BYTES;
+        GD2_RDX(X0, at, 0); GD2_RDW(PA, b1, 0, 0);                          GD2_SB();
+        GD2_MF(PH, X1, 3);  stage_a2(0, adma, tf * GT_BK);   GD2_SB();   // the held group of tile t - 1
+        GD2_RDW(PB, b1, 1, 0);                                              GD2_SB();
+        GD2_MF(PA, X0, 0);  stage_a2(1, adma, tf * GT_BK);   GD2_SB();
+        GD2_RDW(PA, b1, 2, 0);                                              GD2_SB();
+        GD2_MF(PB, X0, 1);  issue_w(tf, rI);                                GD2_SB();
+        GD2_RDW(PB, b1, 3, 0); GD2_RDX(X1, at, 1);                          GD2_SB();
+        GD2_MF(PA, X0, 2);  issue_zs(tf, rI);                               GD2_SB();
+        GD2_RDW(PA, b1, 0, 1);                                              GD2_SB();
+        GD2_MF(PB, X0, 3);  GD2_WAIT("10", rW);                             GD2_SB();
+        GD2_RDW(PB, b1, 1, 1);                                              GD2_SB();
+        GD2_MF(PA, X1, 0);  store_word(bcur ^ 1, 0, rW, 0);                 GD2_SB();
+        GD2_RDW(PA, b1, 2, 1);                                              GD2_SB();
+        GD2_MF(PB, X1, 1);  store_word(bcur ^ 1, 1, rW, 0);                 GD2_SB();
+        GD2_RDW(PH, b1, 3, 1);                                              GD2_SB();
+        GD2_MF(PA, X1, 2);  store_word(bcur ^ 1, 0, rW, 1); store_word(bcur ^ 1, 1, rW, 1);   GD2_SB();
+        block_barrier();
+        a_slot = ring(a_slot, 1);
+    };
+    for (int t = 0; t < nk; t += 2) {
+        step(t, rX, rY, 0);
+        step(t + 1, rY, rX, 1);
+    }
+    GD2_MF(PH, X1, 3);                                                    // the held group of the last tile
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the two redundant fetches
+#undef GD2_WAIT
+#undef GD2_RDX
+#undef GD2_RDW
+#undef GD2_MF
+#undef GD2_SB
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int im = 0; im < 4; ++im) {
+        const int row = m0 + (wm * 4 + im) * 16 + fr;
+        if (row < M) {
+#pragma unroll
+            for (int in = 0; in < 4; ++in) {
+                const int n = n0 + (wn * 4 + in) * 16 + fk * 4;
+                if (n < N) {
+                    const size_t o = (size_t) row * N + n;
+                    f16x4 g, u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { g[j] = (f16) acc1[in][im][j]; u[j] = (f16) acc2[in][im][j]; }
+                    if constexpr (SILU) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {                 // exactly elementwise.hip: silu_mul_h on the fp16 values
+                            const f16 e = (f16) __expf((float) (f16) (-g[j]));
+                            const f16 sm = (f16) 1.0f + e;
+                            const f16 rc = (f16) (1.0f / (float) sm);
+                            const f16 v = g[j] * rc;
+                            g[j] = v * u[j];
+                        }
+                        *(f16x4*) (out1 + o) = g;
+                    } else {
+                        *(f16x4*) (out1 + o) = g;
+                        *(f16x4*) (out2 + o) = u;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // out1 = silu(x @ W1) * (x @ W2) (silu != 0) or out1 = x @ W1, out2 = x @ W2.  Returns 1 when the pair is not eligible
 // for the dual kernel (the caller then runs the two products separately), 0 on success, otherwise an error.
 int launch_q4_gemm_dual(const Q4Matrix* w1, const Q4Matrix* w2, const f16* x, int rows, f16* out1, f16* out2, int silu,
@@ -1122,14 +1347,26 @@ int launch_q4_gemm_dual(const Q4Matrix* w1, const Q4Matrix* w2, const f16* x, in
     const int mtiles = (rows + 255) / 256;
     const int ntiles = (N + GT_BN - 1) / GT_BN;
     const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
-    const size_t smem = 2 * (size_t) 256 * 128 + 4 * GT_BTILE_BYTES;
-    static bool big_silu[EXL_MAX_DEVICES] = {}, big_pair[EXL_MAX_DEVICES] = {};
-    EXL_TRY(exl_lds_opt_in((const void*) q4_gemm_t16d_kernel<true>, big_silu));
-    EXL_TRY(exl_lds_opt_in((const void*) q4_gemm_t16d_kernel<false>, big_pair));
 #define GD_ARGS x, (const uint4*) w1->qweight, w1->qzeros, w1->scales, (const uint4*) w2->qweight, w2->qzeros, w2->scales, out1, out2, \
                 rows, K, N, gshift, w1->groupsize, mtiles, ntiles
-    if (silu) hipLaunchKernelGGL(q4_gemm_t16d_kernel<true>, dim3(grid), dim3(512), smem, s, GD_ARGS);
-    else      hipLaunchKernelGGL(q4_gemm_t16d_kernel<false>, dim3(grid), dim3(512), smem, s, GD_ARGS);
+    static const bool unpipelined = getenv("EXL_GEMM_DUAL_UNPIPELINED") != nullptr;   // A/B switch: the predecessor (compiler-scheduled K step)
+    // the pipelined kernel: power-of-two groups (one shift), 32-bit byte offsets into the weight / scale / activation arrays
+    const bool pipelined_ok = gshift >= 5 && (uint64_t) K * (uint64_t) N < (1ull << 32) && (uint64_t) rows * (uint64_t) K < (1ull << 31);
+    if (unpipelined || !pipelined_ok) {
+        const size_t smem = 2 * (size_t) 256 * 128 + 4 * GT_BTILE_BYTES;
+        static bool big_silu[EXL_MAX_DEVICES] = {}, big_pair[EXL_MAX_DEVICES] = {};
+        EXL_TRY(exl_lds_opt_in((const void*) q4_gemm_t16d_kernel<true>, big_silu));
+        EXL_TRY(exl_lds_opt_in((const void*) q4_gemm_t16d_kernel<false>, big_pair));
+        if (silu) hipLaunchKernelGGL(q4_gemm_t16d_kernel<true>, dim3(grid), dim3(512), smem, s, GD_ARGS);
+        else      hipLaunchKernelGGL(q4_gemm_t16d_kernel<false>, dim3(grid), dim3(512), smem, s, GD_ARGS);
+    } else {
+        const size_t smem = 3 * (size_t) 256 * 128 + 4 * GT_BTILE_BYTES;              // 160 KiB: the whole LDS of a CU
+        static bool big_silu[EXL_MAX_DEVICES] = {}, big_pair[EXL_MAX_DEVICES] = {};
+        EXL_TRY(exl_lds_opt_in((const void*) q4_gemm_t16d2_kernel<true>, big_silu));
+        EXL_TRY(exl_lds_opt_in((const void*) q4_gemm_t16d2_kernel<false>, big_pair));
+        if (silu) hipLaunchKernelGGL(q4_gemm_t16d2_kernel<true>, dim3(grid), dim3(512), smem, s, GD_ARGS);
+        else      hipLaunchKernelGGL(q4_gemm_t16d2_kernel<false>, dim3(grid), dim3(512), smem, s, GD_ARGS);
+    }
 #undef GD_ARGS
     EXL_LAUNCH_CHECK();
     return 0;
