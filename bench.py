@@ -555,7 +555,7 @@ def prefill_gemm_probe(model, dims, S, dev, reps=2):
     us = e0.elapsed_time(e1) * 1e3 / (reps * len(mlps))
     flops = 2 * 2.0 * S * h * I
     tf = flops / us / 1e6
-    return {"bound": "mfma", "kernel": "q4_gemm_t16d_kernel (fused int4 dequant + gate/up MFMA GEMMs + SiLU*mul, one launch per layer)",
+    return {"bound": "mfma", "kernel": "q4_gemm_t16d2_kernel (fused int4 dequant + gate/up MFMA GEMMs + SiLU*mul, one launch per layer)",
             "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
             "launches": reps * len(mlps), "avg_launch_us": round(us, 2), "flops_per_launch": int(flops), "rows": S}
 

@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(512) void q4_gemm_t16d_kernel(const f16* __restrict
 // and only 4 % of it waiting for LDS -- both waves of a SIMD walk the same phases (fragment reads -> 64 MFMAs -> wait ->
 // dequantise + store -> barrier) at the same time, so the matrix pipe idles through every wait, store and barrier.
 // Here a K step is cut into 8 groups of 8 MFMAs (one weight fragment pair x 4 activation fragments x 2 matrices); the
-// fragments of group g + 1 are requested before group g is issued, the activation DMA / weight loads of tile t + 2, the
+// fragments of group g + 2 are requested before group g is issued, the activation DMA / weight loads of tile t + 2, the
 // wait for tile t + 1 and its dequantisation + LDS stores sit BETWEEN the groups, and the LAST group of tile t is held
 // back across the barrier: it runs while the first fragments of tile t + 1 are on their way.  Registers: 128 accumulators
 // + 56 fragment registers (two activation sets, three weight pairs) -- the full P / Q double set of the single-matrix
@@ -1236,11 +1236,11 @@ __global__ __launch_bounds__(512) void q4_gemm_t16d2_kernel(const f16* __restric
     const int fx0 = gt_off(wm * 64 + fr, fk), fw0 = gt_off(wn * 64 + fr, fk);
     struct Pair { f16x8 w1, w2; };
     f16x8 X0[4], X1[4];
-    Pair PA, PB, PH;
+    Pair Q0, Q1, Q2, Q3, Q4;                                              // Q0-Q2 rotate through groups 0-5, Q3 / Q4 carry groups 6 / 7 across the barrier
     const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 4; ++i) { X0[i] = zero8; X1[i] = zero8; }
-    PH.w1 = zero8; PH.w2 = zero8; PA = PH; PB = PH;
+    Q3.w1 = zero8; Q3.w2 = zero8; Q4 = Q3; Q0 = Q3; Q1 = Q3; Q2 = Q3;
 #define GD2_RDX(X, at, kk) do { _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) X[i_] = *(const f16x8*) ((at) + (fx0 ^ ((kk) << 6)) + i_ * 2048); } while (0)
 #define GD2_RDW(P, b1, in, kk) do { P.w1 = *(const f16x8*) ((b1) + (fw0 ^ ((kk) << 6)) + (in) * 2048); P.w2 = *(const f16x8*) ((b1) + GT_BTILE_BYTES + (fw0 ^ ((kk) << 6)) + (in) * 2048); } while (0)
 #define GD2_MF(P, X, in) do { _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                         \
@@ -1261,37 +1261,55 @@ __global__ __launch_bounds__(512) void q4_gemm_t16d2_kernel(const f16* __restric
 
     int a_slot = 0;
     auto ring = [](int s, int d) { const int v = s + d; return v >= 3 ? v - 3 : v; };
+#ifdef EXL_GEMM_PROBE
+    unsigned long long p_wait = 0, p_store = 0, p_bar = 0;                // here: first half (incl. the vmcnt wait) / second half / barrier
+    const unsigned long long p_t0 = __builtin_readcyclecounter();
+#endif
     // one K step; rI receives the packed weights of tile t + 2, rW holds tile t + 1 (landing), bcur = LDS slot of B(t)
     auto step = [&](int t, BRegs& rI, BRegs& rW, int bcur) {
         const int tf = min(t + 2, nk - 1);                                // the last two steps re-fetch the last tile (never read)
         const int adma = ring(a_slot, 2);
         const unsigned char* at = lds + (size_t) a_slot * A_BYTES;
         const unsigned char* b1 = ldsB + (size_t) (bcur * 2) * GT_BTILE_BYTES;
-        GD2_RDX(X0, at, 0); GD2_RDW(PA, b1, 0, 0);                          GD2_SB();
-        GD2_MF(PH, X1, 3);  stage_a2(0, adma, tf * GT_BK);   GD2_SB();   // the held group of tile t - 1
-        GD2_RDW(PB, b1, 1, 0);                                              GD2_SB();
-        GD2_MF(PA, X0, 0);  stage_a2(1, adma, tf * GT_BK);   GD2_SB();
-        GD2_RDW(PA, b1, 2, 0);                                              GD2_SB();
-        GD2_MF(PB, X0, 1);  issue_w(tf, rI);                                GD2_SB();
-        GD2_RDW(PB, b1, 3, 0); GD2_RDX(X1, at, 1);                          GD2_SB();
-        GD2_MF(PA, X0, 2);  issue_zs(tf, rI);                               GD2_SB();
-        GD2_RDW(PA, b1, 0, 1);                                              GD2_SB();
-        GD2_MF(PB, X0, 3);  GD2_WAIT("10", rW);                             GD2_SB();
-        GD2_RDW(PB, b1, 1, 1);                                              GD2_SB();
-        GD2_MF(PA, X1, 0);  store_word(bcur ^ 1, 0, rW, 0);                 GD2_SB();
-        GD2_RDW(PA, b1, 2, 1);                                              GD2_SB();
-        GD2_MF(PB, X1, 1);  store_word(bcur ^ 1, 1, rW, 0);                 GD2_SB();
-        GD2_RDW(PH, b1, 3, 1);                                              GD2_SB();
-        GD2_MF(PA, X1, 2);  store_word(bcur ^ 1, 0, rW, 1); store_word(bcur ^ 1, 1, rW, 1);   GD2_SB();
+        GP_CLK(c0);
+        // group g = (kk = g >> 2, in = g & 3); fragments are requested TWO groups ahead of their use (a ds_read_b128 under this load
+        // takes ~250 cycles, a group of 8 MFMAs 128: with one group of lead a wave stalled ~120 cycles per group -- probe: 2055
+        // cycles for its 64 MFMAs); groups 6 and 7 of the previous tile open the step while this tile's first fragments fly
+        GD2_RDX(X0, at, 0); GD2_RDW(Q0, b1, 0, 0); GD2_RDW(Q1, b1, 1, 0);   GD2_SB();
+        GD2_MF(Q3, X1, 2);  stage_a2(0, adma, tf * GT_BK);                  GD2_SB();   // group 6 of tile t - 1
+        GD2_RDW(Q2, b1, 2, 0);                                              GD2_SB();
+        GD2_MF(Q4, X1, 3);  stage_a2(1, adma, tf * GT_BK);                  GD2_SB();   // group 7 of tile t - 1
+        GD2_RDX(X1, at, 1);                                                 GD2_SB();
+        GD2_MF(Q0, X0, 0);  issue_w(tf, rI);                                GD2_SB();
+        GD2_RDW(Q0, b1, 3, 0);                                              GD2_SB();
+        GD2_MF(Q1, X0, 1);  issue_zs(tf, rI);                               GD2_SB();
+        GD2_RDW(Q1, b1, 0, 1);                                              GD2_SB();
+        GD2_MF(Q2, X0, 2);  GD2_WAIT("10", rW);                             GD2_SB();
+        GP_CLK(c1);
+        GD2_RDW(Q2, b1, 1, 1);                                              GD2_SB();
+        GD2_MF(Q0, X0, 3);  store_word(bcur ^ 1, 0, rW, 0);                 GD2_SB();
+        GD2_RDW(Q3, b1, 2, 1);                                              GD2_SB();
+        GD2_MF(Q1, X1, 0);  store_word(bcur ^ 1, 1, rW, 0);                 GD2_SB();
+        GD2_RDW(Q4, b1, 3, 1);                                              GD2_SB();
+        GD2_MF(Q2, X1, 1);  store_word(bcur ^ 1, 0, rW, 1); store_word(bcur ^ 1, 1, rW, 1);   GD2_SB();
+        GP_CLK(c2);
         block_barrier();
+        GP_CLK(c3);
+        GP_ACC(p_wait, c0, c1); GP_ACC(p_store, c1, c2); GP_ACC(p_bar, c2, c3);
         a_slot = ring(a_slot, 1);
     };
     for (int t = 0; t < nk; t += 2) {
         step(t, rX, rY, 0);
         step(t + 1, rY, rX, 1);
     }
-    GD2_MF(PH, X1, 3);                                                    // the held group of the last tile
+    GD2_MF(Q3, X1, 2); GD2_MF(Q4, X1, 3);                                 // the held groups of the last tile
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the two redundant fetches
+#ifdef EXL_GEMM_PROBE
+    if (lane == 0 && b < 1024) {
+        unsigned long long* pp = g_gemm_probe + ((size_t) b * 8 + wave) * 4;
+        pp[0] = __builtin_readcyclecounter() - p_t0; pp[1] = p_wait; pp[2] = p_store; pp[3] = p_bar;
+    }
+#endif
 #undef GD2_WAIT
 #undef GD2_RDX
 #undef GD2_RDW
