@@ -1171,14 +1171,17 @@ __global__ __launch_bounds__(512) void q4_gemm_t16d2_kernel(const f16* __restric
                      :: [l] "s"(l), [sb] "s"(xk), [v0] "v"(a_voff[2 * pair]), [v1] "v"(a_voff[2 * pair + 1]) : "memory", "scc");
     };
 
-    const int pid = tid >> 1, ph = tid & 1;                            // half a T16 piece of EACH matrix per thread per K step
+    // loader part: waves 0-3 fetch the packed weights of matrix 1, waves 4-7 those of matrix 2 -- one whole T16 piece quarter (4 words)
+    // per thread and K step: 3 vector-memory instructions per wave and step instead of 6 (a wave that queues on the memory pipe
+    // cannot issue the MFMAs behind it)
+    const int pid = tid & 255, mat = wave >> 2;
     const int b_tile = pid >> 5;
     const int b_rs = (pid >> 4) & 1;
     const int b_col = pid & 15;
     const int b_nloc = b_tile * 16 + b_col;
     const int b_n = min(n0 + b_nloc, N - 1);
     // packed words of K step `it`: piece (n, rb = it / 2), sub-row (it & 1) * 2 + b_rs, words 2 ph, 2 ph + 1 -> uniform it * 512 bytes + lane part
-    const uint32_t w_voff = (uint32_t) (((size_t) (b_n >> 4) * RB * 64 + (b_n & 15)) * 16 + (size_t) b_rs * 256 + ph * 8);
+    const uint32_t w_voff = (uint32_t) (((size_t) (b_n >> 4) * RB * 64 + (b_n & 15)) * 16 + (size_t) b_rs * 256);
     // group of k = it * 64 + b_rs * 32 (groupsize a power of two >= 32): uniform (it * 64) >> gshift, + b_rs for groupsize 32
     const int zs_lane_grp = gshift == 5 ? b_rs : 0;
     const uint32_t z_voff = (uint32_t) ((zs_lane_grp * (N >> 3) + (b_n >> 3)) * 4);
@@ -1186,38 +1189,37 @@ __global__ __launch_bounds__(512) void q4_gemm_t16d2_kernel(const f16* __restric
     const int b_zsh = (b_n & 7) * 4;
     const uint32_t magic = t16_magic();
     const uint32_t b_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned char*) ldsB;
-    uint32_t b_dst[2];
+    uint32_t b_dst[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) b_dst[j] = b_lds + (uint32_t) gt_off(b_nloc, b_rs * 4 + ph * 2 + j);
+    for (int j = 0; j < 4; ++j) b_dst[j] = b_lds + (uint32_t) (mat * GT_BTILE_BYTES) + (uint32_t) gt_off(b_nloc, b_rs * 4 + j);
 
-    struct BRegs { u32x2 wa; uint32_t za, sa; u32x2 wb; uint32_t zb, sb; };
+    struct BRegs { u32x4 w4; uint32_t zw, sc; };
+    const unsigned char* const qw_m = (const unsigned char*) (mat ? qw2 : qw1);       // wave-uniform
+    const uint32_t* const qz_m = mat ? qz2 : qz1;
+    const f16* const sc_m = mat ? sc2 : sc1;
     auto issue_w = [&](int it, BRegs& r) {
         const size_t wo = (size_t) it * 512;                                                              // uniform
-        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r.wa) : "v"(w_voff), "s"((const unsigned char*) qw1 + wo) : "memory");
-        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r.wb) : "v"(w_voff), "s"((const unsigned char*) qw2 + wo) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r.w4) : "v"(w_voff), "s"(qw_m + wo) : "memory");
     };
     auto issue_zs = [&](int it, BRegs& r) {
         const int grp = (it * GT_BK) >> gshift;
         const size_t zo = (size_t) grp * (N >> 3), so = (size_t) grp * N;
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(r.za) : "v"(z_voff), "s"(qz1 + zo) : "memory");
-        asm volatile("global_load_ushort %0, %1, %2" : "=v"(r.sa) : "v"(s_voff), "s"(sc1 + so) : "memory");
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(r.zb) : "v"(z_voff), "s"(qz2 + zo) : "memory");
-        asm volatile("global_load_ushort %0, %1, %2" : "=v"(r.sb) : "v"(s_voff), "s"(sc2 + so) : "memory");
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(r.zw) : "v"(z_voff), "s"(qz_m + zo) : "memory");
+        asm volatile("global_load_ushort %0, %1, %2" : "=v"(r.sc) : "v"(s_voff), "s"(sc_m + so) : "memory");
     };
-#define GD2_WAIT(NSTR, r) asm volatile("s_waitcnt vmcnt(" NSTR ")" : "+v"(r.wa), "+v"(r.za), "+v"(r.sa), "+v"(r.wb), "+v"(r.zb), "+v"(r.sb) :: "memory")
-    // dequantise word j of matrix `which` of the landed register set and store its 8 halves (one 16-byte chunk of the [n][k] tile)
-    auto store_word = [&](int slot2, int which, const BRegs& r, int j) {
-        const uint32_t zw = which ? r.zb : r.za, scb = which ? r.sb : r.sa;
-        const int z = (int) ((zw >> b_zsh) & 0xFu) + 1;
+#define GD2_WAIT(NSTR, r) asm volatile("s_waitcnt vmcnt(" NSTR ")" : "+v"(r.w4), "+v"(r.zw), "+v"(r.sc) :: "memory")
+    // dequantise word j of the landed register set and store its 8 halves (one 16-byte chunk of this wave's [n][k] tile)
+    auto store_word = [&](int slot2, const BRegs& r, int j) {
+        const int z = (int) ((r.zw >> b_zsh) & 0xFu) + 1;
         const f16 za = (f16) (float) (-(1024 + z));
         const f16 zb = (f16) (float) (-(64 + z));
-        const f16 bsc = __builtin_bit_cast(f16, (uint16_t) (scb & 0xFFFFu));
+        const f16 bsc = __builtin_bit_cast(f16, (uint16_t) (r.sc & 0xFFFFu));
         const f16x2 zc0 = {za, za}, zc1 = {zb, zb}, s2 = {bsc, bsc};
-        const f16x8 d = t16_dequant_exact(which ? r.wb[j] : r.wa[j], magic, zc0, zc1);
+        const f16x8 d = t16_dequant_exact(r.w4[j], magic, zc0, zc1);
         const uint4 u = __builtin_bit_cast(uint4, d);
         const u32x4 ov = {__builtin_bit_cast(uint32_t, as_h2(u.x) * s2), __builtin_bit_cast(uint32_t, as_h2(u.y) * s2),
                           __builtin_bit_cast(uint32_t, as_h2(u.z) * s2), __builtin_bit_cast(uint32_t, as_h2(u.w) * s2)};
-        asm volatile("ds_write_b128 %0, %1" :: "v"(b_dst[j] + (uint32_t) ((slot2 * 2 + which) * GT_BTILE_BYTES)), "v"(ov) : "memory");
+        asm volatile("ds_write_b128 %0, %1" :: "v"(b_dst[j] + (uint32_t) (slot2 * 2 * GT_BTILE_BYTES)), "v"(ov) : "memory");
     };
     auto block_barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1254,9 +1256,9 @@ __global__ __launch_bounds__(512) void q4_gemm_t16d2_kernel(const f16* __restric
     issue_w(0, rX); issue_zs(0, rX);
     stage_a2(0, 1, GT_BK); stage_a2(1, 1, GT_BK);                        // nk >= 2 always
     issue_w(1, rY); issue_zs(1, rY);
-    GD2_WAIT("10", rX);                                                   // batch 0 landed (batch 1 may still fly)
+    GD2_WAIT("7", rX);                                                    // batch 0 landed (batch 1 may still fly)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { store_word(0, 0, rX, j); store_word(0, 1, rX, j); }
+    for (int j = 0; j < 4; ++j) store_word(0, rX, j);
     block_barrier();
 
     int a_slot = 0;
@@ -1284,14 +1286,14 @@ __global__ __launch_bounds__(512) void q4_gemm_t16d2_kernel(const f16* __restric
         GD2_RDW(Q0, b1, 3, 0);                                              GD2_SB();
         GD2_MF(Q1, X0, 1);  issue_zs(tf, rI);                               GD2_SB();
         GD2_RDW(Q1, b1, 0, 1);                                              GD2_SB();
-        GD2_MF(Q2, X0, 2);  GD2_WAIT("10", rW);                             GD2_SB();
+        GD2_MF(Q2, X0, 2);  GD2_WAIT("7", rW);                              GD2_SB();
         GP_CLK(c1);
         GD2_RDW(Q2, b1, 1, 1);                                              GD2_SB();
-        GD2_MF(Q0, X0, 3);  store_word(bcur ^ 1, 0, rW, 0);                 GD2_SB();
+        GD2_MF(Q0, X0, 3);  store_word(bcur ^ 1, rW, 0);                    GD2_SB();
         GD2_RDW(Q3, b1, 2, 1);                                              GD2_SB();
-        GD2_MF(Q1, X1, 0);  store_word(bcur ^ 1, 1, rW, 0);                 GD2_SB();
+        GD2_MF(Q1, X1, 0);  store_word(bcur ^ 1, rW, 1);                    GD2_SB();
         GD2_RDW(Q4, b1, 3, 1);                                              GD2_SB();
-        GD2_MF(Q2, X1, 1);  store_word(bcur ^ 1, 0, rW, 1); store_word(bcur ^ 1, 1, rW, 1);   GD2_SB();
+        GD2_MF(Q2, X1, 1);  store_word(bcur ^ 1, rW, 2); store_word(bcur ^ 1, rW, 3);   GD2_SB();
         GP_CLK(c2);
         block_barrier();
         GP_CLK(c3);
