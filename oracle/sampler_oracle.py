@@ -8,7 +8,10 @@ uniform numbers; here, as on the device, the token is drawn by inverse CDF over 
 uniform number u in [0, 1).  Given the same logits, history and u the device kernel must return the same token id
 (bit-exact integer result) except when u falls within float rounding of a cumulative boundary.
 
-The repetition-penalty part is pinned by the reference itself: tests compare `rep_penalty` with oracle/_ref/
+PARITY PINNING: tests/golden/sampler_ref.npz holds what the reference's own ExLlamaGenerator.sample hands to torch.multinomial
+(surviving tokens + probabilities) for seeded logits, produced by importing /root/reference/generator.py on CPU
+(oracle/make_sampler_golden.py); tests/test_sampler.py requires this module to reproduce survivors, probabilities (3e-6:
+torch vs numpy softmax) and the inverse-CDF token.  The repetition-penalty part is pinned by the reference itself: tests compare `rep_penalty` with oracle/_ref/
 librep_penalty_ref.so (the reference's rep_penalty.cpp compiled unmodified) through exl_oracle.apply_rep_penalty.
 """
 

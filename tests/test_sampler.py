@@ -67,6 +67,29 @@ def _device_sample(lib, logits, hist, settings, u, max_len):
     return int(tok), float(pr)
 
 
+
+def test_sampler_oracle_reproduces_the_references_own_sample():
+    """Pinned by the reference: tests/golden/sampler_ref.npz holds what /root/reference/generator.py's ExLlamaGenerator.sample
+    (:91-170) hands to torch.multinomial -- the surviving tokens and their probabilities after temperature, softmax, top-k,
+    top-p / min-p and typical sampling -- for seeded logits (oracle/make_sampler_golden.py, run where the reference lives).  The
+    oracle must reproduce the survivors, their probabilities and the inverse-CDF token."""
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "sampler_ref.npz")
+    z = np.load(path)
+    n = int(z["n"])
+    assert n >= 10
+    for i in range(n):
+        temp, top_k, top_p, min_p, typical, u = (float(v) for v in z[f"params_{i}"])
+        logits = z[f"logits_{i}"]
+        tok, prob, idx, probs = S.sample(logits, [], temperature=temp, top_k=int(top_k), top_p=top_p, min_p=min_p, typical=typical,
+                                         rep_penalty_max=1.0, u=u)
+        ref_p = z[f"probs_{i}"]
+        assert probs.shape == ref_p.shape, (i, probs.shape, ref_p.shape)                  # the same number of survivors
+        assert np.array_equal(np.sort(np.asarray(idx)), z[f"ids_sorted_{i}"]), i           # ... the same tokens
+        np.testing.assert_allclose(probs, ref_p, rtol=3e-6, atol=1e-9, err_msg=str(i))     # ... in the same order (torch vs numpy softmax: 1 ulp)
+        assert tok == int(z[f"token_{i}"]), (i, tok, int(z[f"token_{i}"]))
+        assert abs(prob - float(z[f"tokprob_{i}"])) <= 3e-6 * max(1.0, prob)
+
 @pytest.mark.gpu
 def test_device_sampler_matches_the_oracle_token_for_token():
     from exllama_amd import _lib
