@@ -293,3 +293,43 @@ def test_bench_algorithmic_counts_match_the_survey_table():
     assert per == pytest.approx(46.9e6, rel=2e-3)
     r = bench.whole_job_rates(4, 2048, 128, prefill_ms=20.0, worst_ms=200.0, best_ms=100.0)
     assert r == {"prefill": pytest.approx(4 * 2048 / 0.02), "worst": pytest.approx(4 * 128 / 0.2), "best": pytest.approx(4 * 128 / 0.1)}
+
+
+def test_config_and_device_map_equal_the_references_own_classes(tmp_path):
+    """Pinned by the reference: tests/golden/host_ref.json was written by /root/reference/model.py's ExLlamaConfig /
+    ExLlamaDeviceMap (oracle/make_host_golden.py, run where the reference lives): every scalar attribute of a config built from
+    three config.json files (incl. GQA and a rope_theta), the NTK-scaled rotary base, the parsed auto map, and where the device
+    map sends each kind of tensor key."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "host_ref.json")) as f:
+        gold = json.load(f)
+    from oracle.make_host_golden import CONFIGS, KEYS
+    for name, cfg in CONFIGS.items():
+        p = tmp_path / f"{name}.json"
+        p.write_text(json.dumps(cfg))
+        c = ExLlamaConfig(str(p))
+        want = gold["configs"][name]
+        for k, v in want.items():
+            if k.startswith("rotary_embedding_base_after") or k.startswith("auto_map_of"):
+                continue
+            assert hasattr(c, k), (name, k)
+            assert getattr(c, k) == v, (name, k, getattr(c, k), v)
+        c.alpha_value = 2.5
+        c.calculate_rotary_embedding_base()
+        assert c.rotary_embedding_base == want["rotary_embedding_base_after_alpha_2.5"]
+        c.set_auto_map("10.5,24")
+        assert c.auto_map == want["auto_map_of_10.5,24"]
+    dm = gold["device_map"]
+    m = ExLlamaDeviceMap(8)
+    m.layers = list(dm["layers"])
+    m.norm = m.lm_head = "cuda:1"
+    # the ONE deliberate difference: the reference keeps the embedding table on the CPU (model.py:640), this repository on the first
+    # GPU (SURVEY 8f N2: the lookup is part of the decode graph); with the reference's placement the maps are identical
+    assert dm["defaults"]["embed_tokens"] == "cpu" and ExLlamaDeviceMap(3).embed_tokens == "cuda:0"
+    m.embed_tokens = "cpu"
+    assert {k: m.map(k) for k in KEYS} == dm["map"]
+    assert m.get_layers_devs() == dm["layers_devs"] and m.get_all_devs() == dm["all_devs"]
+    fresh = ExLlamaDeviceMap(3)
+    fresh.embed_tokens = "cpu"
+    assert {"embed_tokens": fresh.embed_tokens, "lm_head": fresh.lm_head, "norm": fresh.norm, "layers": fresh.layers} == dm["defaults"]
