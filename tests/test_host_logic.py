@@ -333,3 +333,33 @@ def test_config_and_device_map_equal_the_references_own_classes(tmp_path):
     fresh = ExLlamaDeviceMap(3)
     fresh.embed_tokens = "cpu"
     assert {"embed_tokens": fresh.embed_tokens, "lm_head": fresh.lm_head, "norm": fresh.norm, "layers": fresh.layers} == dm["defaults"]
+
+
+def test_model_init_equals_the_references_own_model_init(tmp_path):
+    """Pinned by the reference: tests/golden/init_ref.json holds the ExLlamaConfig that /root/reference/model_init.py's own
+    add_args / post_parse / get_model_files / make_config build for 11 argument vectors (oracle/make_init_golden.py, run where
+    the reference lives; on this ROCm torch post_parse switches the half2 paths off unless -fh2, model_init.py:43).  This
+    repository's model_init must build the same config, attribute for attribute."""
+    import argparse
+    import os
+    from exllama_amd import model_init
+    from oracle.make_init_golden import make_dir
+    with open(os.path.join(os.path.dirname(__file__), "golden", "init_ref.json")) as f:
+        cases = json.load(f)
+    d = str(tmp_path / "m")
+    make_dir(d)
+    assert len(cases) >= 10
+    for case in cases:
+        parser = argparse.ArgumentParser()
+        model_init.add_args(parser)
+        args = parser.parse_args([a.replace("{DIR}", d) for a in case["argv"]])
+        model_init.post_parse(args)
+        model_init.get_model_files(args)
+        c = model_init.make_config(args)
+        for k, want in case["config"].items():
+            got = getattr(c, k)
+            if isinstance(got, str):
+                got = got.replace(d, "{DIR}")
+            if isinstance(got, list):
+                got = [x.replace(d, "{DIR}") if isinstance(x, str) else x for x in got]
+            assert got == want, (case["argv"], k, got, want)
