@@ -363,3 +363,22 @@ def test_model_init_equals_the_references_own_model_init(tmp_path):
             if isinstance(got, list):
                 got = [x.replace(d, "{DIR}") if isinstance(x, str) else x for x in got]
             assert got == want, (case["argv"], k, got, want)
+
+
+def test_lora_loader_equals_the_references_own_loader(tmp_path):
+    """Pinned by the reference: tests/golden/lora_ref.json holds what /root/reference/lora.py's own ExLlamaLora.__init__ makes of a
+    seeded synthetic adapter (oracle/make_lora_golden.py, run where the reference lives): keys, shapes, dtypes and SHA-256 of every
+    tensor after transposition, alpha / r pre-scaling of B and fp32 / bf16 -> fp16 conversion, and the ignored zero bias."""
+    import os
+    from safetensors.torch import save_file
+    from exllama_amd.lora import ExLlamaLora
+    from oracle.make_lora_golden import ALPHA, H, INTER, LAYERS, R, adapter_state, describe
+    with open(os.path.join(os.path.dirname(__file__), "golden", "lora_ref.json")) as f:
+        gold = json.load(f)
+    cfg = tmp_path / "adapter_config.json"
+    cfg.write_text(json.dumps({"r": R, "lora_alpha": ALPHA, "fan_in_fan_out": False}))
+    st = tmp_path / "adapter_model.safetensors"
+    save_file({k: v.contiguous() for k, v in adapter_state().items()}, str(st))
+    got = describe(ExLlamaLora(_stub_model(layers=LAYERS, h=H, inter=INTER), str(cfg), str(st)))
+    assert len(gold["tensors"]) == 10
+    assert got == gold
