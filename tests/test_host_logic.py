@@ -382,3 +382,25 @@ def test_lora_loader_equals_the_references_own_loader(tmp_path):
     got = describe(ExLlamaLora(_stub_model(layers=LAYERS, h=H, inter=INTER), str(cfg), str(st)))
     assert len(gold["tensors"]) == 10
     assert got == gold
+
+
+def test_perplexity_harness_equals_the_references_own_perplexity(tmp_path):
+    """Pinned by the reference (BASELINE's `-ppl` leg): tests/golden/ppl_ref.json holds the chunking and the perplexity that
+    /root/reference/perplexity.py's own Perplexity.load / .test produce for a raw text and a .jsonl dataset under six settings, with a
+    deterministic position-dependent stand-in model and a byte tokenizer (oracle/make_ppl_golden.py, run where the reference lives).
+    This repository's harness must cut the same chunks and print the same number, whole-chunk and token by token."""
+    import os
+    from exllama_amd.perplexity import Perplexity
+    from oracle.make_ppl_golden import ByteTokenizer, StandInCache, StandInModel, write_datasets
+    with open(os.path.join(os.path.dirname(__file__), "golden", "ppl_ref.json")) as f:
+        gold = json.load(f)
+    raw, js = write_datasets(str(tmp_path))
+    assert len(gold) == 6
+    for rec in gold:
+        path = raw if rec["kind"] == "raw" else js
+        for mode, key in ((False, "ppl_chunk"), (True, "ppl_token")):
+            p = Perplexity("default", StandInModel(), StandInCache(), ByteTokenizer())
+            p.load(path, **rec["args"])
+            assert [[int(c.shape[1]), int(c[0, 0]), int(c[0, -1])] for c in p.dataset_chunks] == rec["chunks"], rec["args"]
+            got = p.test(ppl_token=mode, quiet=True)
+            assert round(got, 4) == pytest.approx(rec[key], abs=1.5e-4), (rec["args"], mode, got, rec[key])   # the reference prints 4 decimals
