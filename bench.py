@@ -37,7 +37,7 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--model", default="7b", choices=["7b", "13b", "33b", "65b", "tiny", "tiny_gqa"])
+    p.add_argument("--model", default="7b", choices=["7b", "13b", "33b", "65b", "70b", "tiny", "tiny_gqa"])
     p.add_argument("--groupsize", type=int, default=128)
     p.add_argument("--act-order", action="store_true")
     p.add_argument("--prompt", type=int, default=2048)
