@@ -194,6 +194,8 @@ GEMM_SHAPES = [(256, 128, 64, True, 16), (512, 96, 128, False, 33), (704, 256, 6
                # column group, K shorter than the 8 waves, one group for the whole K (odd K), an odd group size (tile-kernel fallback)
                (4096, 4096, 128, False, 256), (512, 96, 128, False, 250), (256, 352, 32, True, 70), (1408, 256, 1408, False, 50),
                (1408, 128, 352, False, 50), (5120, 13824, 128, True, 17),
+               # 257 .. 512 rows: the 128-row tile kernel (q4_gemm_t16m_kernel<2, 2, 4, 4>)
+               (4096, 4096, 128, False, 300), (11008, 4096, 128, True, 512), (4096, 11008, 32, True, 400), (2048, 512, 64, False, 257),
                # > 512 rows: the 256-row pipelined tile, ragged last m-tile
                (4096, 4096, 128, False, 600), (1408, 512, 64, True, 530), (512, 11008, 32, False, 777)]
 
