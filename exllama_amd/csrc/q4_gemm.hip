@@ -1441,9 +1441,15 @@ int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
     static const bool use_reg_b = getenv("EXL_GEMM_REGISTER_B") != nullptr;     // A/B switch: the generic register-B kernel
     static const bool no_spec = getenv("EXL_GEMM_NO_LOADER_WAVES") != nullptr;   // A/B switch: mid-step kernel for every row count
     if (w->layout == EXL_LAYOUT_T16 && !use_reg_b && (uint64_t) rows * (uint64_t) K < (1ull << 31)) {    // 32-bit activation byte offsets
-        const bool spec = !no_spec && rows > 512 && gshift >= 5 && (uint64_t) K * (uint64_t) N < (1ull << 32);   // loader waves: power-of-two groups, 32-bit weight offsets
+        // 257 .. 512 rows take the 256-row kernels too: the 128 x 128 variant below returned garbage in single 16-column tiles at 400
+        // rows x 11008 columns when the launch had more blocks than CUs (two 80 KiB blocks per CU) and the allocator's free memory was
+        // poisoned (found in the last hour of round 2, not yet understood); it is only left for <= 256 rows with group sizes the
+        // short-prompt kernel declines (<= 172 blocks: one per CU).  EXL_GEMM_TILE128=1 brings it back for A/B.
+        static const bool tile128 = getenv("EXL_GEMM_TILE128") != nullptr;
+        const int big_rows = tile128 ? 512 : 256;
+        const bool spec = !no_spec && rows > big_rows && gshift >= 5 && (uint64_t) K * (uint64_t) N < (1ull << 32);   // loader waves: power-of-two groups, 32-bit weight offsets
         if (spec) return launch_gemm_t16w(w, xin, rows, out, no_zero, gshift, s);                 // 256 x 128, 8 MFMA waves + 4 loader waves
-        if (rows > 512) return launch_gemm_t16m<4, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s);  // 256 x 128, 8 waves
+        if (rows > big_rows) return launch_gemm_t16m<4, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s);  // 256 x 128, 8 waves
         return launch_gemm_t16m<2, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s);                // 128 x 128, 4 waves
     }
     if (w->layout == EXL_LAYOUT_T16)
