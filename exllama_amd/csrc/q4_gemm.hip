@@ -475,7 +475,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void q4_gemm_t16m_kernel(co
         step(t + 1, rY, rX, 1);
     }
     GM_MFMA4(P, 0); GM_MFMA4(P, 4); GM_MFMA4(P, 8); GM_MFMA4(P, 12);      // second half of the last tile
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the two redundant fetches
+    // The two redundant fetches.  Their destination registers are operands of the wait on purpose: to the compiler the values are
+    // dead after the loop, and without the tie it shuffled accumulators through the very registers a dwordx4 was still on its way
+    // to (v_accvgpr_read v4..v7 / v_accvgpr_write between the loop and this wait): whole accumulator registers of a wave came out
+    // as weight bits whenever the last fetch was slow (first launch after an idle period, two blocks per CU): the round-2 "400 rows
+    // x 11008 columns" defect, DESIGN.md 9.5.
+    GM_WAIT("0", rX); GM_WAIT("0", rY);
 #ifdef EXL_GEMM_PROBE
     if (lane == 0 && b < 1024) {
         unsigned long long* pp = g_gemm_probe + ((size_t) b * 8 + wave) * 4;
@@ -701,7 +706,7 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
             half_step(ring(a_slot, 2), t3, rY, rX, 0);
             a_slot = ring(a_slot, 1);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the redundant fetches must not outlive the block's LDS
+        GW_WAIT("0", rX); GW_WAIT("0", rY);                              // the redundant fetches must not outlive the block's LDS (registers tied: see q4_gemm_t16m_kernel)
         if constexpr (EPI == 1) {
             if (mi < 2) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }   // the RoPE exchange of the MFMA waves reuses the tiles
         }
@@ -1305,7 +1310,7 @@ __global__ __launch_bounds__(512) void q4_gemm_t16d2_kernel(const f16* __restric
         step(t + 1, rY, rX, 1);
     }
     GD2_MF(Q3, X1, 2); GD2_MF(Q4, X1, 3);                                 // the held groups of the last tile
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the two redundant fetches
+    GD2_WAIT("0", rX); GD2_WAIT("0", rY);                                 // the two redundant fetches (registers tied: see q4_gemm_t16m_kernel)
 #ifdef EXL_GEMM_PROBE
     if (lane == 0 && b < 1024) {
         unsigned long long* pp = g_gemm_probe + ((size_t) b * 8 + wave) * 4;
@@ -1441,10 +1446,10 @@ int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
     static const bool use_reg_b = getenv("EXL_GEMM_REGISTER_B") != nullptr;     // A/B switch: the generic register-B kernel
     static const bool no_spec = getenv("EXL_GEMM_NO_LOADER_WAVES") != nullptr;   // A/B switch: mid-step kernel for every row count
     if (w->layout == EXL_LAYOUT_T16 && !use_reg_b && (uint64_t) rows * (uint64_t) K < (1ull << 31)) {    // 32-bit activation byte offsets
-        // 257 .. 512 rows take the 256-row kernels too: the 128 x 128 variant below returned garbage in single 16-column tiles at 400
-        // rows x 11008 columns when the launch had more blocks than CUs (two 80 KiB blocks per CU) and the allocator's free memory was
-        // poisoned (found in the last hour of round 2, not yet understood); it is only left for <= 256 rows with group sizes the
-        // short-prompt kernel declines (<= 172 blocks: one per CU).  EXL_GEMM_TILE128=1 brings it back for A/B.
+        // 257 .. 512 rows take the 256-row kernels too: the 128 x 128 variant below corrupted accumulators at 400 rows x 11008
+        // columns (in-flight "redundant" fetches landing in registers the compiler had reused; fixed at the end of round 2 by tying
+        // the final wait to those registers, see q4_gemm_t16m_kernel and DESIGN.md 9.5), and the fix has not been re-run under the
+        // failing scenario yet.  EXL_GEMM_TILE128=1 selects the 128-row tile for 257 .. 512 rows (about 10 % faster at 300 - 384 rows).
         static const bool tile128 = getenv("EXL_GEMM_TILE128") != nullptr;
         const int big_rows = tile128 ? 512 : 256;
         const bool spec = !no_spec && rows > big_rows && gshift >= 5 && (uint64_t) K * (uint64_t) N < (1ull << 32);   // loader waves: power-of-two groups, 32-bit weight offsets
