@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""In-flight-register lint for the gfx950 code objects inside libexl_amd.so.
+
+Why: the hand-scheduled GEMM kernels issue their global loads from inline asm and count `s_waitcnt vmcnt(N)` by hand.  The
+compiler does not know that such a load is still WRITING its destination registers after the asm statement: if the value is
+dead in the source (the "redundant" last fetches of a straight-line loop) it may hand those registers to something else before
+the wait that covers the load -- round 2's 400 x 11008 garbage was exactly that: accumulators shuffled through
+v4..v7 while a dwordx4 was still landing there.
+
+What: disassembles every kernel, replays the vector-memory queue the way the hardware counts it on gfx9-family parts (loads,
+LDS-DMA loads and stores all take a vmcnt slot and retire in issue order; `s_waitcnt vmcnt(N)` leaves the youngest N
+outstanding) as a forward dataflow over the control-flow graph, and reports every instruction that reads or writes a VGPR an
+outstanding load has not delivered yet.  Compiler-scheduled loads pass by construction (the compiler's own wait insertion uses
+the same model), so every report is a hand-counting or liveness defect.
+
+    python scripts/isa_lint.py [path/to/libexl_amd.so] [--kernel SUBSTR] [-v]
+Exit code 1 when a hazard is found.  tests/test_isa_lint.py runs it over the built library.
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
+
+VM_PREFIXES = ("global_load", "global_store", "global_atomic", "buffer_load", "buffer_store", "buffer_atomic", "flat_load",
+               "flat_store", "flat_atomic", "scratch_load", "scratch_store")
+_REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+_INSN = re.compile(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):")
+_FUNC = re.compile(r"^[0-9a-f]+ <(\S+)>:")
+
+
+def code_objects(so_path, workdir):
+    """The gfx950 code objects of every translation unit bundled into the shared library."""
+    fat = os.path.join(workdir, "fat.bin")
+    subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", so_path, os.devnull], check=True)
+    blob = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+    out = []
+    for i, s in enumerate(starts):
+        part = os.path.join(workdir, f"bundle{i}.bin")
+        open(part, "wb").write(blob[s:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        co = os.path.join(workdir, f"dev{i}.co")
+        r = subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--targets={TARGET}", f"--input={part}",
+                            f"--output={co}"], capture_output=True)
+        if r.returncode == 0 and os.path.exists(co) and os.path.getsize(co) > 0:
+            out.append(co)
+    return out
+
+
+def disassemble(co):
+    """{kernel name: [(addr, mnemonic, operands)]}"""
+    txt = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+    funcs, cur = {}, None
+    for line in txt.splitlines():
+        m = _FUNC.match(line)
+        if m:
+            cur = funcs.setdefault(m.group(1), [])
+            continue
+        m = _INSN.match(line)
+        if m and cur is not None:
+            cur.append((int(m.group(3), 16), m.group(1), m.group(2)))
+    return funcs
+
+
+def vregs(text):
+    s = set()
+    for m in _REG.finditer(text):
+        if m.group(1) is not None:
+            s.add(int(m.group(1)))
+        else:
+            s.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return s
+
+
+def load_dest(mn, ops):
+    """VGPRs a vector-memory LOAD will write when it completes (empty for stores, LDS-DMA and no-return atomics)."""
+    if "_load" not in mn or "_lds" in mn or " lds" in (" " + ops):
+        return set()
+    first = ops.split(",")[0]
+    return vregs(first)
+
+
+def branch_target(addr, mn, ops):
+    if not mn.startswith(("s_cbranch", "s_branch")):
+        return None
+    m = re.match(r"(\d+)", ops)
+    if not m:
+        return None
+    simm = int(m.group(1))
+    if simm >= 0x8000:
+        simm -= 0x10000
+    return addr + 4 + 4 * simm
+
+
+def vmcnt_of(ops):
+    m = re.search(r"vmcnt\((\d+)\)", ops)
+    return int(m.group(1)) if m else None
+
+
+def lint_kernel(name, insns, verbose=False):
+    """Forward dataflow over the kernel's control-flow graph.  State: {outstanding load (address): fewest vector-memory
+    instructions issued after it on any path}; `s_waitcnt vmcnt(N)` retires every load with at least N younger ones; joins take
+    the union with the smaller age (the path on which the load is retired latest)."""
+    n = len(insns)
+    if n == 0:
+        return []
+    index = {a: i for i, (a, _, _) in enumerate(insns)}
+    targets = {}
+    leaders = {0}
+    for i, (addr, mn, ops) in enumerate(insns):
+        t = branch_target(addr, mn, ops)
+        if t is not None and t in index:
+            targets[i] = index[t]
+            leaders.add(index[t])
+        if mn.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc", "s_swappc")) and i + 1 < n:
+            leaders.add(i + 1)
+    starts = sorted(leaders)
+    block_of = {}
+    blocks = []
+    for bi, lo in enumerate(starts):
+        hi = starts[bi + 1] if bi + 1 < len(starts) else n
+        blocks.append((lo, hi))
+        block_of[lo] = bi
+    succ = []
+    for (lo, hi) in blocks:
+        addr, mn, ops = insns[hi - 1]
+        out = []
+        if mn == "s_endpgm" or mn.startswith("s_setpc"):
+            pass
+        elif mn.startswith("s_branch"):
+            if hi - 1 in targets:
+                out.append(block_of[targets[hi - 1]])
+        else:
+            if mn.startswith("s_cbranch") and hi - 1 in targets:
+                out.append(block_of[targets[hi - 1]])
+            if hi < n:
+                out.append(block_of[hi])
+        succ.append(out)
+    dests = {}
+    texts = {}
+    for i, (addr, mn, ops) in enumerate(insns):
+        if mn.startswith(VM_PREFIXES):
+            d = load_dest(mn, ops)
+            if d:
+                dests[addr] = d
+                texts[addr] = f"{mn} {ops}"
+    AGE_CAP = 64
+
+    def transfer(state, lo, hi, report):
+        state = dict(state)
+        for i in range(lo, hi):
+            addr, mn, ops = insns[i]
+            if mn == "s_waitcnt":
+                k = vmcnt_of(ops)
+                if k is not None:
+                    state = {a: g for a, g in state.items() if g < k}
+                continue
+            if report is not None and state:
+                # a load may target registers an older load is still writing (in-order return: the younger one wins, and the wait
+                # that covers it covers the older one); only its address operands count
+                touched = vregs(ops.split(",", 1)[1] if addr in dests and "," in ops else ops)
+                if touched:
+                    for qa in state:
+                        both = touched & dests[qa]
+                        if both and qa != addr:
+                            report.setdefault((qa, addr), (name, addr, f"{mn} {ops}", qa, texts[qa], sorted(both)))
+            if mn.startswith(VM_PREFIXES):
+                state = {a: min(g + 1, AGE_CAP) for a, g in state.items()}
+                if addr in dests:
+                    state[addr] = 0
+        return state
+
+    def merge(a, b):
+        out = dict(a)
+        for k, g in b.items():
+            out[k] = min(out.get(k, AGE_CAP), g)
+        return out
+
+    ins = [None] * len(blocks)
+    ins[0] = {}
+    work = [0]
+    while work:
+        b = work.pop()
+        out = transfer(ins[b], blocks[b][0], blocks[b][1], None)
+        for s2 in succ[b]:
+            new = out if ins[s2] is None else merge(ins[s2], out)
+            if ins[s2] is None or new != ins[s2]:
+                ins[s2] = new
+                work.append(s2)
+    report = {}
+    for b, (lo, hi) in enumerate(blocks):
+        if ins[b] is not None:
+            transfer(ins[b], lo, hi, report)
+    return list(report.values())
+
+
+def lint_library(so_path, kernel_filter=None, verbose=False):
+    """-> (number of kernels checked, [hazard tuples])"""
+    hazards, count = [], 0
+    with tempfile.TemporaryDirectory() as wd:
+        for co in code_objects(so_path, wd):
+            for name, insns in disassemble(co).items():
+                if kernel_filter and kernel_filter not in name:
+                    continue
+                if not insns:
+                    continue
+                count += 1
+                hz = lint_kernel(name, insns, verbose)
+                if verbose:
+                    print(f"{name[:100]}: {len(insns)} instructions, {len(hz)} hazards")
+                hazards += hz
+    return count, hazards
+
+
+def main(argv):
+    args = [a for a in argv[1:] if not a.startswith("-")]
+    verbose = "-v" in argv
+    kf = None
+    if "--kernel" in argv:
+        kf = argv[argv.index("--kernel") + 1]
+        args = [a for a in args if a != kf]
+    so = args[0] if args else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "exllama_amd", "libexl_amd.so")
+    count, hazards = lint_library(so, kf, verbose)
+    for (name, addr, text, qa, qtext, regs) in hazards:
+        print(f"HAZARD {name[:90]}\n   {addr:#x}: {text}\n   touches v{regs} while the load at {qa:#x} is outstanding: {qtext}")
+    print(f"{count} kernels checked, {len(hazards)} hazards")
+    return 1 if hazards else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv))

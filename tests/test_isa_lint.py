@@ -1,0 +1,71 @@
+"""The in-flight-register lint (scripts/isa_lint.py) over the built gfx950 code objects: no instruction may touch a VGPR that an
+outstanding (inline-asm, hand-counted) global load has not delivered yet.  Guards the defect class of DESIGN.md 9.5."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import isa_lint  # noqa: E402
+
+LIB = os.path.join(ROOT, "exllama_amd", "libexl_amd.so")
+
+
+def _k(lines):
+    """[(mnemonic, operands)] -> instruction list at 4-byte spacing."""
+    return [(0x100 + 4 * i, mn, ops) for i, (mn, ops) in enumerate(lines)]
+
+
+def test_lint_flags_a_register_reused_under_an_outstanding_load():
+    # the round-2 defect in miniature: a "dead" load destination used to move an accumulator before the covering wait
+    bad = _k([("global_load_dwordx4", "v[4:7], v[4:5], off"),
+              ("v_accvgpr_read_b32", "v4, a28"),
+              ("v_accvgpr_write_b32", "a0, v4"),
+              ("s_waitcnt", "vmcnt(0)"),
+              ("s_endpgm", "")])
+    hz = isa_lint.lint_kernel("bad", bad)
+    assert len(hz) == 2 and all(h[5] == [4] for h in hz)
+    good = _k([("global_load_dwordx4", "v[4:7], v[4:5], off"),
+               ("v_accvgpr_read_b32", "v20, a28"),
+               ("s_waitcnt", "vmcnt(0)"),
+               ("v_accvgpr_write_b32", "a0, v4"),
+               ("s_endpgm", "")])
+    assert isa_lint.lint_kernel("good", good) == []
+
+
+def test_lint_counts_the_queue_like_the_hardware():
+    # vmcnt(N) leaves the youngest N outstanding; LDS-DMA and stores take a slot but deliver no register
+    k = _k([("global_load_dwordx4", "v[8:11], v[0:1], off"),
+            ("global_load_lds_dwordx4", "v[2:3], off"),
+            ("global_store_dwordx2", "v[12:13], v[14:15], off"),
+            ("s_waitcnt", "vmcnt(2)"),
+            ("v_add_u32_e32", "v8, v8, v9"),                       # the dwordx4 is the third-youngest: delivered
+            ("global_load_dword", "v16, v[0:1], off"),
+            ("s_waitcnt", "vmcnt(1)"),
+            ("v_mov_b32_e32", "v17, v16"),                         # one op may still be out, and v16 is the youngest
+            ("s_endpgm", "")])
+    hz = isa_lint.lint_kernel("k", k)
+    assert [h[5] for h in hz] == [[16]]
+
+
+def test_lint_follows_loops_and_joins():
+    # loop-carried: the load issued at the bottom of the body is still out when the top of the next iteration reads v5;
+    # the exit path waits first and is clean
+    k = _k([("v_mov_b32_e32", "v5, 0"),
+            ("v_add_u32_e32", "v6, v5, v6"),                       # 0x104: loop head
+            ("global_load_dword", "v5, v[0:1], off"),
+            ("s_cbranch_scc1", str((0x104 - (0x10c + 4)) // 4 & 0xFFFF)),
+            ("s_waitcnt", "vmcnt(0)"),
+            ("v_add_u32_e32", "v7, v5, v6"),
+            ("s_endpgm", "")])
+    hz = isa_lint.lint_kernel("loop", k)
+    assert [(h[1], h[5]) for h in hz] == [(0x104, [5])]
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="library not built (python __graft_entry__.py build)")
+@pytest.mark.skipif(not os.path.exists(os.path.join(isa_lint.LLVM, "llvm-objdump")), reason="no ROCm LLVM tools")
+def test_built_library_has_no_in_flight_register_hazard():
+    count, hazards = isa_lint.lint_library(LIB)
+    assert count > 100                                             # every translation unit's kernels were found
+    assert hazards == [], "\n".join(f"{h[0][:80]} {h[1]:#x}: {h[2]}  <- {h[4]}" for h in hazards[:10])
