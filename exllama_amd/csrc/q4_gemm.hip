@@ -280,12 +280,12 @@ __device__ unsigned long long g_gemm_probe[1024 * 8 * 4];
 // zero fragments (P starts as 0), the last two steps re-fetch the last tile instead of branching (straight-line loop:
 // every hand-counted wait stays unconditional).
 // ---------------------------------------------------------------------------------------------------------------
-template <int WAVES_M, int WAVES_N, int TM, int TN>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int KS>      // KS: 1, or 2 = the K range is cut in two, fp32 slices go to `ws`
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void q4_gemm_t16m_kernel(const f16* __restrict__ x, const uint4* __restrict__ qw,
                                                                const uint32_t* __restrict__ qzeros,
                                                                const f16* __restrict__ scales, f16* __restrict__ out, int M,
                                                                int K, int N, int gshift, int groupsize, int no_zero, int mtiles,
-                                                               int ntiles)
+                                                               int ntiles, float* __restrict__ ws)
 {
     static_assert(WAVES_N * TN == 8, "block is 128 columns wide");
     static_assert(TM == 4 && TN == 4, "the MFMA groups below are written for 4 x 4 tiles per wave");
@@ -302,8 +302,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void q4_gemm_t16m_kernel(co
     const int b = blockIdx.x;
     const int xcd = b & 7;
     const int idx = b >> 3;
-    const int nl = idx / mtiles;
-    const int mt = idx - nl * mtiles;
+    const int nl = idx / (mtiles * KS);
+    const int rem = idx - nl * (mtiles * KS);
+    const int kz = KS == 1 ? 0 : rem / mtiles;                        // which part of K (all row tiles of a part are neighbours: shared weights)
+    const int mt = KS == 1 ? rem : rem - kz * mtiles;
     const int nt = nl * 8 + xcd;
     if (nt >= ntiles) return;
     const int m0 = mt * TBM;
@@ -314,7 +316,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void q4_gemm_t16m_kernel(co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int RB = K >> 7;
-    const int nk = K / GT_BK;                                         // even (K % 128 == 0)
+    const int nk = K / GT_BK / KS;                                    // K steps of this block: even (K % (128 KS) == 0)
+    const int it0 = kz * nk;                                          // its first K tile
 
     uint32_t a_off[APW];                                               // element offsets from x (M * K < 2^32 checked on the host)
 #pragma unroll
@@ -421,11 +424,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void q4_gemm_t16m_kernel(co
     // ---- prologue: batches 0 and 1 in flight, B(0) dequantised --------------------------------------------------------
     BRegs rX, rY;
 #pragma unroll
-    for (int i = 0; i < APW; ++i) stage_a(i, 0, 0);
-    issue_w(0, rX); issue_zs(0, rX);
+    for (int i = 0; i < APW; ++i) stage_a(i, 0, it0 * GT_BK);
+    issue_w(it0, rX); issue_zs(it0, rX);
 #pragma unroll
-    for (int i = 0; i < APW; ++i) stage_a(i, 1, GT_BK);                  // nk >= 2 always
-    issue_w(1, rY); issue_zs(1, rY);
+    for (int i = 0; i < APW; ++i) stage_a(i, 1, (it0 + 1) * GT_BK);      // nk >= 2 always
+    issue_w(it0 + 1, rY); issue_zs(it0 + 1, rY);
     GM_WAIT("7", rX);                                                     // batch 0 landed (batch 1 may still fly)
 #pragma unroll
     for (int j = 0; j < PW; ++j) store_word(0, rX, j);
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void q4_gemm_t16m_kernel(co
     auto ring = [](int s, int d) { const int v = s + d; return v >= 3 ? v - 3 : v; };
     // one K step; rI receives the packed weights of tile t+2, rW holds tile t+1 (landing), bcur = LDS slot of B(t)
     auto step = [&](int t, BRegs& rI, BRegs& rW, int bcur) {
-        const int tf = min(t + 2, nk - 1);                                // the last two steps re-fetch the last tile (never read)
+        const int tf = it0 + min(t + 2, nk - 1);                          // the last two steps re-fetch the last tile (never read)
         const int adma = ring(a_slot, 2);
         GP_CLK(c0);
         GM_MFMA2(P, 0);   stage_a(0, adma, tf * GT_BK);  GM_SB();
@@ -501,6 +504,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void q4_gemm_t16m_kernel(co
             for (int in = 0; in < TN; ++in) {
                 const int n = n0 + (wn * TN + in) * 16 + fk * 4;
                 if (n < N) {
+                    if constexpr (KS > 1) {                               // fp32 slice of this K part; q4_gemm_splitk_reduce_kernel adds them up
+                        *(f32x4*) (ws + ((size_t) kz * M + row) * N + n) = acc[in][im];
+                        continue;
+                    }
                     f16* op = out + (size_t) row * N + n;
                     float v[4] = {acc[in][im][0], acc[in][im][1], acc[in][im][2], acc[in][im][3]};
                     if (no_zero) {
@@ -513,6 +520,27 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void q4_gemm_t16m_kernel(co
             }
         }
     }
+}
+
+// out (+)= sum of the KS fp32 slices of the split-K form above (4 columns per thread)
+__global__ __launch_bounds__(256) void q4_gemm_splitk_reduce_kernel(const float* __restrict__ ws, f16* __restrict__ out, size_t cells4,
+                                                                    size_t slice, int ks, int no_zero)
+{
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= cells4) return;
+    f32x4 v = *(const f32x4*) (ws + i * 4);
+    for (int z = 1; z < ks; ++z) {
+        const f32x4 u = *(const f32x4*) (ws + (size_t) z * slice + i * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += u[j];
+    }
+    f16* op = out + i * 4;
+    if (no_zero) {
+        const f16x4 prev = *(const f16x4*) op;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += (float) prev[j];
+    }
+    *(f16x4*) op = (f16x4){(f16) v[0], (f16) v[1], (f16) v[2], (f16) v[3]};
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1397,21 +1425,29 @@ int launch_q4_gemm_dual(const Q4Matrix* w1, const Q4Matrix* w2, const f16* x, in
     return 0;
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN>
+template <int WAVES_M, int WAVES_N, int TM, int TN, int KS = 1>
 static int launch_gemm_t16m(const Q4Matrix* w, const f16* xin, int rows, f16* out, int no_zero, int gshift, hipStream_t s)
 {
     constexpr int TBM = WAVES_M * TM * 16;
     const int K = w->height, N = w->width;
     const int mtiles = (rows + TBM - 1) / TBM;
     const int ntiles = (N + GT_BN - 1) / GT_BN;
-    const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
+    const int grid = 8 * ((ntiles + 7) / 8) * mtiles * KS;
     const size_t smem = 3 * (size_t) TBM * 128 + 2 * GT_BTILE_BYTES;
-    auto kfn = q4_gemm_t16m_kernel<WAVES_M, WAVES_N, TM, TN>;
+    auto kfn = q4_gemm_t16m_kernel<WAVES_M, WAVES_N, TM, TN, KS>;
     static bool big[EXL_MAX_DEVICES] = {};
     if (smem > 64 * 1024) EXL_TRY(exl_lds_opt_in((const void*) kfn, big));
+    float* ws = nullptr;
+    if constexpr (KS > 1) EXL_TRY(exl_workspace(w->device, (size_t) KS * rows * N, &ws));
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(WAVES_M * WAVES_N * 64), smem, s, xin, (const uint4*) w->qweight, w->qzeros,
-                       w->scales, out, rows, K, N, gshift, w->groupsize, no_zero, mtiles, ntiles);
+                       w->scales, out, rows, K, N, gshift, w->groupsize, no_zero, mtiles, ntiles, ws);
     EXL_LAUNCH_CHECK();
+    if constexpr (KS > 1) {
+        const size_t cells4 = (size_t) rows * N / 4;
+        hipLaunchKernelGGL(q4_gemm_splitk_reduce_kernel, dim3((unsigned) ((cells4 + 255) / 256)), dim3(256), 0, s, ws, out, cells4,
+                           (size_t) rows * N, KS, no_zero);
+        EXL_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -1455,6 +1491,12 @@ int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
         const bool spec = !no_spec && rows > big_rows && gshift >= 5 && (uint64_t) K * (uint64_t) N < (1ull << 32);   // loader waves: power-of-two groups, 32-bit weight offsets
         if (spec) return launch_gemm_t16w(w, xin, rows, out, no_zero, gshift, s);                 // 256 x 128, 8 MFMA waves + 4 loader waves
         if (rows > big_rows) return launch_gemm_t16m<4, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s);  // 256 x 128, 8 waves
+        // EXL_GEMM_SPLITK=1 (with EXL_GEMM_TILE128=1): K cut in two for 257 .. 512 rows, 2 x the blocks of half the length; fp32
+        // slices in the workspace + a reduce kernel.  Measured 0.386 -> 0.303 ms per 7B layer at 300 rows in round 2 before the
+        // kernel's in-flight-register defect was understood; off until it has been re-validated.
+        static const bool splitk = getenv("EXL_GEMM_SPLITK") != nullptr;
+        if (splitk && rows > 256 && K % 256 == 0 && N % 4 == 0 && (size_t) 2 * rows * N <= exl_buffers(w->device)->workspace_floats)
+            return launch_gemm_t16m<2, 2, 4, 4, 2>(w, xin, rows, out, no_zero, gshift, s);
         return launch_gemm_t16m<2, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s);                // 128 x 128, 4 waves
     }
     if (w->layout == EXL_LAYOUT_T16)
