@@ -7,10 +7,13 @@
 //                            the packed word is the per-lane B fragment of v_mfma_f32_32x32x16_f16, dequantised in
 //                            registers by every wave; the activation tile goes through LDS in the nibble order;
 //   q4_gemm_t16m_kernel      T16 layout, weights dequantised ONCE per block into an LDS tile, mid-step barrier schedule
-//                            (<= 512 rows: 128 x 128 tile; also the fallback of the next one);
-//   q4_gemm_t16w_kernel<EPI> the default above 512 rows: 8 MFMA waves + 4 loader waves on a 256 x 128 tile; EPI 1 is the
-//                            q/k/v projection with RoPE and the KV-cache write as its epilogue;
-//   q4_gemm_t16d_kernel      gate and up projections of the MLP in one kernel with the SiLU epilogue;
+//                            (256 x 128 tile: the fallback of the next one; 128 x 128 tile, optionally with K cut in two:
+//                            EXL_GEMM_TILE128 / EXL_GEMM_SPLITK, see launch_q4_gemm);
+//   q4_gemm_t16w_kernel<EPI> the default above 256 rows: 8 MFMA waves + 4 loader waves on a 256 x 128 tile; EPI 1 is the
+//                            q/k/v projection with RoPE and the KV-cache write as its epilogue (> 512 rows);
+//   q4_gemm_t16d2_kernel     gate and up projections of the MLP in one kernel with the SiLU epilogue, software-pipelined
+//                            (> 512 rows; q4_gemm_t16d_kernel is its un-pipelined predecessor);
+//   (q4_gemm_skinny.hip)     <= 256 rows: the decode-shaped short-prompt kernel;
 //   half_gemm_kernel         plain fp16 GEMM of the LoRA path (correctness first).
 // Act-order weights: x is gathered through x_map by column_remap into the borrowed temp_state buffer first
 // (same as the reference, q4_matmul.cu:320-325); folding the gather into the A-tile load is future work.
@@ -265,7 +268,7 @@ __device__ unsigned long long g_gemm_probe[1024 * 8 * 4];
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------
-// Mid-step barrier schedule (<= 512 rows, and the fallback of the wave-specialised kernel).  Stall attribution of its
+// Mid-step barrier schedule (the fallback of the wave-specialised kernel; 128-row tile variant behind EXL_GEMM_TILE128).  Stall attribution of its
 // predecessor, which loaded, dequantised and multiplied tile by tile (scripts/probe_gemm.hip, profiles/r01_gemm_ablation.txt):
 // of ~2100 cycles per K step only ~1000 were MFMA issue; after every barrier both waves of a
 // SIMD wait for their first fragments, and the dequant + LDS store (300 cycles) and the barrier (150-500) run with an
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(256) void q4_gemm_splitk_reduce_kernel(const float*
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Wave-specialised version of the same 256 x 128 x 64 tile (the default for > 512 rows).  Stall attribution of the
+// Wave-specialised version of the same 256 x 128 x 64 tile (the default for > 256 rows).  Stall attribution of the
 // kernels above (scripts/probe_gemm.hip): the half step that carries the 4 LDS-DMA instructions + 3 loads of a wave takes
 // 640 cycles for the older and 1030 for the younger wave of a SIMD instead of 256 -- the CU's vector-memory pipe takes
 // ~16 cycles per wave instruction (32 KiB of activations per K step = 512 cycles) and a wave stalled on a VMEM issue
