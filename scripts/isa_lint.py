@@ -10,7 +10,8 @@ v4..v7 while a dwordx4 was still landing there.
 What: disassembles every kernel, replays the vector-memory queue the way the hardware counts it on gfx9-family parts (loads,
 LDS-DMA loads and stores all take a vmcnt slot and retire in issue order; `s_waitcnt vmcnt(N)` leaves the youngest N
 outstanding) as a forward dataflow over the control-flow graph, and reports every instruction that reads or writes a VGPR an
-outstanding load has not delivered yet.  Compiler-scheduled loads pass by construction (the compiler's own wait insertion uses
+outstanding load has not delivered yet, and every `s_endpgm` reached with an LDS-DMA load (`global_load_lds_*`) still outstanding
+(it would land in the LDS of the next block on that CU).  Compiler-scheduled loads pass by construction (the compiler's own wait insertion uses
 the same model), so every report is a hand-counting or liveness defect.
 
     python scripts/isa_lint.py [path/to/libexl_amd.so] [--kernel SUBSTR] [-v]
@@ -84,6 +85,10 @@ def load_dest(mn, ops):
     return vregs(first)
 
 
+def is_lds_dma(mn, ops):
+    return "_load" in mn and ("_lds" in mn or " lds" in (" " + ops))
+
+
 def branch_target(addr, mn, ops):
     if not mn.startswith(("s_cbranch", "s_branch")):
         return None
@@ -145,7 +150,7 @@ def lint_kernel(name, insns, verbose=False):
     for i, (addr, mn, ops) in enumerate(insns):
         if mn.startswith(VM_PREFIXES):
             d = load_dest(mn, ops)
-            if d:
+            if d or is_lds_dma(mn, ops):                              # LDS-DMA: tracked with an empty register set (end-of-program rule)
                 dests[addr] = d
                 texts[addr] = f"{mn} {ops}"
     AGE_CAP = 64
@@ -159,6 +164,11 @@ def lint_kernel(name, insns, verbose=False):
                 if k is not None:
                     state = {a: g for a, g in state.items() if g < k}
                 continue
+            if report is not None and state and mn == "s_endpgm":
+                # a DMA into LDS that outlives its block lands in the LDS of whichever block the CU runs next
+                for qa in state:
+                    if not dests[qa]:
+                        report.setdefault((qa, addr), (name, addr, "s_endpgm", qa, texts[qa], []))
             if report is not None and state:
                 # a load may target registers an older load is still writing (in-order return: the younger one wins, and the wait
                 # that covers it covers the older one); only its address operands count

@@ -63,6 +63,20 @@ def test_lint_follows_loops_and_joins():
     assert [(h[1], h[5]) for h in hz] == [(0x104, [5])]
 
 
+def test_lint_flags_an_lds_dma_that_outlives_the_block():
+    bad = _k([("global_load_lds_dwordx4", "v[2:3], off"),
+              ("global_load_dword", "v9, v[0:1], off"),
+              ("s_waitcnt", "vmcnt(1)"),                           # covers the DMA ...
+              ("s_endpgm", "")])
+    assert isa_lint.lint_kernel("ok", bad) == []
+    bad = _k([("global_load_dword", "v9, v[0:1], off"),
+              ("global_load_lds_dwordx4", "v[2:3], off"),
+              ("s_waitcnt", "vmcnt(1)"),                           # ... this one only the register load
+              ("s_endpgm", "")])
+    hz = isa_lint.lint_kernel("bad", bad)
+    assert len(hz) == 1 and hz[0][2] == "s_endpgm"
+
+
 @pytest.mark.skipif(not os.path.exists(LIB), reason="library not built (python __graft_entry__.py build)")
 @pytest.mark.skipif(not os.path.exists(os.path.join(isa_lint.LLVM, "llvm-objdump")), reason="no ROCm LLVM tools")
 def test_built_library_has_no_in_flight_register_hazard():
