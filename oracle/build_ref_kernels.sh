@@ -2,8 +2,8 @@
 # TEST INFRASTRUCTURE ONLY -- builds the REFERENCE's own GPU kernels as a comparator for the oracle.
 #
 # The reference's exllama_ext/cuda_func/*.cu are CUDA sources.  This recipe translates them with ROCm's stock
-# hipify-perl FROM WHERE THEY LIE under /root/reference into oracle/_ref/src/ (git-ignored build output: no reference
-# source is ever committed), applies the one fix they need on ROCm >= 5.6 (hip_compat.cuh:4-15 re-defines hrcp / h2rcp with
+# hipify-perl FROM WHERE THEY LIE under /root/reference into a temporary directory OUTSIDE the repository (removed when the
+# script ends: no reference source, translated or not, is ever left in the tree), applies the one fix they need on ROCm >= 5.6 (hip_compat.cuh:4-15 re-defines hrcp / h2rcp with
 # a __half -> __fp16 conversion that no longer exists; the native hrcp / h2rcp of hip_fp16.h are used instead), and
 # compiles them together with oracle/ref_shim.cpp (a plain C ABI over the reference's *_cuda entry points) into
 # oracle/_ref/libexl_ref_kernels.so for gfx950.  hipcc cross-compiles: this runs in the build container, the .so travels
@@ -14,14 +14,15 @@ set -euo pipefail
 REF=${REF:-/root/reference}
 HERE=$(cd "$(dirname "$0")" && pwd)
 OUT=$HERE/_ref
-SRC=$OUT/src
+SRC=$(mktemp -d /tmp/exl_ref_kernels.XXXXXX)
+trap 'rm -rf "$SRC"' EXIT
 EXT=$REF/exllama_ext
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 HIPIFY=${HIPIFY:-/opt/rocm/bin/hipify-perl}
 
 [ -d "$EXT" ] || { echo "reference sources not found at $EXT (GPU box: use the prebuilt oracle/_ref/*.so)"; exit 0; }
-rm -rf "$SRC"
-mkdir -p "$SRC/cuda_func" "$SRC/stub/ATen/cuda"
+rm -rf "$OUT/src"                                  # translated sources of earlier versions of this recipe
+mkdir -p "$OUT" "$SRC/cuda_func" "$SRC/stub/ATen/cuda" "$SRC/obj"
 
 for f in cuda_buffers.cu cuda_buffers.cuh cuda_compat.cuh hip_compat.cuh matrix.cuh tuning.h util.cuh \
          cuda_func/column_remap.cu cuda_func/column_remap.cuh cuda_func/half_matmul.cu cuda_func/half_matmul.cuh \
@@ -57,12 +58,11 @@ FLAGS="--offload-arch=gfx950 -O2 -std=c++17 -fPIC -DUSE_ROCM -D__HIP_PLATFORM_AM
 OBJS=""
 for f in cuda_buffers cuda_func/column_remap cuda_func/half_matmul cuda_func/q4_attn cuda_func/q4_matmul \
          cuda_func/q4_matrix cuda_func/q4_mlp cuda_func/rms_norm cuda_func/rope; do
-    o=$OUT/obj_$(basename $f).o
+    o=$SRC/obj/$(basename $f).o
     "$HIPCC" $FLAGS -c "$SRC/$f.hip" -o "$o" &
     OBJS="$OBJS $o"
 done
-"$HIPCC" $FLAGS -x hip -c "$HERE/ref_shim.cpp" -o "$OUT/obj_ref_shim.o" &
+"$HIPCC" $FLAGS -x hip -c "$HERE/ref_shim.cpp" -o "$SRC/obj/ref_shim.o" &
 wait
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC $OBJS "$OUT/obj_ref_shim.o" -L/opt/rocm/lib -lhipblas -o "$OUT/libexl_ref_kernels.so"
-rm -f $OBJS "$OUT/obj_ref_shim.o"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC $OBJS "$SRC/obj/ref_shim.o" -L/opt/rocm/lib -lhipblas -o "$OUT/libexl_ref_kernels.so"
 echo "built $OUT/libexl_ref_kernels.so"

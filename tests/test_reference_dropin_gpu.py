@@ -1,11 +1,13 @@
-"""The north star's drop-in claim, executed: the reference's UNMODIFIED model.py (/root/reference/model.py, staged by
-scripts/stage_reference_py.sh into the git-ignored oracle/_ref/refpy/ so that it reaches the GPU box) builds ITS ExLlama
+"""The north star's drop-in claim, executed: the reference's UNMODIFIED model.py (/root/reference/model.py, packed by
+scripts/stage_reference_py.sh into the git-ignored archive oracle/_ref/refpy.tgz so that it reaches the GPU box, unpacked
+into a temporary directory here: no reference source file is ever left in the tree) builds ITS ExLlama
 class on a synthetic checkpoint, with `import cuda_ext` resolving to this repository's shim (cuda_ext.py at the repo root ->
 exllama_amd.cuda_ext -> the C ABI -> the HIP kernels), and its logits are compared with exllama_amd.model.ExLlama and with
 the CPU oracle model on the same tokens.  Skipped where the staged copy is absent."""
 import importlib
 import os
 import sys
+import tarfile
 
 import numpy as np
 import pytest
@@ -17,13 +19,20 @@ from oracle.model_oracle import OracleLlama
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REFPY = os.path.join(ROOT, "oracle", "_ref", "refpy")
+ARCHIVE = os.path.join(ROOT, "oracle", "_ref", "refpy.tgz")
+REFPY = None                                              # set by the fixture: where the archive was unpacked
 
 
 @pytest.fixture(scope="module")
-def ref_model_module():
-    if not os.path.exists(os.path.join(REFPY, "model.py")):
+def ref_model_module(tmp_path_factory):
+    global REFPY
+    if not os.path.exists(ARCHIVE):
         pytest.skip("reference model.py not staged (scripts/stage_reference_py.sh)")
+    REFPY = str(tmp_path_factory.mktemp("refpy"))
+    with tarfile.open(ARCHIVE) as tf:
+        for member in tf.getmembers():
+            assert member.name in ("model.py", "lora.py", "generator.py") and member.isfile()
+        tf.extractall(REFPY)
     for p in (REFPY, ROOT):                               # ROOT first: `import cuda_ext` must be OUR shim
         if p in sys.path:
             sys.path.remove(p)
