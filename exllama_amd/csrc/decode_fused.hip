@@ -20,67 +20,11 @@
 // Every GEMV block streams one contiguous 16-column weight tile over the FULL K range (T16 layout, gemv_t16.h), so
 // there is no split-K, no partial-sum slab, no atomics: results are bit-reproducible run to run.  The position is
 // read from device memory, so one captured graph serves every context length.
-#include "gemv_t16.h"
+#include "decode_args.h"
 
 #include <vector>
 #include <stdlib.h>
 
-#define DEC_MAX_MATS 3
-#define DEC_MAX_NSPLIT 16
-#define DEC_ATT_MAX_KEYS 1024
-#define DEC_WAVES 8
-#define DEC_THREADS (DEC_WAVES * 64)
-
-T16Matrix t16_view(const Q4Matrix* m);          // q4_gemv.hip
-
-struct DecGemvArgs {
-    // ---- prologue: the activation vector of length K staged in LDS ----
-    const f16* vec;               // PNORM 0: plain fp16 [K];  PNORM 1: residual stream [h] (or the embedding table when tok)
-    const int64_t* tok;           // PNORM 1, layer 0: token id (device)
-    const f16* norm_w;            // PNORM 1
-    float eps;
-    f16* hid_copy;                // PNORM 1 with tok: block 0 stores the embedding row here (start of the residual stream)
-    const float* att_ml;          // PNORM 3: (max, sum) of every (head, split) of the attention kernel; vec = their fp16 outputs
-    int att_nsplit;               // PNORM 3
-    // ---- matrices; 16-column tiles are numbered across them in order ----
-    int nmat;
-    T16Matrix mat[DEC_MAX_MATS];
-    int tile_end[DEC_MAX_MATS];   // cumulative tile counts (EMODE 2: tiles of mat[0]; mat[1] is walked in lock-step)
-    // ---- epilogue ----
-    f16* out[DEC_MAX_MATS];       // EMODE 0: out[mi][n] = h(y);  EMODE 2: out[0][n] = silu(h(y_gate)) * h(y_up)
-    f16* hid_io;                  // EMODE 1: hid_io[n] = h(res_in[n] + y)
-    const f16* res_in;            // EMODE 1: where the residual is read (= hid_io, or a zero vector on the tensor-parallel ranks that do not own it)
-    int rb_per_wave;
-    int xs_images;                // 1, or 2 when gate and up carry different act-order maps (EMODE 2)
-    int ablate;                   // measurement only (EXL_DEC_ABLATE): 1 = skip the dequant + MFMA work, 3 = also the scale / zero loads, 4 = also the activation loads
-    int nblocks;                  // = gridDim.x (passed explicitly: the implicit-argument load is one more scalar round trip)
-    int units_lo, units_rem;      // unit count per block: units_lo + (block < units_rem)
-    int early_weights;            // 1 (default): first weight batch issued before the activation has landed; 0: EXL_DEC_X_FIRST=1
-    // act-order (reference: column_remap.cu:7-36 gathers x through x_map before every matmul):
-    const uint16_t* map16[DEC_MAX_MATS];   // gather maps of the matrices of this launch as 16-bit indices (K < 65536), or NULL:
-                                           // NULL with an act-order matrix means its input arrives ALREADY gathered (out_perm below)
-    const uint16_t* out_perm;     // EMODE 0 (mat 0 only) / EMODE 2: the consumer's inverse gather map -- column n is stored at out_perm[n],
-                                  // so that the next kernel reads its activation linearly and gathers nothing
-};
-
-// Every field of a matrix view the streaming loop touches, forced into SGPRs at the top of the kernel: the compiler
-// otherwise indexes the kernarg segment dynamically (a.mat[mi] with a computed mi), i.e. issues a scalar load, waits,
-// computes, issues the next -- six dependent round trips to a cold scalar cache (~1.4 us) before the first weight load.
-#define DEC_PIN_S(x) asm volatile("" : "+s"(x))
-// pointers: pinned as integers and rebuilt as GLOBAL pointers (an opaque generic pointer would turn every access into a
-// flat_load, which counts against both the vector-memory and the LDS wait counters)
-template <typename T>
-__device__ __forceinline__ T* dec_pin_ptr(T* p)
-{
-    uint64_t v = (uint64_t) p;
-    asm volatile("" : "+s"(v));
-    return (T*) (T __attribute__((address_space(1)))*) v;
-}
-__device__ __forceinline__ void dec_pin(T16Matrix& m)
-{
-    m.qw = dec_pin_ptr(m.qw); m.qzeros = dec_pin_ptr(m.qzeros); m.scales = dec_pin_ptr(m.scales); m.x_map = dec_pin_ptr(m.x_map);
-    DEC_PIN_S(m.N); DEC_PIN_S(m.RB); DEC_PIN_S(m.gprows); DEC_PIN_S(m.gshift);
-}
 // One wave's share of one 16-column tile.  Everything here is wave-uniform (SGPRs): a weight load is
 // (uniform base + uniform row-block offset) + lane * 16 bytes -- the saddr form, one VALU instruction for all of them.
 struct DecUnit {
@@ -159,23 +103,6 @@ __device__ __forceinline__ void dec_stage_from_lds(const f16* xlin, const uint16
         xs[idx] = __builtin_bit_cast(uint4, g);
     }
 }
-__device__ __forceinline__ T16Matrix dec_pick(const T16Matrix& m0, const T16Matrix& m1, const T16Matrix& m2, int mi)
-{
-    T16Matrix m = m0;                                                // mi is wave-uniform: scalar selects
-    if (mi == 1) m = m1;
-    if (mi == 2) m = m2;
-    return m;
-}
-
-__device__ __forceinline__ f16 silu_mul_f16(f16 x, f16 y)
-{
-    const f16 e = (f16) __expf((float) (f16) (-x));
-    const f16 sm = (f16) 1.0f + e;
-    const f16 rc = (f16) (1.0f / (float) sm);
-    const f16 v = x * rc;
-    return v * y;
-}
-
 // PNORM: 0 plain vector, 1 RMSNorm(residual stream).  EMODE: 0 store fp16, 1 residual add, 2 silu(gate) * up pair.
 // NV = 8-half vectors of the activation per thread (K <= 4096 * NV).
 //
@@ -934,6 +861,7 @@ struct Decoder {
     void* block;                  // one hipMalloc
     uint16_t* maps;               // act-order maps of all layers: per layer 2 x (6 hidden + inter) entries
     f16* zero_res;                // [h] zeros: the residual a tensor-parallel rank that does not own it adds (exl_decoder_set_tp)
+    int ring, ring_fence;         // exl_decoder_set_option: rolling-ring weight stream (decode_ring.hip) / its start-up barrier
     bool residual_owner;          // tensor parallel: only one rank adds the residual stream to its partial o_proj / down_proj sums
     int qd() const { return heads * hd; }     // width of q / attention output: = h, or this rank's heads of a tensor-parallel shard
     bool has_embed() const { return embed != nullptr; }
@@ -1005,6 +933,8 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     d->maps = (uint16_t*) (b + o_maps);
     d->zero_res = (f16*) (b + o_zero);
     d->residual_owner = true;
+    d->ring = getenv("EXL_DEC_RING") ? atoi(getenv("EXL_DEC_RING")) : 1;
+    d->ring_fence = getenv("EXL_DEC_RING_FENCE") ? atoi(getenv("EXL_DEC_RING_FENCE")) : 1;
     d->separate_merge = getenv("EXL_DEC_SEPARATE_MERGE") != nullptr;
     int bpc = 2;
     if (const char* env = getenv("EXL_DEC_BLOCKS_PER_CU")) { bpc = atoi(env); if (bpc < 1) bpc = 1; if (bpc > 4) bpc = 4; }
@@ -1175,11 +1105,12 @@ static int launch_dec_gemv_cfg(bool g16, int rbw, dim3 grid, size_t smem, hipStr
 // pnorm / emode as in dec_gemv_kernel.  mats: nmat matrices sharing K (emode 2: gate, up).
 // maps: the 16-bit gather map of every matrix (NULL entries / NULL array: the activation is read linearly -- no act-order, or a
 // producer already stored it gathered); out_perm: inverse gather map of the CONSUMER of this launch's output (EMODE 2).
-static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec, const int64_t* tok, const f16* norm_w, float eps, f16* hid_copy,
+static int launch_dec_gemv(const Decoder* dcfg, int pnorm, int emode, const f16* vec, const int64_t* tok, const f16* norm_w, float eps, f16* hid_copy,
                            int nmat, Q4Matrix* const* mats, f16* const* outs, f16* hid_io, hipStream_t s,
                            const float* att_ml = nullptr, int att_nsplit = 0, const uint16_t* const* maps = nullptr,
                            const uint16_t* out_perm = nullptr, const f16* res_in = nullptr)
 {
+    const int max_blocks = dcfg->max_blocks;
     DecGemvArgs a;
     a.vec = vec; a.tok = tok; a.norm_w = norm_w; a.eps = eps; a.hid_copy = hid_copy; a.nmat = nmat; a.hid_io = hid_io;
     a.res_in = res_in ? res_in : hid_io;
@@ -1226,6 +1157,15 @@ static int launch_dec_gemv(int max_blocks, int pnorm, int emode, const f16* vec,
     a.nblocks = (int) grid.x;
     a.units_lo = tiles / (int) grid.x;
     a.units_rem = tiles % (int) grid.x;
+    // The rolling-ring stream (decode_ring.hip) takes every launch it covers (exl_decoder_set_option / EXL_DEC_RING=0 keep
+    // dec_stream_kernel for A/B; EXL_DEC_RING_FENCE=0 drops the barrier between a block's activation requests and its first
+    // weight requests).
+    const int ring = dcfg->ring;
+    a.ring_flags = dcfg->ring_fence ? 1 : 0;
+    if (ring) {
+        const int rr = launch_dec_ring(pnorm, emode, g16, rbw, nv, (int) grid.x, two_per_cu, a, s, g_plan);
+        if (rr != 1) return rr;
+    }
     // NV (8-half activation vectors per thread) instantiations by kernel class: the normed / merged inputs have K = hidden
     // <= 8192 (NV <= 2; the merge fold only exists for hidden <= 4096), only o_proj / down_proj see K = intermediate size
 #define DEC_GO(P, E, N) launch_dec_gemv_cfg<P, E, N>(g16, rbw, grid, smem, s, a, two_per_cu)
@@ -1274,7 +1214,7 @@ static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int3
         const int64_t* tk = emb ? token_dev : nullptr;
         f16* hc = emb ? d->hid : nullptr;
         const uint16_t* maps[3] = {l.map_q, l.map_k, l.map_v};
-        return launch_dec_gemv(d->max_blocks, 1, 0, xin, tk, l.in_norm, d->eps, hc, 3, qkv, qkv_out, nullptr, s, nullptr, 0, maps);
+        return launch_dec_gemv(d, 1, 0, xin, tk, l.in_norm, d->eps, hc, 3, qkv, qkv_out, nullptr, s, nullptr, 0, maps);
     }
     case EXL_DEC_ATTN: {
         const float scale = 1.0f / sqrtf((float) d->hd);
@@ -1304,23 +1244,23 @@ static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int3
         const f16* res = d->residual_owner ? d->hid : d->zero_res;
         if (d->nsplit > 1 && dec_folds_merge(d)) {                   // merged in this kernel's prologue, then gathered through o_proj's own map
             const uint16_t* maps[1] = {l.map_o};
-            return launch_dec_gemv(d->max_blocks, 3, 1, (const f16*) d->partial, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s,
+            return launch_dec_gemv(d, 3, 1, (const f16*) d->partial, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s,
                                    d->partial + (size_t) d->heads * d->nsplit * 64, d->nsplit, maps, nullptr, res);
         }
         // the attention (one split) / merge kernel stored its output through inv_o: already in o_proj's row order, nothing to gather
-        return launch_dec_gemv(d->max_blocks, 0, 1, d->attn_out, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s, nullptr, 0, nullptr,
+        return launch_dec_gemv(d, 0, 1, d->attn_out, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s, nullptr, 0, nullptr,
                                nullptr, res);
     }
     case EXL_DEC_GATE_UP: {
         Q4Matrix* gu[2] = {l.gate, l.up};
         f16* gu_out[2] = {d->act, nullptr};
         const uint16_t* maps[2] = {l.map_gate, l.map_up};
-        return launch_dec_gemv(d->max_blocks, 1, 2, d->hid, nullptr, l.post_norm, d->eps, nullptr, 2, gu, gu_out, nullptr, s, nullptr, 0, maps,
+        return launch_dec_gemv(d, 1, 2, d->hid, nullptr, l.post_norm, d->eps, nullptr, 2, gu, gu_out, nullptr, s, nullptr, 0, maps,
                                l.inv_down);                          // the activation is stored in down_proj's row order
     }
     case EXL_DEC_DOWN: {
         Q4Matrix* dm[1] = {l.down};
-        return launch_dec_gemv(d->max_blocks, 0, 1, d->act, nullptr, nullptr, 0.f, nullptr, 1, dm, nullptr, d->hid, s, nullptr, 0, nullptr, nullptr,
+        return launch_dec_gemv(d, 0, 1, d->act, nullptr, nullptr, 0.f, nullptr, 1, dm, nullptr, d->hid, s, nullptr, 0, nullptr, nullptr,
                                d->residual_owner ? d->hid : d->zero_res);
     }
     case EXL_DEC_HEAD: {
@@ -1394,6 +1334,16 @@ extern "C" int exl_decoder_step_part(void* dec, int layer, int part, const int64
     }
     if (prev != d->device) (void) hipSetDevice(prev);
     return rc;
+}
+
+extern "C" int exl_decoder_set_option(void* dec, int option, int value)
+{
+    Decoder* d = dec_from(dec);
+    EXL_REQUIRE(d, EXL_E_INVALID, "decoder_set_option: invalid decoder");
+    if (option == EXL_DEC_OPT_RING) d->ring = value;
+    else if (option == EXL_DEC_OPT_RING_FENCE) d->ring_fence = value;
+    else EXL_FAIL(EXL_E_INVALID, "decoder_set_option: unknown option %d", option);
+    return 0;
 }
 
 extern "C" int exl_decoder_set_tp(void* dec, int residual_owner)

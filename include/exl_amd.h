@@ -264,9 +264,17 @@ int exl_decoder_hidden(void* decoder, void** out_hidden_dev);
 int exl_decoder_set_hidden(void* decoder, void* hidden_dev);
 /* Test / measurement aid: which kernel configuration one step launches for kernel class `cls` with the current KV-split
  * setting, without launching anything.  out10: [0] launched (0 = this class is folded away), GEMV classes: [1] U (16-byte
- * loads in flight per lane), [2] NP (passes), [3] G16 (group size % 128 == 0), [4] PNORM, [5] EMODE, [6] NV (8-half
+ * loads in flight per lane), [2] NP (passes), [3] kernel kind (2 = rolling-ring stream; 1 / 0 = compiler-scheduled stream, group size % 128 == 0 / 32, 64), [4] PNORM, [5] EMODE, [6] NV (8-half
  * activation vectors per thread), [7] grid, [8] dynamic LDS bytes, [9] activation images; attention / merge: [1] KV splits. */
 int exl_decoder_plan(void* decoder, int cls, int* out10);
+/* Test / measurement aid: which weight-stream kernel the GEMV classes of this decoder launch.  EXL_DEC_OPT_RING: 1 (default;
+ * environment EXL_DEC_RING) = the hand-counted rolling-ring stream wherever it covers the launch, 0 = the compiler-scheduled
+ * stream everywhere (same results bit for bit: tests compare the two).  EXL_DEC_OPT_RING_FENCE: 1 (default; EXL_DEC_RING_FENCE)
+ * = a block queues the activation requests of all its waves before any weight request.  Graphs captured before a change keep
+ * the kernels they were captured with. */
+#define EXL_DEC_OPT_RING       0
+#define EXL_DEC_OPT_RING_FENCE 1
+int exl_decoder_set_option(void* decoder, int option, int value);
 /* Tensor parallelism (not in the reference: doc/TODO.md:19; exllama_amd/tp.py): a decoder built from ONE rank's shard --
  * heads * head_dim < hidden (its own heads), its own intermediate columns, the full residual stream.  exl_decoder_step_part
  * runs a token step in pieces so that the caller can all-reduce the residual stream (exl_decoder_hidden) between them:

@@ -5,7 +5,7 @@
 mkdir -p gpurun_out
 out=gpurun_out/r03_tile128_validation.txt
 : > $out
-for i in $(seq 1 12); do
+for i in $(seq 1 8); do
     echo "== process $i" >> $out
     EXL_GEMM_TILE128=1 timeout 60 python scripts/diag_tile128.py 2>&1 | grep -v amdgpu.ids | cut -c1-300 >> $out
 done

@@ -29,6 +29,7 @@ TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
 
 VM_PREFIXES = ("global_load", "global_store", "global_atomic", "buffer_load", "buffer_store", "buffer_atomic", "flat_load",
                "flat_store", "flat_atomic", "scratch_load", "scratch_store")
+HAND_COUNTED_PREFIXES = ("_Z15dec_ring_kernel",)   # kernels that must not spill
 _REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 _INSN = re.compile(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):")
 _FUNC = re.compile(r"^[0-9a-f]+ <(\S+)>:")
@@ -75,6 +76,33 @@ def vregs(text):
         else:
             s.update(range(int(m.group(2)), int(m.group(3)) + 1))
     return s
+
+
+_PK64 = ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_pk_mov_b32")
+_SEL = re.compile(r"op_sel(_hi)?:\[([01,]+)\]")
+
+
+def read_write_regs(mn, ops):
+    """VGPRs an instruction reads or writes.  Packed-f32 instructions name 64-bit register pairs but read, per source, only the
+    halves op_sel / op_sel_hi select (hipcc pairs a live scalar with whatever register sits next to it: `v[94:95]` with
+    op_sel_hi 0 for that source never looks at v95)."""
+    if mn not in _PK64:
+        return vregs(ops)
+    sel = {"": [0, 0, 0], "_hi": [1, 1, 1]}
+    for m in _SEL.finditer(ops):
+        vals = [int(x) for x in m.group(2).split(",")]
+        sel[m.group(1) or ""] = vals + [1 if m.group(1) else 0] * (3 - len(vals))
+    fields = [f.strip() for f in re.sub(r"op_sel(_hi)?:\[[01,]+\]", "", ops).split(",") if f.strip()]
+    out = vregs(fields[0]) if fields else set()
+    for i, f in enumerate(fields[1:4]):
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", f)
+        if not m:
+            out |= vregs(f)
+            continue
+        lo = int(m.group(1))
+        halves = {sel[""][i], sel["_hi"][i]}
+        out |= {lo + h for h in halves}
+    return out
 
 
 def load_dest(mn, ops):
@@ -154,6 +182,14 @@ def lint_kernel(name, insns, verbose=False):
                 dests[addr] = d
                 texts[addr] = f"{mn} {ops}"
     AGE_CAP = 64
+    extra = []
+    if name.startswith(HAND_COUNTED_PREFIXES):
+        # every vector-memory instruction of these kernels is counted by hand: a register spill (scratch traffic takes vmcnt
+        # slots and makes hipcc drain the queue around it) silently turns the ring into a stop-and-wait loop
+        for addr, mn, ops in insns:
+            if mn.startswith("scratch_"):
+                extra.append((name, addr, f"{mn} {ops}", addr, "scratch traffic in a hand-counted kernel", []))
+                break
 
     def transfer(state, lo, hi, report):
         state = dict(state)
@@ -172,7 +208,7 @@ def lint_kernel(name, insns, verbose=False):
             if report is not None and state:
                 # a load may target registers an older load is still writing (in-order return: the younger one wins, and the wait
                 # that covers it covers the older one); only its address operands count
-                touched = vregs(ops.split(",", 1)[1] if addr in dests and "," in ops else ops)
+                touched = vregs(ops.split(",", 1)[1]) if addr in dests and "," in ops else read_write_regs(mn, ops)
                 if touched:
                     for qa in state:
                         both = touched & dests[qa]
@@ -205,7 +241,7 @@ def lint_kernel(name, insns, verbose=False):
     for b, (lo, hi) in enumerate(blocks):
         if ins[b] is not None:
             transfer(ins[b], lo, hi, report)
-    return list(report.values())
+    return list(report.values()) + extra
 
 
 def lint_library(so_path, kernel_filter=None, verbose=False):

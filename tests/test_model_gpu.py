@@ -331,22 +331,27 @@ def test_weight_arena_is_one_allocation_and_changes_nothing():
 
 
 # ---- the native decode executor at the REAL layer shapes (BASELINE configs 1-4) ------------------------------------------------
-# What bench.py times are dec_stream_kernel instantiations picked by layer shape (decode_fused.hip: launch_dec_gemv_cfg):
-# (U, NP) by row-blocks per wave, G16 by group size, NV by K, the stand-alone split merge for hidden > 4096, act-order
-# staging through x_map.  The tiny presets above only ever launch <4,1,.,.,.,1>; these cases run the executor (eager, graph
-# replay, greedy generation) on truncated models of the real dimensions against the CPU oracle model, and assert through
-# exl_decoder_plan WHICH instantiation ran, so that every configuration the benchmark launches is compared with the oracle.
-#   (U, NP, G16, PNORM, EMODE, NV) per kernel class, [1] = launched at all
+# What bench.py times are dec_ring_kernel (decode_ring.hip: the hand-counted rolling-ring weight stream) and, for what the ring
+# does not cover (group sizes 32 / 64, launches that gather through an act-order map, the deepest two-per-CU down_proj streams),
+# dec_stream_kernel instantiations picked by layer shape (decode_fused.hip: launch_dec_gemv_cfg): (U, NP) by row-blocks per
+# wave, NV by K, the stand-alone split merge for hidden > 4096, act-order staging through x_map.  The tiny presets above only
+# ever launch <4,1,.,.,.,1>; these cases run the executor (eager, graph replay, greedy generation) on truncated models of the
+# real dimensions against the CPU oracle model, and assert through exl_decoder_plan WHICH instantiation ran, so that every
+# configuration the benchmark launches is compared with the oracle.
+#   (U, NP, KIND, PNORM, EMODE, NV) per kernel class, [1] = launched at all; KIND 2 = dec_ring_kernel, 1 / 0 = dec_stream_kernel
+#   with the scale applied per row-block (group size % 128 == 0) / per k-group (group sizes 32, 64)
 _REAL_SHAPES = {
     #        name   gs   act    L  qkv                    o_proj (>1 split)       gate_up                down                   merge kernel
-    "7b":  ("7b", 128, False, 2, (4, 1, 1, 1, 0, 1), (4, 1, 1, 3, 1, 1), (4, 2, 1, 1, 2, 1), (6, 2, 1, 0, 1, 3), False),
+    "7b":  ("7b", 128, False, 2, (4, 1, 2, 1, 0, 1), (4, 1, 2, 3, 1, 1), (8, 1, 2, 1, 2, 1), (11, 1, 2, 0, 1, 3), False),
     # (U, NP) fits the row-blocks per wave exactly where it can: 13B 5 / 10 / 14, 33B 7 / 13 / 18, 65B 8 / 16 / 22, 70B 8 / 16 / 28
-    # (down_proj of 13B / 65B / 70B has more tiles than the chip has CUs: the 4-deep streams that fit two blocks per CU)
-    "13b": ("13b", 128, True, 1, (5, 1, 1, 1, 0, 2), (5, 1, 1, 0, 1, 2), (5, 2, 1, 1, 2, 2), (4, 4, 1, 0, 1, 6), True),
+    # 13B act-order: q/k/v and gate/up gather through their maps (dec_stream_kernel); o_proj / down_proj get their input already
+    # in row order (ring).  down_proj of 65B / 70B: more tiles than CUs and 22 / 28 row-blocks per wave -- the 4-deep streams
+    # that fit two blocks per CU (dec_stream_kernel)
+    "13b": ("13b", 128, True, 1, (5, 1, 1, 1, 0, 2), (5, 1, 2, 0, 1, 2), (5, 2, 1, 1, 2, 2), (7, 2, 2, 0, 1, 6), True),
     "33b": ("33b", 32, True, 1, (4, 2, 0, 1, 0, 2), (4, 2, 0, 0, 1, 2), (7, 2, 0, 1, 2, 2), (6, 3, 0, 0, 1, 6), True),
-    "65b": ("65b", 128, False, 1, (4, 2, 1, 1, 0, 2), (4, 2, 1, 0, 1, 2), (4, 4, 1, 1, 2, 2), (4, 6, 1, 0, 1, 6), True),
+    "65b": ("65b", 128, False, 1, (8, 1, 2, 1, 0, 2), (8, 1, 2, 0, 1, 2), (8, 2, 2, 1, 2, 2), (4, 6, 1, 0, 1, 6), True),
     # Llama-2-70B: GQA (8 kv heads) and K = 28672 in down_proj -- 28 row-blocks per wave, 7 -> 8 vectors per thread
-    "70b": ("70b", 128, False, 1, (4, 2, 1, 1, 0, 2), (4, 2, 1, 0, 1, 2), (4, 4, 1, 1, 2, 2), (4, 7, 1, 0, 1, 8), True),
+    "70b": ("70b", 128, False, 1, (8, 1, 2, 1, 0, 2), (8, 1, 2, 0, 1, 2), (8, 2, 2, 1, 2, 2), (4, 7, 1, 0, 1, 8), True),
 }
 
 
@@ -422,6 +427,59 @@ def test_native_decode_executor_at_real_layer_shapes(key):
                 l2 = model.forward(torch.tensor([[t1]], device="cuda:0"), c2)
                 assert got.tolist() == [t1, int(l2[0, -1].argmax())]
     assert len(seen) >= 3, seen                                      # 1 split, 4 splits and the decoder's maximum all ran
+    model.free_unmanaged()
+
+
+@pytest.mark.parametrize("key", ["7b", "13b", "65b"])
+def test_ring_stream_equals_compiler_stream_bit_for_bit(key):
+    """decode_ring.hip (every vector-memory instruction inline asm, every wait counted by hand) against dec_stream_kernel
+    (ordinary loads, hipcc's waits) on the same decoder: same arithmetic in the same order, so the logits, the appended K/V
+    rows and the greedy tokens must be IDENTICAL bit patterns -- at the real layer shapes (7B; 13B act-order, where the ring
+    takes o_proj / down_proj only; 65B two-pass gate/up), with and without the start-up barrier, in the one-split and the
+    many-split attention buckets, several tokens in a row (each step consumes what the previous one wrote).  A miscounted
+    wait shows up here as a different bit somewhere, not as a tolerance question."""
+    import ctypes as C
+    from exllama_amd import cuda_ext
+    from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
+    name, gs, act, L = _REAL_SHAPES[key][:4]
+    dims = synth.PRESETS[name]
+    tensors = synth.make_checkpoint(dims, groupsize=gs, act_order=act, seed=11, device="cpu", zeros="rand", num_layers=L)
+    cfg = ExLlamaConfig(synth.config_dict(dims, L))
+    cfg.max_seq_len = 1408
+    cfg.max_input_len = 1024
+    model = ExLlama(cfg, tensors=tensors)
+    lib = cuda_ext.exllama_ext._lib
+    rs = np.random.RandomState(9)
+    ids = torch.from_numpy(rs.randint(1, dims.vocab_size, size=(1, 1000))).to("cuda:0")
+    for P in (30, 900):
+        cache = ExLlamaCache(model)
+        model.disable_decode_graph()
+        model.forward(ids[:, :P], cache, preprocess_only=True)
+        toks = ids[0, P:P + 4].tolist()
+        runs = {}
+        for mode in ((0, 0), (1, 1), (1, 0)):                        # (ring, fence)
+            c = ExLlamaCache(model, copy_from=cache)
+            c.current_seq_len = P
+            model.enable_decode_graph(c, use_graph=False)
+            for sg in model._decoder["stages"]:
+                cuda_ext.check(lib.exl_decoder_set_option(sg["handle"], 0, mode[0]), "set_option")
+                cuda_ext.check(lib.exl_decoder_set_option(sg["handle"], 1, mode[1]), "set_option")
+            kinds = {cls: _plan(model, j)[3] for j, cls in enumerate(model.DECODER_CLASSES) if cls in ("qkv", "o_proj", "gate_up", "down")}
+            if mode[0]:
+                assert 2 in kinds.values(), kinds                    # the ring really is what ran
+            else:
+                assert 2 not in kinds.values(), kinds
+            out = [model.forward(torch.tensor([[t]], device="cuda:0"), c)[0, 0].float().cpu().numpy().copy() for t in toks]
+            kv = [c.key_states[l][0, :, P:P + 4].cpu().numpy().copy() for l in range(L)]
+            runs[mode] = (out, kv)
+        ref_out, ref_kv = runs[(0, 0)]
+        for mode in ((1, 1), (1, 0)):
+            out, kv = runs[mode]
+            for i in range(len(toks)):
+                assert np.isfinite(out[i]).all()
+                assert np.array_equal(out[i].view(np.uint32), ref_out[i].view(np.uint32)), (key, P, mode, i, float(np.abs(out[i] - ref_out[i]).max()))
+            for l in range(L):
+                assert np.array_equal(kv[l].view(np.uint16), ref_kv[l].view(np.uint16)), (key, P, mode, l)
     model.free_unmanaged()
 
 
