@@ -519,7 +519,7 @@ def decoder_roofline_probe(model, cache, dims, g, ctx, steps=6):
             traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
     except Exception:
         traffic = None
-    return {"bound": "hbm", "kernel": "dec_stream_kernel<PNORM=1, EMODE=2> (fused RMSNorm + gate/up projections + SiLU*mul, one launch per layer)",
+    return {"bound": "hbm", "kernel": "dec_ring_kernel<PNORM=1, EMODE=2> (fused RMSNorm + gate/up projections + SiLU*mul, one launch per layer)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
             "traffic_source": ("offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (scripts/gpu_r02_profiles.sh), FETCH_SIZE doubled per "

@@ -78,7 +78,6 @@ __device__ __forceinline__ f16 silu_mul_f16(f16 x, f16 y)
 }
 
 
-// decode_ring.hip: the rolling-ring stream kernels.  Returns 1 when the launch is not covered (the caller falls back to
-// dec_stream_kernel), 0 on success, an error code otherwise.  plan: exl_decoder_plan's record (or NULL).
-int launch_dec_ring(int pnorm, int emode, bool g16, int rbw, int nv, int grid, bool two_per_cu, const DecGemvArgs& a, hipStream_t s,
-                    int* plan);
+// decode_ring.hip: the rolling-ring stream kernels.  depth: loads in flight per lane (2 .. 4).  Returns 1 when the launch is not
+// covered (the caller falls back to dec_stream_kernel), 0 on success, an error code otherwise.  plan: exl_decoder_plan's record (or NULL).
+int launch_dec_ring(int pnorm, int emode, bool g16, int rbw, int nv, int grid, int depth, const DecGemvArgs& a, hipStream_t s, int* plan);

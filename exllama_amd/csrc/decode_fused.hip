@@ -861,7 +861,7 @@ struct Decoder {
     void* block;                  // one hipMalloc
     uint16_t* maps;               // act-order maps of all layers: per layer 2 x (6 hidden + inter) entries
     f16* zero_res;                // [h] zeros: the residual a tensor-parallel rank that does not own it adds (exl_decoder_set_tp)
-    int ring, ring_fence;         // exl_decoder_set_option: rolling-ring weight stream (decode_ring.hip) / its start-up barrier
+    int ring, ring_fence, ring_depth;   // exl_decoder_set_option: rolling-ring weight stream (decode_ring.hip) / its start-up barrier
     bool residual_owner;          // tensor parallel: only one rank adds the residual stream to its partial o_proj / down_proj sums
     int qd() const { return heads * hd; }     // width of q / attention output: = h, or this rank's heads of a tensor-parallel shard
     bool has_embed() const { return embed != nullptr; }
@@ -933,8 +933,9 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     d->maps = (uint16_t*) (b + o_maps);
     d->zero_res = (f16*) (b + o_zero);
     d->residual_owner = true;
-    d->ring = getenv("EXL_DEC_RING") ? atoi(getenv("EXL_DEC_RING")) : 1;
+    d->ring = getenv("EXL_DEC_RING") ? atoi(getenv("EXL_DEC_RING")) : 15;
     d->ring_fence = getenv("EXL_DEC_RING_FENCE") ? atoi(getenv("EXL_DEC_RING_FENCE")) : 1;
+    d->ring_depth = getenv("EXL_DEC_RING_DEPTH") ? atoi(getenv("EXL_DEC_RING_DEPTH")) : 4;
     d->separate_merge = getenv("EXL_DEC_SEPARATE_MERGE") != nullptr;
     int bpc = 2;
     if (const char* env = getenv("EXL_DEC_BLOCKS_PER_CU")) { bpc = atoi(env); if (bpc < 1) bpc = 1; if (bpc > 4) bpc = 4; }
@@ -1105,7 +1106,7 @@ static int launch_dec_gemv_cfg(bool g16, int rbw, dim3 grid, size_t smem, hipStr
 // pnorm / emode as in dec_gemv_kernel.  mats: nmat matrices sharing K (emode 2: gate, up).
 // maps: the 16-bit gather map of every matrix (NULL entries / NULL array: the activation is read linearly -- no act-order, or a
 // producer already stored it gathered); out_perm: inverse gather map of the CONSUMER of this launch's output (EMODE 2).
-static int launch_dec_gemv(const Decoder* dcfg, int pnorm, int emode, const f16* vec, const int64_t* tok, const f16* norm_w, float eps, f16* hid_copy,
+static int launch_dec_gemv(const Decoder* dcfg, int cls, int pnorm, int emode, const f16* vec, const int64_t* tok, const f16* norm_w, float eps, f16* hid_copy,
                            int nmat, Q4Matrix* const* mats, f16* const* outs, f16* hid_io, hipStream_t s,
                            const float* att_ml = nullptr, int att_nsplit = 0, const uint16_t* const* maps = nullptr,
                            const uint16_t* out_perm = nullptr, const f16* res_in = nullptr)
@@ -1160,10 +1161,10 @@ static int launch_dec_gemv(const Decoder* dcfg, int pnorm, int emode, const f16*
     // The rolling-ring stream (decode_ring.hip) takes every launch it covers (exl_decoder_set_option / EXL_DEC_RING=0 keep
     // dec_stream_kernel for A/B; EXL_DEC_RING_FENCE=0 drops the barrier between a block's activation requests and its first
     // weight requests).
-    const int ring = dcfg->ring;
+    const int ring = (dcfg->ring >> cls) & 1;                        // one bit per GEMV class: q/k/v, o_proj, gate/up, down_proj
     a.ring_flags = dcfg->ring_fence ? 1 : 0;
     if (ring) {
-        const int rr = launch_dec_ring(pnorm, emode, g16, rbw, nv, (int) grid.x, two_per_cu, a, s, g_plan);
+        const int rr = launch_dec_ring(pnorm, emode, g16, rbw, nv, (int) grid.x, dcfg->ring_depth, a, s, g_plan);
         if (rr != 1) return rr;
     }
     // NV (8-half activation vectors per thread) instantiations by kernel class: the normed / merged inputs have K = hidden
@@ -1214,7 +1215,7 @@ static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int3
         const int64_t* tk = emb ? token_dev : nullptr;
         f16* hc = emb ? d->hid : nullptr;
         const uint16_t* maps[3] = {l.map_q, l.map_k, l.map_v};
-        return launch_dec_gemv(d, 1, 0, xin, tk, l.in_norm, d->eps, hc, 3, qkv, qkv_out, nullptr, s, nullptr, 0, maps);
+        return launch_dec_gemv(d, 0, 1, 0, xin, tk, l.in_norm, d->eps, hc, 3, qkv, qkv_out, nullptr, s, nullptr, 0, maps);
     }
     case EXL_DEC_ATTN: {
         const float scale = 1.0f / sqrtf((float) d->hd);
@@ -1244,23 +1245,23 @@ static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int3
         const f16* res = d->residual_owner ? d->hid : d->zero_res;
         if (d->nsplit > 1 && dec_folds_merge(d)) {                   // merged in this kernel's prologue, then gathered through o_proj's own map
             const uint16_t* maps[1] = {l.map_o};
-            return launch_dec_gemv(d, 3, 1, (const f16*) d->partial, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s,
+            return launch_dec_gemv(d, 1, 3, 1, (const f16*) d->partial, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s,
                                    d->partial + (size_t) d->heads * d->nsplit * 64, d->nsplit, maps, nullptr, res);
         }
         // the attention (one split) / merge kernel stored its output through inv_o: already in o_proj's row order, nothing to gather
-        return launch_dec_gemv(d, 0, 1, d->attn_out, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s, nullptr, 0, nullptr,
+        return launch_dec_gemv(d, 1, 0, 1, d->attn_out, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s, nullptr, 0, nullptr,
                                nullptr, res);
     }
     case EXL_DEC_GATE_UP: {
         Q4Matrix* gu[2] = {l.gate, l.up};
         f16* gu_out[2] = {d->act, nullptr};
         const uint16_t* maps[2] = {l.map_gate, l.map_up};
-        return launch_dec_gemv(d, 1, 2, d->hid, nullptr, l.post_norm, d->eps, nullptr, 2, gu, gu_out, nullptr, s, nullptr, 0, maps,
+        return launch_dec_gemv(d, 2, 1, 2, d->hid, nullptr, l.post_norm, d->eps, nullptr, 2, gu, gu_out, nullptr, s, nullptr, 0, maps,
                                l.inv_down);                          // the activation is stored in down_proj's row order
     }
     case EXL_DEC_DOWN: {
         Q4Matrix* dm[1] = {l.down};
-        return launch_dec_gemv(d, 0, 1, d->act, nullptr, nullptr, 0.f, nullptr, 1, dm, nullptr, d->hid, s, nullptr, 0, nullptr, nullptr,
+        return launch_dec_gemv(d, 3, 0, 1, d->act, nullptr, nullptr, 0.f, nullptr, 1, dm, nullptr, d->hid, s, nullptr, 0, nullptr, nullptr,
                                d->residual_owner ? d->hid : d->zero_res);
     }
     case EXL_DEC_HEAD: {
@@ -1342,6 +1343,7 @@ extern "C" int exl_decoder_set_option(void* dec, int option, int value)
     EXL_REQUIRE(d, EXL_E_INVALID, "decoder_set_option: invalid decoder");
     if (option == EXL_DEC_OPT_RING) d->ring = value;
     else if (option == EXL_DEC_OPT_RING_FENCE) d->ring_fence = value;
+    else if (option == EXL_DEC_OPT_RING_DEPTH) d->ring_depth = value;
     else EXL_FAIL(EXL_E_INVALID, "decoder_set_option: unknown option %d", option);
     return 0;
 }

@@ -6,23 +6,26 @@
 // `s_waitcnt vmcnt` itself, and at every control-flow join it has to assume the path with the fewest loads in flight -- the
 // disassembly shows `vmcnt(1)` / `vmcnt(0)` in front of the consume step right after the next pass was requested, i.e. the pass
 // that was meant to stay in flight is drained first, and the second half of a tile is only requested after the block-wide
-// activation barrier.  The phase probe put the consequence at 35-50 % of a launch: the memory system idles while waves sit in
-// barriers and dequantise.
+// activation barrier.
 //
 // Here every vector-memory instruction of a wave is inline asm and every wait is counted by hand:
-//   * a wave keeps a RING of U 16-byte-per-lane loads (U KiB) in flight at all times: step (p, q) of a unit waits for slot q
-//     (`vmcnt(U - 1)`: exactly the U - 1 younger ring loads stay outstanding), consumes it (dequantise + 4 MFMA) and immediately
-//     re-requests slot q with the row-block U steps ahead -- of this unit's next pass, or of the block's NEXT unit, whose
-//     scale / zero entries travel just ahead of its first weight load;
+//   * a wave keeps a RING of U 16-byte-per-lane loads in flight: step l of a unit (UL row-blocks of one 16-column tile) waits for
+//     slot l % U, consumes it (dequantise + 4 MFMA) and immediately re-requests that slot with the row-block U steps ahead -- of
+//     this unit, or of the block's NEXT unit, whose scale / zero words travel just ahead of the weight load that first needs them
+//     (one pair of small loads per 4 row-blocks);
+//   * the ring is SHALLOW (U <= 4): a CU accepts about 2 KiB of outstanding requests per wave (measured, DESIGN.md section 3: with 8
+//     loads per wave the last wave of a block is still queueing its start-up requests when the first 120 KiB have arrived, and the
+//     block-wide activation barrier -- hence all arithmetic -- waits for it); deeper rings only move the waiting from `s_waitcnt` to
+//     the issue stage, where it also blocks the barrier;
 //   * the start-up order is what the in-order memory pipe of a CU wants: activation loads of ALL waves first (an optional bare
 //     s_barrier keeps the first weight requests of the early waves from queueing ahead of the late waves' activation loads),
-//     then the small entry loads, then the ring -- the RMSNorm / split merge / LDS-DMA copy then completes while the first U
-//     KiB per wave stream in, and nothing else is ever waited for;
-//   * steady units (a next unit exists) and the last unit of a block are two code paths with their own static wait counts, so
-//     no load is ever conditional between its issue and its wait.
+//     then the entry loads, then the ring;
+//   * steady units (a next unit exists) and the last unit of a block are two code paths, so no load is ever conditional between
+//     its issue and its wait; the wait counts are not written down by hand but computed at compile time by replaying the issue
+//     order (ring_younger below).
 // Counting rules (checked mechanically by scripts/isa_lint.py over the built library): a register an asm load is still writing
 // is an operand ("+v") of the wait that covers it; compiler-visible stores are ignored by the counts (a store in flight can
-// only make a wait stricter); there is no compiler-visible vector load after the first asm load.
+// only make a wait stricter); there is no compiler-visible vector load after the first asm load; no scratch.
 //
 // Covered: group sizes that are multiples of 128 (the scale applies to the fp32 sum of a row-block), no gather map on the
 // launch (act-order inputs arrive gathered or the launch falls back to dec_stream_kernel).
@@ -47,10 +50,13 @@ __device__ __forceinline__ void rg_ldw(u32x4& d, uint32_t voff, const void* sbas
     const uint64_t b = (uint64_t) sbase;
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t) b), hi = __builtin_amdgcn_readfirstlane((uint32_t) (b >> 32));
     const void* sb = (const void*) (((uint64_t) hi << 32) | lo);
-    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(d) : "v"(voff), "s"(sb) : "memory");
+    // s_nop 4: a VALU write of an SGPR (the v_readfirstlane above, when it is real) needs 5 wait states before a vector-memory
+    // instruction reads that SGPR as its base; hipcc pads its own instructions, never the inside of an asm statement
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt" : "=v"(d) : "v"(voff), "s"(sb) : "memory");
 }
 __device__ __forceinline__ void rg_ld16(u32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
-__device__ __forceinline__ void rg_ld8(u32x2& d, const void* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+// (8 bytes travel as one uint64_t: hipcc 7.2 reads element 0 for BOTH elements of a 2 x 32-bit ext_vector that comes out of an asm)
+__device__ __forceinline__ void rg_ld8(uint64_t& d, const void* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
 __device__ __forceinline__ void rg_ld4(uint32_t& d, const void* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
 __device__ __forceinline__ void rg_ld2(uint32_t& d, const void* p) { asm volatile("global_load_ushort %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
 // 1 KiB of global memory straight into LDS (lds_dst: wave-uniform LDS byte address; lane l lands at lds_dst + 16 l)
@@ -63,9 +69,9 @@ __device__ __forceinline__ void rg_dma16(uint32_t lds_dst, const void* gsrc)
 template <int N> __device__ __forceinline__ void rg_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void rg_wait(u32x4& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory"); }
 // after a wait: the value is only defined from here on (no consumer may be scheduled above the wait)
-__device__ __forceinline__ void rg_tie(u32x4& a) { asm volatile("" : "+v"(a) :: "memory"); }
-__device__ __forceinline__ void rg_tie(u32x2& a) { asm volatile("" : "+v"(a) :: "memory"); }
-__device__ __forceinline__ void rg_tie(uint32_t& a) { asm volatile("" : "+v"(a) :: "memory"); }
+__device__ __forceinline__ void rg_tie(u32x4& a) { asm volatile("; tie %0" : "+v"(a) :: "memory"); }
+__device__ __forceinline__ void rg_tie(uint64_t& a) { asm volatile("; tie %0" : "+v"(a) :: "memory"); }
+__device__ __forceinline__ void rg_tie(uint32_t& a) { asm volatile("; tie %0" : "+v"(a) :: "memory"); }
 // block barrier that knows nothing about vector memory: LDS traffic of this wave done, then s_barrier
 __device__ __forceinline__ void rg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -85,19 +91,78 @@ struct RingUnit {                  // wave-uniform description of one unit of th
 
 }  // namespace
 
+// Phase attribution (probe builds only, -DEXL_RING_PROBE; scripts/probe_ring.sh): shader cycles since block start at 7 points,
+// per kernel class [0 q/k/v, 1 o_proj + merge, 2 gate/up, 3 plain vector (o_proj behind the merge kernel, down_proj)].
+#ifdef EXL_RING_PROBE
+__device__ unsigned long long g_ring_probe[4 * 512 * 8];
+#define RP_CLK(i) rp_t[i] = __builtin_readcyclecounter()
+extern "C" int exl_debug_ring_probe(int cls, unsigned long long* out8)     // sums over blocks; out8[7] = number of blocks that reported
+{
+    static unsigned long long h[512 * 8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ring_probe), sizeof(h), (size_t) cls * sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    for (int b = 0; b < 512; ++b) {
+        if (!h[b * 8 + 6]) continue;
+        for (int i = 0; i < 7; ++i) out8[i] += h[b * 8 + i];
+        out8[7] += 1;
+    }
+    return 0;
+}
+#else
+#define RP_CLK(i) do { } while (0)
+#endif
+
+// ---- the issue order of a wave, replayed at compile time ------------------------------------------------------------------------
+// Unit = UL steps (row-blocks rb_lo + l of one tile); ring slot of step l = l % U.  After consuming step l a wave requests, into the
+// same slot, step l + U of the same unit or -- from the last use of a slot on -- step l % U of the NEXT unit (none in a block's
+// last unit).  The first U steps of a unit are therefore requested in the order of the previous unit's last U steps (the
+// prologue uses the same order for the first unit).  A request for a step that opens a chunk of 4 row-blocks (step % 4 == 0) is
+// preceded by the chunk's entry loads: 2, plus the residual load with chunk 0 when the epilogue adds the residual (EL0).
+constexpr int ring_entry_loads(int step, int el0) { return step % 4 == 0 ? (step == 0 ? el0 : 2) : 0; }
+// One raw entry set: the words of a chunk must have been combined before the next chunk's words are requested.  Inside a unit that
+// holds for every U <= 4 (chunk c + 1 is requested at step 4 (c + 1) - U >= 4 c); across units the next unit's chunk 0 goes out at
+// the last use of slot 0, which must not come before the last chunk of this unit is combined.
+constexpr bool ring_valid(int U, int UL) { return U >= 1 && U <= 4 && UL >= U && ((UL - 1) / U) * U >= ((UL - 1) / 4) * 4; }
+// vector-memory instructions issued after the load of step `li` and before step `li` is consumed = the N of its `s_waitcnt vmcnt(N)`
+constexpr int ring_younger(int U, int UL, int el0, bool last, int li)
+{
+    int issued = 0;                 // instructions issued so far
+    int pos = -1;                   // issue index of the load of (this unit, li)
+    for (int j = 0; j < U; ++j) {   // the previous unit's tail (or the prologue): this unit's steps (UL - U + j) % U
+        const int t = (UL - U + j) % U;
+        issued += ring_entry_loads(t, el0);
+        if (t == li) pos = issued;
+        issued += 1;
+    }
+    for (int s = 0; s < UL; ++s) {  // this unit's own steps, up to the consumption of li
+        if (s == li) return issued - (pos + 1);
+        const int T = s + U;
+        if (T < UL) {
+            issued += ring_entry_loads(T, el0);
+            if (T == li) pos = issued;
+            issued += 1;
+        } else if (!last) {
+            issued += ring_entry_loads(s % U, el0) + 1;          // next unit's step s % U
+        }
+    }
+    return 0;
+}
+
 // OCC: blocks per CU the register budget is cut for (2 -> at most 128 VGPRs, 1 -> 256).
-template <int U, int NP, int PNORM, int EMODE, int NV, int OCC>
+template <int U, int UL, int PNORM, int EMODE, int NV, int OCC>
 __global__ __launch_bounds__(DEC_THREADS, 2 * OCC) void dec_ring_kernel(const DecGemvArgs a)
 {
-    constexpr int UL = U * NP;                                       // row-block slots per wave and unit
-    constexpr int NSLOT = (U + 3) / 4;                               // entry words per lane and PASS (one per 4 row-blocks)
+    static_assert(ring_valid(U, UL), "one raw entry set: see ring_valid");
     constexpr int WPT = EMODE == 2 ? DEC_WAVES / 2 : DEC_WAVES;      // waves per tile
-    constexpr int EL = 2 * NSLOT + (EMODE == 1 ? 1 : 0);             // small loads that travel ahead of a pass' first weight load
+    constexpr int EL0 = 2 + (EMODE == 1 ? 1 : 0);                    // entry loads of chunk 0 (with the residual value of the column)
     constexpr int IMG_ROWS = WPT * UL * 16 > NV * DEC_THREADS ? WPT * UL * 16 : NV * DEC_THREADS;   // packed rows of the image (zero padded)
     constexpr int MS = PNORM == 3 ? DEC_MAX_NSPLIT : 1;
     static_assert(PNORM != 3 || NV == 1, "the merge prologue holds one 8-dim vector per thread");
-    static_assert(U + EL + 2 * NV + MS + 1 < 60, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef EXL_RING_PROBE
+    unsigned long long rp_t[7] = {0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long rp_t0 = __builtin_readcyclecounter();
+#endif
 
     // ---- 0. kernel arguments into SGPRs (one batch of scalar loads) ----------------------------------------------------------
     T16Matrix M0 = a.mat[0], M1 = a.mat[1], M2 = a.mat[2];
@@ -147,43 +212,37 @@ __global__ __launch_bounds__(DEC_THREADS, 2 * OCC) void dec_ring_kernel(const De
 
     // ---- ring state ---------------------------------------------------------------------------------------------------------
     u32x4 ring[U];
-    uint32_t rz[NSLOT], rs[NSLOT], rres = 0;                         // raw scale / zero words (and the residual) of the pass in flight
-    uint32_t ent[NSLOT];                                             // entries of the pass being consumed
-    auto issue_w = [&](const RingUnit& u, auto qc, int li) {        // slot q <- row-block rb_lo + li of unit u (clamped: always a valid address)
-        constexpr int q = decltype(qc)::value;
-        const int rb = min(rb_lo + li, RB - 1);
-        rg_ldw(ring[q], lane16, u.wbase + (size_t) (uint32_t) rb * 1024u);
-    };
-    // The scale / zero words of pass p of unit u -- slot h of lane (rsub, col): row-block p U + 4 h + rsub, column col -- and the
-    // residual value of the unit's column: EL loads, in this order, issued just ahead of the pass' first weight load.
-    auto issue_entries = [&](const RingUnit& u, int p) {
-        const int n = u.n0 + col;
-#pragma unroll
-        for (int h = 0; h < NSLOT; ++h) {
-            const int rb = min(rb_lo + p * U + 4 * h + rsub, RB - 1);
-            const int g = u.gshift >= 0 ? ((rb * 16) >> u.gshift) : ((rb * 16) / u.gprows);
-            rg_ld4(rz[h], u.qzeros + (size_t) g * (u.N >> 3) + (n >> 3));
-            rg_ld2(rs[h], u.scales + (size_t) g * u.N + n);
-        }
-        if constexpr (EMODE == 1) rg_ld2(rres, (const uint16_t*) a_res + n);
-    };
+    uint32_t rz = 0, rs = 0, rres = 0;                               // raw zero / scale word of the chunk in flight (and the residual)
+    uint32_t ent = 0;                                                // entries of the chunk being consumed: lane (rsub, col) holds row-block 4 c + rsub
     float res_cur = 0.f;
-    auto combine_entries = [&](int p) {                              // after the wait that covers the raw words
-#pragma unroll
-        for (int h = 0; h < NSLOT; ++h) {
-            rg_tie(rz[h]); rg_tie(rs[h]);
-            const uint32_t e = (rs[h] & 0xFFFFu) | ((0xE401u + ((rz[h] >> (uint32_t) ((col & 7) * 4)) & 0xFu)) << 16);
-            ent[h] = (rb_lo + p * U + 4 * h + rsub < rb_hi) ? e : 0u;   // rows past the wave's range: scale 0 -> contribute nothing
-        }
-        if constexpr (EMODE == 1) { rg_tie(rres); if (p == 0) res_cur = (float) __builtin_bit_cast(f16, (uint16_t) rres); }
+    auto issue_entries = [&](const RingUnit& u, int chunk) {         // ring_entry_loads(4 * chunk) loads, in this order
+        const int n = u.n0 + col;
+        const int rb = min(rb_lo + 4 * chunk + rsub, RB - 1);
+        const int g = u.gshift >= 0 ? ((rb * 16) >> u.gshift) : ((rb * 16) / u.gprows);
+        rg_ld4(rz, u.qzeros + (size_t) g * (u.N >> 3) + (n >> 3));
+        rg_ld2(rs, u.scales + (size_t) g * u.N + n);
+        if (EMODE == 1 && chunk == 0) rg_ld2(rres, (const uint16_t*) a_res + n);
+    };
+    auto combine_entries = [&](int chunk) {                          // after the wait that covers the raw words
+        rg_tie(rz); rg_tie(rs);
+        const uint32_t e = (rs & 0xFFFFu) | ((0xE401u + ((rz >> (uint32_t) ((col & 7) * 4)) & 0xFu)) << 16);
+        ent = (rb_lo + 4 * chunk + rsub < rb_hi) ? e : 0u;           // rows past the wave's range: scale 0 -> contribute nothing
+        if (EMODE == 1 && chunk == 0) { rg_tie(rres); res_cur = (float) __builtin_bit_cast(f16, (uint16_t) rres); }
+    };
+    // request step `t` (a compile-time constant) of unit u into its slot, entries of its chunk first when it opens one
+    auto issue_step = [&](const RingUnit& u, auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if constexpr (t % 4 == 0) issue_entries(u, t / 4);
+        const int rb = min(rb_lo + t, RB - 1);                        // clamped: always a valid address
+        rg_ldw(ring[t % U], lane16, u.wbase + (size_t) (uint32_t) rb * 1024u);
     };
 
-    // ---- 1. activation loads (all waves), then entries + ring of the first unit ---------------------------------------------
+    // ---- 1. activation loads (all waves), then the ring of the first unit -----------------------------------------------------
     const f16* src = a_vec;
     if constexpr (PNORM == 1) { if (a_tok) src = a_vec + (size_t) (*a_tok) * K; }
     u32x4 xraw[NV], wraw[NV];
     u32x4 praw[MS];
-    u32x2 pml = {0u, 0u};
+    uint64_t pml = 0;
     if constexpr (PNORM == 1) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -215,16 +274,18 @@ __global__ __launch_bounds__(DEC_THREADS, 2 * OCC) void dec_ring_kernel(const De
             rg_dma16(xs_lds + (uint32_t) idx0 * 16u, src + ci * 8);
         }
     }
+    RP_CLK(0);                                                       // activation requests issued
     if (flags & 1) asm volatile("s_barrier" ::: "memory");           // every wave's activation request is queued before any weight request
     RingUnit cur = describe(0);
-    issue_entries(cur, 0);
-    static_for<0, U>([&](auto qc) { issue_w(cur, qc, decltype(qc)::value); });
+    static_for<0, U>([&](auto jc) { issue_step(cur, std::integral_constant<int, (UL - U + decltype(jc)::value) % U>{}); });
+    RP_CLK(1);                                                       // ring of the first unit issued
     // zero padding of the image: slots past a wave's range read it (finite x, scale 0)
     for (int idx = tid; idx < IMG_ROWS; idx += DEC_THREADS)
         if (idx >= nvec && (PNORM != 0 || idx >= NV * DEC_THREADS)) xs[idx] = make_uint4(0u, 0u, 0u, 0u);
 
     // ---- 2. activation image --------------------------------------------------------------------------------------------------
-    rg_wait<EL + U>();                                               // everything older than the entries has landed
+    rg_wait<EL0 + U>();                                              // everything older than the ring has landed
+    RP_CLK(2);                                                       // activation landed
     if constexpr (PNORM == 1) {
         f16x8 xv[NV];
         float ss = 0.f;
@@ -261,8 +322,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2 * OCC) void dec_ring_kernel(const De
 #pragma unroll
         for (int sp2 = 0; sp2 < MS; ++sp2) rg_tie(praw[sp2]);
         const bool live = (lane & 15) < a.att_nsplit;
-        const float pm = live ? __builtin_bit_cast(float, pml[0]) : -INFINITY;
-        const float pl = live ? __builtin_bit_cast(float, pml[1]) : 0.f;
+        const float pm = live ? __uint_as_float((uint32_t) pml) : -INFINITY;
+        const float pl = live ? __uint_as_float((uint32_t) (pml >> 32)) : 0.f;
         float M = pm;
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
@@ -285,6 +346,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2 * OCC) void dec_ring_kernel(const De
         if (tid < nvec) xs[tid] = __builtin_bit_cast(uint4, r);
     }
     rg_barrier();
+    RP_CLK(3);                                                       // image staged
 
     // ---- 3. walk the units --------------------------------------------------------------------------------------------------------
     const uint32_t magic = t16_magic();
@@ -294,29 +356,24 @@ __global__ __launch_bounds__(DEC_THREADS, 2 * OCC) void dec_ring_kernel(const De
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
         static_for<0, UL>([&](auto lic) {
             constexpr int li = decltype(lic)::value;
-            constexpr int p = li / U, q = li % U;
-            // younger vector-memory instructions than the load of (p, q): the other U - 1 ring loads, plus -- past slot 0 -- the
-            // entry loads that went out at slot 0 of this round (next pass / next unit); in the last pass of a block's last
-            // unit the ring runs empty
-            constexpr bool reissue = p + 1 < NP || !LAST;
-            constexpr int cnt = reissue ? U - 1 + (q >= 1 ? EL : 0) : U - 1 - q;
-            rg_wait<cnt>(ring[q]);
-            if constexpr (q == 0) combine_entries(p);
-            const uint32_t e = (uint32_t) __shfl((int) ent[q >> 2], ((q & 3) << 4) | col, 64);
-            const uint4 w = make_uint4(ring[q][0], ring[q][1], ring[q][2], ring[q][3]);
+            rg_wait<ring_younger(U, UL, EL0, LAST, li)>(ring[li % U]);
+            if constexpr (li % 4 == 0) combine_entries(li / 4);
+            const uint32_t e = (uint32_t) __shfl((int) ent, ((li & 3) << 4) | col, 64);
+            const uint4 w = make_uint4(ring[li % U][0], ring[li % U][1], ring[li % U][2], ring[li % U][3]);
+#ifdef EXL_RING_ABLATE                                               /* measurement builds: the loads without the arithmetic */
+            c[0] += __uint_as_float((w.x ^ w.w) & 0x3fffffffu) + __uint_as_float(e & 0x3fffffffu);
+#else
             t16_rowblock<true>(w, e, magic, xrow + li * 16, c);
-            if constexpr (p + 1 < NP) {
-                if constexpr (q == 0) issue_entries(uc, p + 1);
-                issue_w(uc, std::integral_constant<int, q>{}, li + U);
-            } else if constexpr (!LAST) {
-                if constexpr (q == 0) issue_entries(un, 0);
-                issue_w(un, std::integral_constant<int, q>{}, q);
-            }
+#endif
+            if constexpr (li + U < UL) issue_step(uc, std::integral_constant<int, li + U>{});
+            else if constexpr (!LAST) issue_step(un, std::integral_constant<int, li % U>{});
         });
         float* rp = red + (i & 1) * DEC_WAVES * 16;
         const float res = res_cur;                                   // (the next unit's entries may already be on their way: res_cur is this unit's)
         if (lane < 16) rp[wave * 16 + lane] = c[0];
+        if (i == 0) RP_CLK(4);                                       // unit 0 consumed
         rg_barrier();
+        if (i == 0) RP_CLK(5);                                       // unit 0: all waves through
         if (tid < 16) {
             const int n = uc.n0 + tid;
             if constexpr (EMODE == 2) {
@@ -340,25 +397,35 @@ __global__ __launch_bounds__(DEC_THREADS, 2 * OCC) void dec_ring_kernel(const De
         cur = nxt;
     }
     unit_body(std::true_type{}, cur, cur, i);
+#ifdef EXL_RING_PROBE
+    RP_CLK(6);
+    if (tid == 0 && b < 512) {
+        constexpr int cls = PNORM == 3 ? 1 : EMODE == 2 ? 2 : PNORM == 1 ? 0 : 3;
+        unsigned long long* dst = g_ring_probe + ((size_t) cls * 512 + b) * 8;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) dst[q] = rp_t[q] - rp_t0;
+        dst[7] = (unsigned long long) n_my;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------------------
-size_t dec_ring_smem(int U, int NP, int emode, int nv)
+static size_t dec_ring_smem(int UL, int emode, int nv)
 {
     const int wpt = emode == 2 ? DEC_WAVES / 2 : DEC_WAVES;
-    const int rows = wpt * U * NP * 16 > nv * DEC_THREADS ? wpt * U * NP * 16 : nv * DEC_THREADS;
+    const int rows = wpt * UL * 16 > nv * DEC_THREADS ? wpt * UL * 16 : nv * DEC_THREADS;
     return (size_t) rows * 16 + (2 * DEC_WAVES * 16 + DEC_WAVES) * sizeof(float);
 }
 
-template <int U, int NP, int PNORM, int EMODE, int NV, int OCC>
+template <int U, int UL, int PNORM, int EMODE, int NV>
 static int ring_go(int grid, const DecGemvArgs& a, hipStream_t s, int* plan)
 {
-    auto kfn = dec_ring_kernel<U, NP, PNORM, EMODE, NV, OCC>;
-    const size_t smem = dec_ring_smem(U, NP, EMODE, NV);
-    if (plan) {                                                      // exl_decoder_plan: [0] launched, [1] U, [2] NP, [3] 2 = ring kernel, [4] PNORM, [5] EMODE, [6] NV
-        plan[0] = 1; plan[1] = U; plan[2] = NP; plan[3] = 2; plan[4] = PNORM; plan[5] = EMODE; plan[6] = NV;
+    auto kfn = dec_ring_kernel<U, UL, PNORM, EMODE, NV, (UL >= 24 ? 1 : 2)>;   // (the longest unrolled units want more than 128 registers)
+    const size_t smem = dec_ring_smem(UL, EMODE, NV);
+    if (plan) {                                                      // exl_decoder_plan: [0] launched, [1] U, [2] UL, [3] 2 = ring kernel, [4] PNORM, [5] EMODE, [6] NV
+        plan[0] = 1; plan[1] = U; plan[2] = UL; plan[3] = 2; plan[4] = PNORM; plan[5] = EMODE; plan[6] = NV;
         plan[7] = grid; plan[8] = (int) smem; plan[9] = 1;
         return 0;
     }
@@ -369,61 +436,41 @@ static int ring_go(int grid, const DecGemvArgs& a, hipStream_t s, int* plan)
     return 0;
 }
 
-// (U, NP): U loads in flight per lane, NP passes; U * NP >= rbw with as few idle slots as possible (an idle slot re-reads a
-// valid row-block with scale 0: real traffic).  two_per_cu: the grid has more blocks than CUs, so two blocks must be co-resident
-// (128 VGPRs); otherwise one block per CU may take 256.  Only the (U, NP) a kernel class can meet are instantiated: NV fixes
-// the range of K, hence of the row-blocks per wave.
+// Row-blocks per wave -> the unit length UL the kernel is instantiated for: exact wherever a Llama shape asks for it (no idle slot:
+// an idle slot re-reads a valid row-block with scale 0, real traffic), the next listed value otherwise; 0 = not covered.
+// Only the lengths a kernel class can meet are instantiated: NV fixes the range of K, hence of the row-blocks per wave.
+#ifdef EXL_DEC_FAST_BUILD                                            /* ISA inspection / experiment builds: the 7B shapes */
+#define RING_ULS(X) X(4) X(8) X(11)
+#else
+#define RING_ULS(X) X(4) X(5) X(6) X(7) X(8) X(10) X(11) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(28) X(32)
+#endif
 template <int PNORM, int EMODE, int NV>
-static int ring_cfg(int rbw, int grid, bool two_per_cu, const DecGemvArgs& a, hipStream_t s, int* plan)
+static int ring_cfg(int depth, int rbw, int grid, const DecGemvArgs& a, hipStream_t s, int* plan)
 {
     constexpr int WPT = EMODE == 2 ? DEC_WAVES / 2 : DEC_WAVES;
     constexpr int NVP = NV == 1 ? 0 : NV == 2 ? 1 : NV == 3 ? 2 : NV == 6 ? 3 : 6;   // the next smaller instantiated NV
     constexpr int RBW_HI = NV * 32 / WPT, RBW_LO = NVP * 32 / WPT + 1;               // K in (NVP * 4096, NV * 4096]
-    // rbw in (TLO, THI] -> <U, NP, OCC>
-#define RING(TLO, THI, U, NP, OCC) if constexpr ((THI) >= RBW_LO && (TLO) < RBW_HI) { if (rbw > (TLO) && rbw <= (THI)) return ring_go<U, NP, PNORM, EMODE, NV, OCC>(grid, a, s, plan); }
-#ifdef EXL_DEC_FAST_BUILD                                            /* ISA inspection builds: 7B instantiations only */
-    if (two_per_cu) { RING(0, 4, 4, 1, 2) } else { RING(0, 4, 4, 1, 1) }
-    RING(4, 8, 8, 1, 2)
-    if (!two_per_cu) { RING(8, 11, 11, 1, 1) }
-    return 1;
-#else
-    if constexpr (PNORM != 0) {                                      // K = hidden size (<= 8192): q/k/v, o_proj with the merge, gate/up
-        if (two_per_cu) { RING(0, 4, 4, 1, 2) RING(4, 5, 5, 1, 2) } else { RING(0, 4, 4, 1, 1) RING(4, 5, 5, 1, 1) }
-        RING(5, 6, 6, 1, 2)
-        RING(6, 8, 8, 1, 2)
-        if constexpr (EMODE == 2) {
-            RING(8, 10, 5, 2, 2)
-            RING(10, 12, 6, 2, 2)
-            RING(12, 14, 7, 2, 2)
-            RING(14, 16, 8, 2, 2)
-        }
-        return 1;
-    } else {                                                         // o_proj behind the merge kernel (K = hidden), down_proj (K = intermediate size)
-        if (two_per_cu) { RING(0, 4, 4, 1, 2) RING(4, 5, 5, 1, 2) RING(5, 8, 8, 1, 2) }
-        else {
-            RING(0, 4, 4, 1, 1) RING(4, 5, 5, 1, 1) RING(5, 8, 8, 1, 1)
-            RING(8, 11, 11, 1, 1)
-            RING(11, 12, 12, 1, 1)
-            RING(12, 14, 14, 1, 1)
-            RING(21, 22, 11, 2, 1)
-        }
-        RING(8, 12, 6, 2, 2)
-        RING(12, 14, 7, 2, 2)
-        RING(14, 16, 8, 2, 2)
-        RING(16, 18, 6, 3, 2)
-        return 1;                                                    // (deeper two-per-CU streams spill under 128 VGPRs: dec_stream_kernel keeps them)
+    int prev = 0;
+#define RING_ONE(ULV)                                                                                                          \
+    if constexpr (((ULV) >= RBW_LO && (ULV) <= RBW_HI) || ((ULV) == 4 && RBW_LO <= 4)) {                                                       \
+        if (rbw > prev && rbw <= (ULV)) {                                                                                      \
+            if (depth <= 2) return ring_go<2, ULV, PNORM, EMODE, NV>(grid, a, s, plan);                                        \
+            if constexpr (ring_valid(3, ULV)) { if (depth == 3) return ring_go<3, ULV, PNORM, EMODE, NV>(grid, a, s, plan); }  \
+            return ring_go<4, ULV, PNORM, EMODE, NV>(grid, a, s, plan);                                                        \
+        }                                                                                                                      \
+        prev = (ULV);                                                                                                          \
     }
-#endif
-#undef RING
+    RING_ULS(RING_ONE)
+#undef RING_ONE
+    return 1;
 }
 
-int launch_dec_ring(int pnorm, int emode, bool g16, int rbw, int nv, int grid, bool two_per_cu, const DecGemvArgs& a, hipStream_t s,
-                    int* plan)
+int launch_dec_ring(int pnorm, int emode, bool g16, int rbw, int nv, int grid, int depth, const DecGemvArgs& a, hipStream_t s, int* plan)
 {
     if (!g16 || a.out_perm) return 1;
     for (int i = 0; i < DEC_MAX_MATS; ++i)
         if (a.map16[i]) return 1;
-#define RING_GO(P, E, N) return ring_cfg<P, E, N>(rbw, grid, two_per_cu, a, s, plan)
+#define RING_GO(P, E, N) return ring_cfg<P, E, N>(depth, rbw, grid, a, s, plan)
 #ifdef EXL_DEC_FAST_BUILD
     if (pnorm == 1 && emode == 0 && nv == 1) RING_GO(1, 0, 1);
     if (pnorm == 1 && emode == 2 && nv == 1) RING_GO(1, 2, 1);

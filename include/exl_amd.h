@@ -267,13 +267,14 @@ int exl_decoder_set_hidden(void* decoder, void* hidden_dev);
  * loads in flight per lane), [2] NP (passes), [3] kernel kind (2 = rolling-ring stream; 1 / 0 = compiler-scheduled stream, group size % 128 == 0 / 32, 64), [4] PNORM, [5] EMODE, [6] NV (8-half
  * activation vectors per thread), [7] grid, [8] dynamic LDS bytes, [9] activation images; attention / merge: [1] KV splits. */
 int exl_decoder_plan(void* decoder, int cls, int* out10);
-/* Test / measurement aid: which weight-stream kernel the GEMV classes of this decoder launch.  EXL_DEC_OPT_RING: 1 (default;
- * environment EXL_DEC_RING) = the hand-counted rolling-ring stream wherever it covers the launch, 0 = the compiler-scheduled
- * stream everywhere (same results bit for bit: tests compare the two).  EXL_DEC_OPT_RING_FENCE: 1 (default; EXL_DEC_RING_FENCE)
+/* Test / measurement aid: which weight-stream kernel the GEMV classes of this decoder launch.  EXL_DEC_OPT_RING: a bit per class (1 q/k/v,
+ * 2 o_proj, 4 gate/up, 8 down_proj; default 15; environment EXL_DEC_RING): set = the hand-counted rolling-ring stream wherever
+ * it covers the launch, 0 = the compiler-scheduled stream everywhere (same results bit for bit: tests compare the two).  EXL_DEC_OPT_RING_FENCE: 1 (default; EXL_DEC_RING_FENCE)
  * = a block queues the activation requests of all its waves before any weight request.  Graphs captured before a change keep
  * the kernels they were captured with. */
 #define EXL_DEC_OPT_RING       0
 #define EXL_DEC_OPT_RING_FENCE 1
+#define EXL_DEC_OPT_RING_DEPTH 2   /* 16-byte loads a lane keeps in flight in the ring stream: 2 .. 4 (default 4; EXL_DEC_RING_DEPTH) */
 int exl_decoder_set_option(void* decoder, int option, int value);
 /* Tensor parallelism (not in the reference: doc/TODO.md:19; exllama_amd/tp.py): a decoder built from ONE rank's shard --
  * heads * head_dim < hidden (its own heads), its own intermediate columns, the full residual stream.  exl_decoder_step_part

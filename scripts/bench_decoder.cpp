@@ -10,6 +10,9 @@
 #include <math.h>
 #include <vector>
 #include "exl_amd.h"
+#ifdef EXL_RING_PROBE
+extern "C" int exl_debug_ring_probe(int cls, unsigned long long* out8);
+#endif
 #ifdef EXL_ATTN_PROBE
 extern "C" int exl_debug_attn_probe(unsigned long long* out8);
 extern "C" int exl_debug_stream_probe(int cls, unsigned long long* out12);
@@ -118,6 +121,18 @@ int main(int argc, char** argv)
         float tms = 0;
         CK(hipEventElapsedTime(&tms, e0, e1));
         printf("ctx %5d  graph replay: %.4f ms/token = %.1f tokens/s (x%d layers)\n", p0, tms / reps, 1e3 * reps / tms, L);
+#ifdef EXL_RING_PROBE
+        {
+            static const char* rn[4] = {"qkv", "o_proj + merge", "gate_up", "plain vector (last launched: down)"};
+            for (int cls = 0; cls < 4; ++cls) {
+                unsigned long long pr[8];
+                if (exl_debug_ring_probe(cls, pr) != 0 || !pr[7]) continue;
+                const double nb = (double) pr[7];
+                printf("ctx %5d  ring kernel [%s], mean cycles over %llu blocks: activation requested %.0f  ring issued %.0f  activation landed %.0f  image staged %.0f  unit 0 consumed %.0f  unit 0 reduced %.0f  end %.0f\n",
+                       p0, rn[cls], pr[7], pr[0] / nb, pr[1] / nb, pr[2] / nb, pr[3] / nb, pr[4] / nb, pr[5] / nb, pr[6] / nb);
+            }
+        }
+#endif
 #ifdef EXL_ATTN_PROBE
         {
             unsigned long long pr[12];

@@ -105,6 +105,46 @@ def read_write_regs(mn, ops):
     return out
 
 
+_SREG = re.compile(r"\bs(\d+)\b|\bs\[(\d+):(\d+)\]")
+
+
+def sregs(text):
+    out = set()
+    for m in _SREG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def valu_sgpr_hazards(name, insns):
+    """VALU write of an SGPR (v_readfirstlane / v_readlane) -> vector-memory instruction reading that SGPR (base, offset or
+    descriptor) needs 5 wait states in between.  hipcc pads its own code; it cannot see into an inline-asm string, so a
+    `v_readfirstlane` that lands right in front of an asm load is a silent wrong-address bug (round 3: memory access faults)."""
+    out = []
+    n = len(insns)
+    for i, (addr, mn, ops) in enumerate(insns):
+        if mn not in ("v_readfirstlane_b32", "v_readlane_b32"):
+            continue
+        written = sregs(ops.split(",")[0])
+        states = 0
+        for j in range(i + 1, min(i + 8, n)):
+            a2, m2, o2 = insns[j]
+            if m2.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")):
+                break
+            if m2.startswith(VM_PREFIXES) and states < 5:
+                if written & sregs(o2):
+                    out.append((name, a2, f"{m2} {o2}", addr, f"{mn} {ops} only {states} wait states earlier (5 needed)", []))
+                    break
+            states += (int(o2.split()[0]) + 1) if m2 == "s_nop" and o2.split() and o2.split()[0].isdigit() else 1
+            if states >= 5:
+                break
+            if written & sregs(o2.split(",")[0]) and not m2.startswith(VM_PREFIXES) and m2.startswith("s_"):
+                break                                               # the SGPR was overwritten by scalar code: a new value
+    return out
+
+
 def load_dest(mn, ops):
     """VGPRs a vector-memory LOAD will write when it completes (empty for stores, LDS-DMA and no-return atomics)."""
     if "_load" not in mn or "_lds" in mn or " lds" in (" " + ops):
@@ -241,7 +281,7 @@ def lint_kernel(name, insns, verbose=False):
     for b, (lo, hi) in enumerate(blocks):
         if ins[b] is not None:
             transfer(ins[b], lo, hi, report)
-    return list(report.values()) + extra
+    return list(report.values()) + extra + valu_sgpr_hazards(name, insns)
 
 
 def lint_library(so_path, kernel_filter=None, verbose=False):

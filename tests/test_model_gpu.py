@@ -338,20 +338,20 @@ def test_weight_arena_is_one_allocation_and_changes_nothing():
 # ever launch <4,1,.,.,.,1>; these cases run the executor (eager, graph replay, greedy generation) on truncated models of the
 # real dimensions against the CPU oracle model, and assert through exl_decoder_plan WHICH instantiation ran, so that every
 # configuration the benchmark launches is compared with the oracle.
-#   (U, NP, KIND, PNORM, EMODE, NV) per kernel class, [1] = launched at all; KIND 2 = dec_ring_kernel, 1 / 0 = dec_stream_kernel
-#   with the scale applied per row-block (group size % 128 == 0) / per k-group (group sizes 32, 64)
+#   per kernel class, [1] = launched at all: dec_ring_kernel (U, UL, 2, PNORM, EMODE, NV) -- U loads in flight per lane, UL row-blocks
+#   per wave and tile -- or dec_stream_kernel (U, NP, G16, PNORM, EMODE, NV) with the scale applied per row-block (G16 = 1: group
+#   size % 128 == 0) / per k-group (0: group sizes 32, 64)
 _REAL_SHAPES = {
     #        name   gs   act    L  qkv                    o_proj (>1 split)       gate_up                down                   merge kernel
-    "7b":  ("7b", 128, False, 2, (4, 1, 2, 1, 0, 1), (4, 1, 2, 3, 1, 1), (8, 1, 2, 1, 2, 1), (11, 1, 2, 0, 1, 3), False),
+    "7b":  ("7b", 128, False, 2, (4, 4, 2, 1, 0, 1), (4, 4, 2, 3, 1, 1), (4, 8, 2, 1, 2, 1), (4, 11, 2, 0, 1, 3), False),
     # (U, NP) fits the row-blocks per wave exactly where it can: 13B 5 / 10 / 14, 33B 7 / 13 / 18, 65B 8 / 16 / 22, 70B 8 / 16 / 28
     # 13B act-order: q/k/v and gate/up gather through their maps (dec_stream_kernel); o_proj / down_proj get their input already
-    # in row order (ring).  down_proj of 65B / 70B: more tiles than CUs and 22 / 28 row-blocks per wave -- the 4-deep streams
-    # that fit two blocks per CU (dec_stream_kernel)
-    "13b": ("13b", 128, True, 1, (5, 1, 1, 1, 0, 2), (5, 1, 2, 0, 1, 2), (5, 2, 1, 1, 2, 2), (7, 2, 2, 0, 1, 6), True),
+    # in row order (ring)
+    "13b": ("13b", 128, True, 1, (5, 1, 1, 1, 0, 2), (4, 5, 2, 0, 1, 2), (5, 2, 1, 1, 2, 2), (4, 14, 2, 0, 1, 6), True),
     "33b": ("33b", 32, True, 1, (4, 2, 0, 1, 0, 2), (4, 2, 0, 0, 1, 2), (7, 2, 0, 1, 2, 2), (6, 3, 0, 0, 1, 6), True),
-    "65b": ("65b", 128, False, 1, (8, 1, 2, 1, 0, 2), (8, 1, 2, 0, 1, 2), (8, 2, 2, 1, 2, 2), (4, 6, 1, 0, 1, 6), True),
+    "65b": ("65b", 128, False, 1, (4, 8, 2, 1, 0, 2), (4, 8, 2, 0, 1, 2), (4, 16, 2, 1, 2, 2), (4, 22, 2, 0, 1, 6), True),
     # Llama-2-70B: GQA (8 kv heads) and K = 28672 in down_proj -- 28 row-blocks per wave, 7 -> 8 vectors per thread
-    "70b": ("70b", 128, False, 1, (8, 1, 2, 1, 0, 2), (8, 1, 2, 0, 1, 2), (8, 2, 2, 1, 2, 2), (4, 7, 1, 0, 1, 8), True),
+    "70b": ("70b", 128, False, 1, (4, 8, 2, 1, 0, 2), (4, 8, 2, 0, 1, 2), (4, 16, 2, 1, 2, 2), (4, 28, 2, 0, 1, 8), True),
 }
 
 
@@ -430,7 +430,7 @@ def test_native_decode_executor_at_real_layer_shapes(key):
     model.free_unmanaged()
 
 
-@pytest.mark.parametrize("key", ["7b", "13b", "65b"])
+@pytest.mark.parametrize("key", ["7b", "13b", "65b", "70b"])
 def test_ring_stream_equals_compiler_stream_bit_for_bit(key):
     """decode_ring.hip (every vector-memory instruction inline asm, every wait counted by hand) against dec_stream_kernel
     (ordinary loads, hipcc's waits) on the same decoder: same arithmetic in the same order, so the logits, the appended K/V
@@ -457,13 +457,14 @@ def test_ring_stream_equals_compiler_stream_bit_for_bit(key):
         model.forward(ids[:, :P], cache, preprocess_only=True)
         toks = ids[0, P:P + 4].tolist()
         runs = {}
-        for mode in ((0, 0), (1, 1), (1, 0)):                        # (ring, fence)
+        for mode in ((0, 0, 4), (15, 1, 4), (15, 0, 3), (15, 1, 2)):  # (ring classes, start-up barrier, loads in flight per lane)
             c = ExLlamaCache(model, copy_from=cache)
             c.current_seq_len = P
             model.enable_decode_graph(c, use_graph=False)
             for sg in model._decoder["stages"]:
                 cuda_ext.check(lib.exl_decoder_set_option(sg["handle"], 0, mode[0]), "set_option")
                 cuda_ext.check(lib.exl_decoder_set_option(sg["handle"], 1, mode[1]), "set_option")
+                cuda_ext.check(lib.exl_decoder_set_option(sg["handle"], 2, mode[2]), "set_option")
             kinds = {cls: _plan(model, j)[3] for j, cls in enumerate(model.DECODER_CLASSES) if cls in ("qkv", "o_proj", "gate_up", "down")}
             if mode[0]:
                 assert 2 in kinds.values(), kinds                    # the ring really is what ran
@@ -472,8 +473,8 @@ def test_ring_stream_equals_compiler_stream_bit_for_bit(key):
             out = [model.forward(torch.tensor([[t]], device="cuda:0"), c)[0, 0].float().cpu().numpy().copy() for t in toks]
             kv = [c.key_states[l][0, :, P:P + 4].cpu().numpy().copy() for l in range(L)]
             runs[mode] = (out, kv)
-        ref_out, ref_kv = runs[(0, 0)]
-        for mode in ((1, 1), (1, 0)):
+        ref_out, ref_kv = runs[(0, 0, 4)]
+        for mode in ((15, 1, 4), (15, 0, 3), (15, 1, 2)):
             out, kv = runs[mode]
             for i in range(len(toks)):
                 assert np.isfinite(out[i]).all()
