@@ -78,6 +78,33 @@ __device__ __forceinline__ f16 silu_mul_f16(f16 x, f16 y)
 }
 
 
-// decode_ring.hip: the rolling-ring stream kernels.  depth: loads in flight per lane (2 .. 4).  Returns 1 when the launch is not
+// ---- cross-lane reductions on the vector ALU (DPP): no LDS-pipe round trips (a ds_bpermute butterfly is ~150 cycles per step
+// when the CU is streaming).  Both stream kernels use the same ORDER of additions, so their results stay bit-identical:
+// pairs, quads (quad_perm), 8 and 16 lanes (row_half_mirror / row_mirror: after each step the lanes of a group hold the same
+// value, so the mirrored partner carries the other group's sum), then the four 16-lane rows as (r0 + r1) + (r2 + r3).
+template <int CTRL>
+__device__ __forceinline__ float dec_dpp(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dec_row_sum(float v)                // sum over the 16 lanes of a row, in every lane
+{
+    v += dec_dpp<0xB1>(v); v += dec_dpp<0x4E>(v); v += dec_dpp<0x141>(v); v += dec_dpp<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ float dec_row_max(float v)
+{
+    v = fmaxf(v, dec_dpp<0xB1>(v)); v = fmaxf(v, dec_dpp<0x4E>(v)); v = fmaxf(v, dec_dpp<0x141>(v)); v = fmaxf(v, dec_dpp<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ float dec_lane(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
+__device__ __forceinline__ float dec_wave_sum(float v)               // sum over the 64 lanes, wave-uniform
+{
+    v = dec_row_sum(v);
+    return (dec_lane(v, 0) + dec_lane(v, 16)) + (dec_lane(v, 32) + dec_lane(v, 48));
+}
+
+// decode_ring.hip: the rolling-ring stream kernels.  depth: loads in flight per lane (2 .. 4); wide_blocks: 16-wave blocks for the
+// plain-vector launches (o_proj behind the merge / one KV split, down_proj) whose grid leaves one block per CU.  Returns 1 when the launch is not
 // covered (the caller falls back to dec_stream_kernel), 0 on success, an error code otherwise.  plan: exl_decoder_plan's record (or NULL).
-int launch_dec_ring(int pnorm, int emode, bool g16, int rbw, int nv, int grid, int depth, const DecGemvArgs& a, hipStream_t s, int* plan);
+int launch_dec_ring(int pnorm, int emode, bool g16, int K, int grid, int depth, bool wide_blocks, const DecGemvArgs& a, hipStream_t s, int* plan);

@@ -273,8 +273,7 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_MIN_WAVES(U, NP, G16, PNORM, EMODE
                 for (int j = 0; j < 8; ++j) { const float f = (float) xv[i][j]; ss = fmaf(f, f, ss); }
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+        ss = dec_wave_sum(ss);
         if (lane == 0) red[2 * DEC_WAVES * 16 + wave] = ss;
         __syncthreads();
         float total = 0.f;
@@ -449,7 +448,7 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(const f16* __restrict
                                                        int max_seq, int nsplit, float scale, f16* __restrict__ direct_out,
                                                        const uint16_t* __restrict__ out_perm)
 {
-    constexpr int HD = 128, LPK = 16, KPI = NW * 4, UN = DEC_ATT_CHUNK / KPI, NT = NW * 64;
+    constexpr int HD = 128, LPK = 16, KPI = NW * 4, UN = DEC_ATT_CHUNK / 16, NT = NW * 64;   // 10 rows per thread and pass: 160 keys with 4 waves, 320 with 8
     __shared__ float sc[DEC_ATT_MAX_KEYS];
     __shared__ float red[KPI][HD + 1];
     __shared__ float stat[2 * NW];
@@ -861,7 +860,7 @@ struct Decoder {
     void* block;                  // one hipMalloc
     uint16_t* maps;               // act-order maps of all layers: per layer 2 x (6 hidden + inter) entries
     f16* zero_res;                // [h] zeros: the residual a tensor-parallel rank that does not own it adds (exl_decoder_set_tp)
-    int ring, ring_fence, ring_depth;   // exl_decoder_set_option: rolling-ring weight stream (decode_ring.hip) / its start-up barrier
+    int ring, ring_fence, ring_depth, ring_wide;   // exl_decoder_set_option: rolling-ring weight stream (decode_ring.hip) / its start-up barrier
     bool residual_owner;          // tensor parallel: only one rank adds the residual stream to its partial o_proj / down_proj sums
     int qd() const { return heads * hd; }     // width of q / attention output: = h, or this rank's heads of a tensor-parallel shard
     bool has_embed() const { return embed != nullptr; }
@@ -895,7 +894,12 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     d->sin = (const f16*) sin; d->cos = (const f16*) cos;
     d->layers.resize(n_layers);
     for (auto& l : d->layers) l.set = false;
-    int ns = (max_seq_len > 1280 ? 512 : 256) / heads;             // long contexts: 2 blocks per CU, <= 160 keys each
+    // KV splits of the deepest bucket: one 8-wave block per CU and head-split with up to 320 keys per pass (long contexts), or
+    // one 4-wave block per CU with up to 160.  (Round 2 ran 512 four-wave blocks of <= 160 keys: the o_proj kernel that merges the
+    // splits reads every partial in every block, and halving their number paid more than the attention kernel lost.)
+    // Wider models (hidden > 4096) merge in a kernel of their own and keep the 512-block form.
+    const bool folds = heads * head_dim <= DEC_THREADS * 8;
+    int ns = (max_seq_len > 1280 && !folds ? 512 : 256) / heads;
     if (const char* env = getenv("EXL_DEC_NSPLIT")) ns = atoi(env);  // measurement aid
     if (ns < 1) ns = 1;
     if (ns > DEC_MAX_NSPLIT) ns = DEC_MAX_NSPLIT;
@@ -935,7 +939,8 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     d->residual_owner = true;
     d->ring = getenv("EXL_DEC_RING") ? atoi(getenv("EXL_DEC_RING")) : 15;
     d->ring_fence = getenv("EXL_DEC_RING_FENCE") ? atoi(getenv("EXL_DEC_RING_FENCE")) : 1;
-    d->ring_depth = getenv("EXL_DEC_RING_DEPTH") ? atoi(getenv("EXL_DEC_RING_DEPTH")) : 4;
+    d->ring_depth = getenv("EXL_DEC_RING_DEPTH") ? atoi(getenv("EXL_DEC_RING_DEPTH")) : 3;
+    d->ring_wide = getenv("EXL_DEC_RING_WIDE") ? atoi(getenv("EXL_DEC_RING_WIDE")) : 1;
     d->separate_merge = getenv("EXL_DEC_SEPARATE_MERGE") != nullptr;
     int bpc = 2;
     if (const char* env = getenv("EXL_DEC_BLOCKS_PER_CU")) { bpc = atoi(env); if (bpc < 1) bpc = 1; if (bpc > 4) bpc = 4; }
@@ -1164,7 +1169,7 @@ static int launch_dec_gemv(const Decoder* dcfg, int cls, int pnorm, int emode, c
     const int ring = (dcfg->ring >> cls) & 1;                        // one bit per GEMV class: q/k/v, o_proj, gate/up, down_proj
     a.ring_flags = dcfg->ring_fence ? 1 : 0;
     if (ring) {
-        const int rr = launch_dec_ring(pnorm, emode, g16, rbw, nv, (int) grid.x, dcfg->ring_depth, a, s, g_plan);
+        const int rr = launch_dec_ring(pnorm, emode, g16, K, (int) grid.x, dcfg->ring_depth, dcfg->ring_wide && !two_per_cu, a, s, g_plan);
         if (rr != 1) return rr;
     }
     // NV (8-half activation vectors per thread) instantiations by kernel class: the normed / merged inputs have K = hidden
@@ -1220,7 +1225,10 @@ static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int3
     case EXL_DEC_ATTN: {
         const float scale = 1.0f / sqrtf((float) d->hd);
         if (g_plan) { g_plan[0] = 1; g_plan[1] = d->nsplit; g_plan[7] = d->nsplit * d->heads; return 0; }
-        static const int attn_waves = getenv("EXL_DEC_ATTN_WAVES") ? atoi(getenv("EXL_DEC_ATTN_WAVES")) : 4;
+        // 8 waves (320 keys per pass) where a split of the deepest bucket can exceed the 160 keys a 4-wave pass holds
+        static const int attn_waves_env = getenv("EXL_DEC_ATTN_WAVES") ? atoi(getenv("EXL_DEC_ATTN_WAVES")) : 0;
+        const int attn_waves = attn_waves_env ? attn_waves_env
+                             : (d->qd() <= DEC_THREADS * 8 && d->nsplit > 1 && d->nsplit == d->nsplit_max && (d->max_seq + d->nsplit - 1) / d->nsplit > DEC_ATT_CHUNK) ? 8 : 4;
 #define DEC_ATTN_LAUNCH(SH, NWV, GRID, NS, OUT) hipLaunchKernelGGL((dec_attn_kernel<SH, NWV>), dim3(GRID), dim3(NWV * 64), 0, s, d->qbuf, d->kbuf, \
             d->vbuf, l.kc, l.vc, d->sin, d->cos, d->partial, pos_dev, d->heads, d->kv_heads, d->max_seq, NS, scale, OUT, l.inv_o)
         if (d->nsplit == 1) {
@@ -1344,6 +1352,7 @@ extern "C" int exl_decoder_set_option(void* dec, int option, int value)
     if (option == EXL_DEC_OPT_RING) d->ring = value;
     else if (option == EXL_DEC_OPT_RING_FENCE) d->ring_fence = value;
     else if (option == EXL_DEC_OPT_RING_DEPTH) d->ring_depth = value;
+    else if (option == EXL_DEC_OPT_RING_WIDE) d->ring_wide = value;
     else EXL_FAIL(EXL_E_INVALID, "decoder_set_option: unknown option %d", option);
     return 0;
 }

@@ -123,6 +123,13 @@ constexpr int ring_entry_loads(int step, int el0) { return step % 4 == 0 ? (step
 // holds for every U <= 4 (chunk c + 1 is requested at step 4 (c + 1) - U >= 4 c); across units the next unit's chunk 0 goes out at
 // the last use of slot 0, which must not come before the last chunk of this unit is combined.
 constexpr bool ring_valid(int U, int UL) { return U >= 1 && U <= 4 && UL >= U && ((UL - 1) / U) * U >= ((UL - 1) / 4) * 4; }
+// vector-memory instructions the first `n` ring requests of the prologue make up (entries included)
+constexpr int ring_prologue_ops(int U, int UL, int el0, int n)
+{
+    int ops = 0;
+    for (int j = 0; j < n; ++j) ops += ring_entry_loads((UL - U + j) % U, el0) + 1;
+    return ops;
+}
 // vector-memory instructions issued after the load of step `li` and before step `li` is consumed = the N of its `s_waitcnt vmcnt(N)`
 constexpr int ring_younger(int U, int UL, int el0, bool last, int li)
 {
@@ -148,14 +155,18 @@ constexpr int ring_younger(int U, int UL, int el0, bool last, int li)
     return 0;
 }
 
-// OCC: blocks per CU the register budget is cut for (2 -> at most 128 VGPRs, 1 -> 256).
-template <int U, int UL, int PNORM, int EMODE, int NV, int OCC>
-__global__ __launch_bounds__(DEC_THREADS, 2 * OCC) void dec_ring_kernel(const DecGemvArgs a)
+// NW: waves per block (8; 16 for the plain-vector launches that leave one block per CU: twice the requests in flight per CU, half
+// the serial chain per wave).  Register budget: two 8-wave blocks or one 16-wave block per CU (128 VGPRs); the longest unrolled
+// units (UL >= 24) and the merge prologue (hidden <= 4096: never more blocks than CUs) are allowed 256.
+template <int U, int UL, int PNORM, int EMODE, int NV, int NW, int PRE>
+__global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 : 4) void dec_ring_kernel(const DecGemvArgs a)
 {
+    static_assert(PRE >= 0 && PRE <= U, "ring requests ahead of the activation image");
+    constexpr int NT = NW * 64;
     static_assert(ring_valid(U, UL), "one raw entry set: see ring_valid");
-    constexpr int WPT = EMODE == 2 ? DEC_WAVES / 2 : DEC_WAVES;      // waves per tile
+    constexpr int WPT = EMODE == 2 ? NW / 2 : NW;                    // waves per tile
     constexpr int EL0 = 2 + (EMODE == 1 ? 1 : 0);                    // entry loads of chunk 0 (with the residual value of the column)
-    constexpr int IMG_ROWS = WPT * UL * 16 > NV * DEC_THREADS ? WPT * UL * 16 : NV * DEC_THREADS;   // packed rows of the image (zero padded)
+    constexpr int IMG_ROWS = WPT * UL * 16 > NV * NT ? WPT * UL * 16 : NV * NT;   // packed rows of the image (zero padded)
     constexpr int MS = PNORM == 3 ? DEC_MAX_NSPLIT : 1;
     static_assert(PNORM != 3 || NV == 1, "the merge prologue holds one 8-dim vector per thread");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -164,24 +175,67 @@ __global__ __launch_bounds__(DEC_THREADS, 2 * OCC) void dec_ring_kernel(const De
     const unsigned long long rp_t0 = __builtin_readcyclecounter();
 #endif
 
-    // ---- 0. kernel arguments into SGPRs (one batch of scalar loads) ----------------------------------------------------------
-    T16Matrix M0 = a.mat[0], M1 = a.mat[1], M2 = a.mat[2];
-    dec_pin(M0); dec_pin(M1); dec_pin(M2);
-    int K = M0.K;
+    // ---- 0. the few kernel arguments the activation requests need; the matrix views follow once those requests are out (each
+    // group of pinned scalars is a scalar-cache round trip: with all three matrix views first, q/k/v issued its activation loads
+    // 3,000 cycles into the block)
+    int K = a.mat[0].K, flags = a.ring_flags;
     const f16* a_vec = dec_pin_ptr(a.vec); const f16* a_norm_w = dec_pin_ptr(a.norm_w); const int64_t* a_tok = dec_pin_ptr(a.tok);
-    const f16* a_res = dec_pin_ptr(a.res_in);
-    int te0 = a.tile_end[0], te1 = a.tile_end[1], te2 = a.tile_end[2], a_nmat = a.nmat;
-    int a_rbw = a.rb_per_wave, nb = a.nblocks, units_lo = a.units_lo, units_rem = a.units_rem, flags = a.ring_flags;
-    DEC_PIN_S(K); DEC_PIN_S(te0); DEC_PIN_S(te1); DEC_PIN_S(te2); DEC_PIN_S(a_nmat); DEC_PIN_S(a_rbw);
-    DEC_PIN_S(nb); DEC_PIN_S(units_lo); DEC_PIN_S(units_rem); DEC_PIN_S(flags);
-    const int RB = M0.RB;
+    DEC_PIN_S(K); DEC_PIN_S(flags);
     uint4* xs = (uint4*) smem;                                       // [IMG_ROWS]
-    float* red = (float*) (smem + (size_t) IMG_ROWS * 16);           // [2][DEC_WAVES][16] + [DEC_WAVES]
-
+    float* red = (float*) (smem + (size_t) IMG_ROWS * 16);           // [2][NW][16] + [NW]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rsub = lane >> 4, col = lane & 15;
     const uint32_t lane16 = (uint32_t) lane * 16u;
+    const int nvec = K >> 3;
+
+    // ---- 1. activation loads (all waves), then the ring of the first unit -----------------------------------------------------
+    const f16* src = a_vec;
+    if constexpr (PNORM == 1) { if (a_tok) src = a_vec + (size_t) (*a_tok) * K; }
+    u32x4 xraw[NV], wraw[NV];
+    u32x4 praw[MS];
+    uint64_t pml = 0;
+    if constexpr (PNORM == 1) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * NT;
+            const int ci = idx < nvec ? idx : 0;
+            rg_ld16(xraw[i], src + ci * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * NT;
+            const int ci = idx < nvec ? idx : 0;
+            rg_ld16(wraw[i], a_norm_w + ci * 8);
+        }
+    } else if constexpr (PNORM == 3) {
+        // 16 consecutive 8-dim vectors = one head; lane (l & 15) also fetches (max, sum) of split l & 15 of that head
+        const int ci = tid < nvec ? tid : 0;
+        const int hd = ci >> 4, sp = min(lane & 15, a.att_nsplit - 1);
+        rg_ld8(pml, a.att_ml + ((size_t) hd * a.att_nsplit + sp) * 2);
+        const uint4* base = (const uint4*) (src + (size_t) hd * a.att_nsplit * 128 + (ci & 15) * 8);
+#pragma unroll
+        for (int sp2 = 0; sp2 < MS; ++sp2) rg_ld16(praw[sp2], base + min(sp2, a.att_nsplit - 1) * 16);   // splits beyond nsplit re-read the last one (coefficient 0)
+    } else {
+        const uint32_t xs_lds = rg_lds_addr(xs);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {                              // PNORM 0: plain copy, 1 KiB per wave instruction straight into LDS
+            const int idx0 = wave * 64 + i * NT;            // first packed row of this wave's piece (uniform)
+            const int idx = idx0 + lane;
+            const int ci = idx < nvec ? idx : 0;                     // rows past the end copy row 0 into the padding (finite; never weighted)
+            rg_dma16(xs_lds + (uint32_t) idx0 * 16u, src + ci * 8);
+        }
+    }
+    RP_CLK(0);                                                       // activation requests issued
+    // ---- the rest of the kernel arguments into SGPRs ---------------------------------------------------------------------------
+    T16Matrix M0 = a.mat[0], M1 = a.mat[1], M2 = a.mat[2];
+    dec_pin(M0); dec_pin(M1); dec_pin(M2);
+    const f16* a_res = dec_pin_ptr(a.res_in);
+    int te0 = a.tile_end[0], te1 = a.tile_end[1], te2 = a.tile_end[2], a_nmat = a.nmat;
+    int a_rbw = a.rb_per_wave, nb = a.nblocks, units_lo = a.units_lo, units_rem = a.units_rem;
+    DEC_PIN_S(te0); DEC_PIN_S(te1); DEC_PIN_S(te2); DEC_PIN_S(a_nmat); DEC_PIN_S(a_rbw);
+    DEC_PIN_S(nb); DEC_PIN_S(units_lo); DEC_PIN_S(units_rem);
+    const int RB = M0.RB;
     const int nunits = EMODE == 2 ? te0 : (a_nmat == 1 ? te0 : a_nmat == 2 ? te1 : te2);
     const int b = blockIdx.x;
     const int n_my = units_lo + (b < units_rem ? 1 : 0);
@@ -189,7 +243,6 @@ __global__ __launch_bounds__(DEC_THREADS, 2 * OCC) void dec_ring_kernel(const De
     const int per = nunits >> 3;
     const int rb_lo = (wave % WPT) * a_rbw;
     const int rb_hi = min(RB, rb_lo + a_rbw);
-    const int nvec = K >> 3;
 
     auto describe = [&](int i) {
         const int v = b + i * nb;
@@ -237,54 +290,18 @@ __global__ __launch_bounds__(DEC_THREADS, 2 * OCC) void dec_ring_kernel(const De
         rg_ldw(ring[t % U], lane16, u.wbase + (size_t) (uint32_t) rb * 1024u);
     };
 
-    // ---- 1. activation loads (all waves), then the ring of the first unit -----------------------------------------------------
-    const f16* src = a_vec;
-    if constexpr (PNORM == 1) { if (a_tok) src = a_vec + (size_t) (*a_tok) * K; }
-    u32x4 xraw[NV], wraw[NV];
-    u32x4 praw[MS];
-    uint64_t pml = 0;
-    if constexpr (PNORM == 1) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int idx = tid + i * DEC_THREADS;
-            const int ci = idx < nvec ? idx : 0;
-            rg_ld16(xraw[i], src + ci * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int idx = tid + i * DEC_THREADS;
-            const int ci = idx < nvec ? idx : 0;
-            rg_ld16(wraw[i], a_norm_w + ci * 8);
-        }
-    } else if constexpr (PNORM == 3) {
-        // 16 consecutive 8-dim vectors = one head; lane (l & 15) also fetches (max, sum) of split l & 15 of that head
-        const int ci = tid < nvec ? tid : 0;
-        const int hd = ci >> 4, sp = min(lane & 15, a.att_nsplit - 1);
-        rg_ld8(pml, a.att_ml + ((size_t) hd * a.att_nsplit + sp) * 2);
-        const uint4* base = (const uint4*) (src + (size_t) hd * a.att_nsplit * 128 + (ci & 15) * 8);
-#pragma unroll
-        for (int sp2 = 0; sp2 < MS; ++sp2) rg_ld16(praw[sp2], base + min(sp2, a.att_nsplit - 1) * 16);   // splits beyond nsplit re-read the last one (coefficient 0)
-    } else {
-        const uint32_t xs_lds = rg_lds_addr(xs);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {                              // PNORM 0: plain copy, 1 KiB per wave instruction straight into LDS
-            const int idx0 = wave * 64 + i * DEC_THREADS;            // first packed row of this wave's piece (uniform)
-            const int idx = idx0 + lane;
-            const int ci = idx < nvec ? idx : 0;                     // rows past the end copy row 0 into the padding (finite; never weighted)
-            rg_dma16(xs_lds + (uint32_t) idx0 * 16u, src + ci * 8);
-        }
-    }
-    RP_CLK(0);                                                       // activation requests issued
     if (flags & 1) asm volatile("s_barrier" ::: "memory");           // every wave's activation request is queued before any weight request
     RingUnit cur = describe(0);
-    static_for<0, U>([&](auto jc) { issue_step(cur, std::integral_constant<int, (UL - U + decltype(jc)::value) % U>{}); });
-    RP_CLK(1);                                                       // ring of the first unit issued
+    // PRE of the U ring requests go out now; the rest follows the image barrier: a wave that is still queueing requests cannot
+    // reach that barrier, and nothing is consumed before it (PRE = U: the whole ring first)
+    static_for<0, PRE>([&](auto jc) { issue_step(cur, std::integral_constant<int, (UL - U + decltype(jc)::value) % U>{}); });
+    RP_CLK(1);                                                       // first ring requests issued
     // zero padding of the image: slots past a wave's range read it (finite x, scale 0)
-    for (int idx = tid; idx < IMG_ROWS; idx += DEC_THREADS)
-        if (idx >= nvec && (PNORM != 0 || idx >= NV * DEC_THREADS)) xs[idx] = make_uint4(0u, 0u, 0u, 0u);
+    for (int idx = tid; idx < IMG_ROWS; idx += NT)
+        if (idx >= nvec && (PNORM != 0 || idx >= NV * NT)) xs[idx] = make_uint4(0u, 0u, 0u, 0u);
 
     // ---- 2. activation image --------------------------------------------------------------------------------------------------
-    rg_wait<EL0 + U>();                                              // everything older than the ring has landed
+    rg_wait<ring_prologue_ops(U, UL, EL0, PRE)>();                   // everything older than the ring requests has landed
     RP_CLK(2);                                                       // activation landed
     if constexpr (PNORM == 1) {
         f16x8 xv[NV];
@@ -292,7 +309,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2 * OCC) void dec_ring_kernel(const De
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             rg_tie(xraw[i]); rg_tie(wraw[i]);
-            const int idx = tid + i * DEC_THREADS;
+            const int idx = tid + i * NT;
             xv[i] = __builtin_bit_cast(f16x8, xraw[i]);
             if (idx < nvec) {
                 if (a_tok && a.hid_copy && b == 0) *(f16x8*) (a.hid_copy + idx * 8) = xv[i];
@@ -300,20 +317,19 @@ __global__ __launch_bounds__(DEC_THREADS, 2 * OCC) void dec_ring_kernel(const De
                 for (int j = 0; j < 8; ++j) { const float f = (float) xv[i][j]; ss = fmaf(f, f, ss); }
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
-        if (lane == 0) red[2 * DEC_WAVES * 16 + wave] = ss;
+        ss = dec_wave_sum(ss);
+        if (lane == 0) red[2 * NW * 16 + wave] = ss;
         rg_barrier();
         float total = 0.f;
 #pragma unroll
-        for (int i = 0; i < DEC_WAVES; ++i) total += red[2 * DEC_WAVES * 16 + i];
+        for (int i = 0; i < NW; ++i) total += red[2 * NW * 16 + i];
         const f16 rm = (f16) (1.0f / sqrtf(total * (1.0f / (float) K) + a.eps));
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const f16x8 nw = __builtin_bit_cast(f16x8, wraw[i]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const f16 t = xv[i][j] * rm; xv[i][j] = t * nw[j]; }
-            const int idx = tid + i * DEC_THREADS;
+            const int idx = tid + i * NT;
             if (idx < nvec) xs[idx] = __builtin_bit_cast(uint4, xv[i]);
         }
     } else if constexpr (PNORM == 3) {
@@ -324,22 +340,18 @@ __global__ __launch_bounds__(DEC_THREADS, 2 * OCC) void dec_ring_kernel(const De
         const bool live = (lane & 15) < a.att_nsplit;
         const float pm = live ? __uint_as_float((uint32_t) pml) : -INFINITY;
         const float pl = live ? __uint_as_float((uint32_t) (pml >> 32)) : 0.f;
-        float M = pm;
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
+        const float M = dec_row_max(pm);
         const float lw = pm > -INFINITY ? pl * __expf(pm - M) : 0.f;
-        float L = lw;
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) L += __shfl_xor(L, off, 64);
+        const float L = dec_row_sum(lw);
         const float coef = lw / L;
         float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int sp2 = 0; sp2 < MS; ++sp2) {
-            const float cf = __shfl(coef, sp2, 16);
+        static_for<0, MS>([&](auto sc) {
+            constexpr int sp2 = decltype(sc)::value;
+            const float cf = dec_dpp<0x150 + sp2>(coef);              // row_newbcast: lane sp2 of this 16-lane row
             const f16x8 o8 = __builtin_bit_cast(f16x8, praw[sp2]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc8[j] = fmaf((float) o8[j], cf, acc8[j]);
-        }
+        });
         f16x8 r;
 #pragma unroll
         for (int j = 0; j < 8; ++j) r[j] = (f16) acc8[j];
@@ -347,6 +359,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2 * OCC) void dec_ring_kernel(const De
     }
     rg_barrier();
     RP_CLK(3);                                                       // image staged
+    static_for<PRE, U>([&](auto jc) { issue_step(cur, std::integral_constant<int, (UL - U + decltype(jc)::value) % U>{}); });
 
     // ---- 3. walk the units --------------------------------------------------------------------------------------------------------
     const uint32_t magic = t16_magic();
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2 * OCC) void dec_ring_kernel(const De
             if constexpr (li + U < UL) issue_step(uc, std::integral_constant<int, li + U>{});
             else if constexpr (!LAST) issue_step(un, std::integral_constant<int, li % U>{});
         });
-        float* rp = red + (i & 1) * DEC_WAVES * 16;
+        float* rp = red + (i & 1) * NW * 16;
         const float res = res_cur;                                   // (the next unit's entries may already be on their way: res_cur is this unit's)
         if (lane < 16) rp[wave * 16 + lane] = c[0];
         if (i == 0) RP_CLK(4);                                       // unit 0 consumed
@@ -384,7 +397,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2 * OCC) void dec_ring_kernel(const De
             } else {
                 float v = 0.f;
 #pragma unroll
-                for (int k = 0; k < DEC_WAVES; ++k) v += rp[k * 16 + tid];
+                for (int k = 0; k < NW; ++k) v += rp[k * 16 + tid];
                 if constexpr (EMODE == 0) a.out[uc.mi][n] = (f16) v;
                 else a.hid_io[n] = (f16) (v + res);
             }
@@ -412,26 +425,30 @@ __global__ __launch_bounds__(DEC_THREADS, 2 * OCC) void dec_ring_kernel(const De
 // ---------------------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------------------
-static size_t dec_ring_smem(int UL, int emode, int nv)
+static size_t dec_ring_smem(int UL, int emode, int nv, int nw)
 {
-    const int wpt = emode == 2 ? DEC_WAVES / 2 : DEC_WAVES;
-    const int rows = wpt * UL * 16 > nv * DEC_THREADS ? wpt * UL * 16 : nv * DEC_THREADS;
-    return (size_t) rows * 16 + (2 * DEC_WAVES * 16 + DEC_WAVES) * sizeof(float);
+    const int wpt = emode == 2 ? nw / 2 : nw;
+    const int rows = wpt * UL * 16 > nv * nw * 64 ? wpt * UL * 16 : nv * nw * 64;
+    return (size_t) rows * 16 + (2 * nw * 16 + nw) * sizeof(float);
 }
 
-template <int U, int UL, int PNORM, int EMODE, int NV>
-static int ring_go(int grid, const DecGemvArgs& a, hipStream_t s, int* plan)
+template <int U, int UL, int PNORM, int EMODE, int NV, int NW>
+static int ring_go(int grid, int rbw, const DecGemvArgs& a0, hipStream_t s, int* plan)
 {
-    auto kfn = dec_ring_kernel<U, UL, PNORM, EMODE, NV, (UL >= 24 ? 1 : 2)>;   // (the longest unrolled units want more than 128 registers)
-    const size_t smem = dec_ring_smem(UL, EMODE, NV);
-    if (plan) {                                                      // exl_decoder_plan: [0] launched, [1] U, [2] UL, [3] 2 = ring kernel, [4] PNORM, [5] EMODE, [6] NV
+    // (PRE < U -- part of the ring requested only after the activation image is staged -- measured within noise of PRE = U on
+    // every 7B class, round 3: the template parameter stays, one value is instantiated)
+    auto kfn = dec_ring_kernel<U, UL, PNORM, EMODE, NV, NW, U>;
+    const size_t smem = dec_ring_smem(UL, EMODE, NV, NW);
+    if (plan) {                                                      // exl_decoder_plan: [0] launched, [1] U, [2] UL, [3] 2 = ring kernel, [4] PNORM, [5] EMODE, [6] NV, [9] waves per block
         plan[0] = 1; plan[1] = U; plan[2] = UL; plan[3] = 2; plan[4] = PNORM; plan[5] = EMODE; plan[6] = NV;
-        plan[7] = grid; plan[8] = (int) smem; plan[9] = 1;
+        plan[7] = grid; plan[8] = (int) smem; plan[9] = NW;
         return 0;
     }
+    DecGemvArgs a = a0;
+    a.rb_per_wave = rbw;                                             // (the caller's value is for 8 waves per block)
     static bool big[EXL_MAX_DEVICES] = {};
     if (smem > 64 * 1024) EXL_TRY(exl_lds_opt_in((const void*) kfn, big));
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(DEC_THREADS), smem, s, a);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), smem, s, a);
     EXL_LAUNCH_CHECK();
     return 0;
 }
@@ -440,23 +457,26 @@ static int ring_go(int grid, const DecGemvArgs& a, hipStream_t s, int* plan)
 // an idle slot re-reads a valid row-block with scale 0, real traffic), the next listed value otherwise; 0 = not covered.
 // Only the lengths a kernel class can meet are instantiated: NV fixes the range of K, hence of the row-blocks per wave.
 #ifdef EXL_DEC_FAST_BUILD                                            /* ISA inspection / experiment builds: the 7B shapes */
-#define RING_ULS(X) X(4) X(8) X(11)
+#define RING_ULS(X) X(2) X(4) X(6) X(8) X(11)
 #else
-#define RING_ULS(X) X(4) X(5) X(6) X(7) X(8) X(10) X(11) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(28) X(32)
+#define RING_ULS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(28) X(32)
 #endif
-template <int PNORM, int EMODE, int NV>
+template <int PNORM, int EMODE, int NV, int NW>
 static int ring_cfg(int depth, int rbw, int grid, const DecGemvArgs& a, hipStream_t s, int* plan)
 {
-    constexpr int WPT = EMODE == 2 ? DEC_WAVES / 2 : DEC_WAVES;
-    constexpr int NVP = NV == 1 ? 0 : NV == 2 ? 1 : NV == 3 ? 2 : NV == 6 ? 3 : 6;   // the next smaller instantiated NV
-    constexpr int RBW_HI = NV * 32 / WPT, RBW_LO = NVP * 32 / WPT + 1;               // K in (NVP * 4096, NV * 4096]
+    constexpr int WPT = EMODE == 2 ? NW / 2 : NW;
+    constexpr int NVP = NV <= 3 ? NV - 1 : (NV == 4 || NV == 6) ? 3 : 6;              // the next smaller instantiated NV (8 waves: 1 2 3 6 8; 16 waves: 1 2 3 4)
+    constexpr int KU = NW * 64 * 8;                                                    // K covered by one vector per thread
+    constexpr int RBW_HI = NV * KU / 128 / WPT, RBW_LO = NVP * KU / 128 / WPT + 1;     // K in (NVP * KU, NV * KU]
     int prev = 0;
+    // (units shorter than the requested depth run with the ring as deep as the unit)
 #define RING_ONE(ULV)                                                                                                          \
-    if constexpr (((ULV) >= RBW_LO && (ULV) <= RBW_HI) || ((ULV) == 4 && RBW_LO <= 4)) {                                                       \
+    if constexpr (((ULV) >= RBW_LO && (ULV) <= RBW_HI) || ((ULV) <= 4 && RBW_LO <= 4 && (ULV) >= 2)) {                         \
         if (rbw > prev && rbw <= (ULV)) {                                                                                      \
-            if (depth <= 2) return ring_go<2, ULV, PNORM, EMODE, NV>(grid, a, s, plan);                                        \
-            if constexpr (ring_valid(3, ULV)) { if (depth == 3) return ring_go<3, ULV, PNORM, EMODE, NV>(grid, a, s, plan); }  \
-            return ring_go<4, ULV, PNORM, EMODE, NV>(grid, a, s, plan);                                                        \
+            constexpr int UMAX = (ULV) < 4 ? (ULV) : 4;                                                                        \
+            if (depth <= 2) return ring_go<2, ULV, PNORM, EMODE, NV, NW>(grid, rbw, a, s, plan);                              \
+            if constexpr (UMAX >= 3 && ring_valid(3, ULV)) { if (depth == 3) return ring_go<3, ULV, PNORM, EMODE, NV, NW>(grid, rbw, a, s, plan); } \
+            return ring_go<UMAX, ULV, PNORM, EMODE, NV, NW>(grid, rbw, a, s, plan);                                            \
         }                                                                                                                      \
         prev = (ULV);                                                                                                          \
     }
@@ -465,27 +485,40 @@ static int ring_cfg(int depth, int rbw, int grid, const DecGemvArgs& a, hipStrea
     return 1;
 }
 
-int launch_dec_ring(int pnorm, int emode, bool g16, int rbw, int nv, int grid, int depth, const DecGemvArgs& a, hipStream_t s, int* plan)
+int launch_dec_ring(int pnorm, int emode, bool g16, int K, int grid, int depth, bool wide_blocks, const DecGemvArgs& a, hipStream_t s, int* plan)
 {
     if (!g16 || a.out_perm) return 1;
     for (int i = 0; i < DEC_MAX_MATS; ++i)
         if (a.map16[i]) return 1;
-#define RING_GO(P, E, N) return ring_cfg<P, E, N>(depth, rbw, grid, a, s, plan)
+    const int RB = K / 128;
+    const bool wide = wide_blocks && pnorm == 0 && emode == 1 && RB >= 32;   // 16 waves: at least two row-blocks per wave
+    const int nw = wide ? 16 : DEC_WAVES;
+    const int wpt = emode == 2 ? nw / 2 : nw;
+    const int rbw = (RB + wpt - 1) / wpt;
+    const int nv = (K / 8 + nw * 64 - 1) / (nw * 64);
+#define RING_GO(P, E, N, W) return ring_cfg<P, E, N, W>(depth, rbw, grid, a, s, plan)
 #ifdef EXL_DEC_FAST_BUILD
-    if (pnorm == 1 && emode == 0 && nv == 1) RING_GO(1, 0, 1);
-    if (pnorm == 1 && emode == 2 && nv == 1) RING_GO(1, 2, 1);
-    if (pnorm == 3 && emode == 1 && nv == 1) RING_GO(3, 1, 1);
-    if (pnorm == 0 && emode == 1) { if (nv <= 1) RING_GO(0, 1, 1); if (nv <= 3) RING_GO(0, 1, 3); }
+    if (pnorm == 1 && emode == 0 && nv == 1) RING_GO(1, 0, 1, 8);
+    if (pnorm == 1 && emode == 2 && nv == 1) RING_GO(1, 2, 1, 8);
+    if (pnorm == 3 && emode == 1 && nv == 1) RING_GO(3, 1, 1, 8);
+    if (pnorm == 0 && emode == 1 && !wide) { if (nv <= 1) RING_GO(0, 1, 1, 8); if (nv <= 3) RING_GO(0, 1, 3, 8); }
+    if (pnorm == 0 && emode == 1 && wide) { if (nv <= 1) RING_GO(0, 1, 1, 16); if (nv <= 2) RING_GO(0, 1, 2, 16); }
 #else
-    if (pnorm == 1 && emode == 0) { if (nv <= 1) RING_GO(1, 0, 1); if (nv <= 2) RING_GO(1, 0, 2); }
-    if (pnorm == 1 && emode == 2) { if (nv <= 1) RING_GO(1, 2, 1); if (nv <= 2) RING_GO(1, 2, 2); }
-    if (pnorm == 3 && emode == 1 && nv <= 1) RING_GO(3, 1, 1);
-    if (pnorm == 0 && emode == 1) {
-        if (nv <= 1) RING_GO(0, 1, 1);
-        if (nv <= 2) RING_GO(0, 1, 2);
-        if (nv <= 3) RING_GO(0, 1, 3);
-        if (nv <= 6) RING_GO(0, 1, 6);
-        if (nv <= 8) RING_GO(0, 1, 8);
+    if (pnorm == 1 && emode == 0) { if (nv <= 1) RING_GO(1, 0, 1, 8); if (nv <= 2) RING_GO(1, 0, 2, 8); }
+    if (pnorm == 1 && emode == 2) { if (nv <= 1) RING_GO(1, 2, 1, 8); if (nv <= 2) RING_GO(1, 2, 2, 8); }
+    if (pnorm == 3 && emode == 1 && nv <= 1) RING_GO(3, 1, 1, 8);
+    if (pnorm == 0 && emode == 1 && !wide) {
+        if (nv <= 1) RING_GO(0, 1, 1, 8);
+        if (nv <= 2) RING_GO(0, 1, 2, 8);
+        if (nv <= 3) RING_GO(0, 1, 3, 8);
+        if (nv <= 6) RING_GO(0, 1, 6, 8);
+        if (nv <= 8) RING_GO(0, 1, 8, 8);
+    }
+    if (pnorm == 0 && emode == 1 && wide) {
+        if (nv <= 1) RING_GO(0, 1, 1, 16);
+        if (nv <= 2) RING_GO(0, 1, 2, 16);
+        if (nv <= 3) RING_GO(0, 1, 3, 16);
+        if (nv <= 4) RING_GO(0, 1, 4, 16);
     }
 #endif
 #undef RING_GO

@@ -274,7 +274,8 @@ int exl_decoder_plan(void* decoder, int cls, int* out10);
  * the kernels they were captured with. */
 #define EXL_DEC_OPT_RING       0
 #define EXL_DEC_OPT_RING_FENCE 1
-#define EXL_DEC_OPT_RING_DEPTH 2   /* 16-byte loads a lane keeps in flight in the ring stream: 2 .. 4 (default 4; EXL_DEC_RING_DEPTH) */
+#define EXL_DEC_OPT_RING_DEPTH 2   /* 16-byte loads a lane keeps in flight in the ring stream: 2 .. 4 (default 3, 4 where 3 does not fit the unit length; EXL_DEC_RING_DEPTH) */
+#define EXL_DEC_OPT_RING_WIDE  3   /* 1 (default; EXL_DEC_RING_WIDE): 16-wave blocks where a plain-vector launch leaves one block per CU */
 int exl_decoder_set_option(void* decoder, int option, int value);
 /* Tensor parallelism (not in the reference: doc/TODO.md:19; exllama_amd/tp.py): a decoder built from ONE rank's shard --
  * heads * head_dim < hidden (its own heads), its own intermediate columns, the full residual stream.  exl_decoder_step_part

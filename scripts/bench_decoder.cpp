@@ -2,7 +2,7 @@
 // Llama-7B-shaped GPTQ model in HBM, then reports per-kernel-class times (exl_decoder_step_timed) and the hipGraph
 // replay rate at two context lengths.  Doubles as a C-caller example of include/exl_amd.h.
 //   hipcc -O2 -std=c++17 scripts/bench_decoder.cpp -Iinclude -Lexllama_amd -lexl_amd -Wl,-rpath,'$ORIGIN/../exllama_amd' -o build/bench_decoder
-//   build/bench_decoder [layers=32] [ctx=2048] [groupsize=128]
+//   build/bench_decoder [layers=32] [ctx=2048] [groupsize=128] [contexts=2: ctx and 4; 1: ctx only (counter passes)]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -60,6 +60,7 @@ int main(int argc, char** argv)
     const int L = argc > 1 ? atoi(argv[1]) : 32;
     const int ctx = argc > 2 ? atoi(argv[2]) : 2048;
     const int gs = argc > 3 ? atoi(argv[3]) : 128;
+    const int nctx = argc > 4 ? atoi(argv[4]) : 2;
     const int h = 4096, I = 11008, heads = 32, kvh = 32, hd = 128, V = 32000, maxseq = ctx + 160;
     CK(hipSetDevice(0));
     _Float16 *embed, *lm_head, *fnorm, *sin, *cos;
@@ -92,7 +93,7 @@ int main(int argc, char** argv)
     CK(hipStreamCreate(&s));
     static const char* names[EXL_DEC_NCLASS] = {"qkv", "attn", "merge", "o_proj", "gate_up", "down", "head"};
     const int ctxs[2] = {ctx, 4};
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < nctx && c < 2; ++c) {
         const int32_t p0 = ctxs[c];
         CK(hipMemcpy(pos, &p0, 4, hipMemcpyHostToDevice));
         float ms[EXL_DEC_NCLASS];

@@ -343,16 +343,20 @@ def test_weight_arena_is_one_allocation_and_changes_nothing():
 #   size % 128 == 0) / per k-group (0: group sizes 32, 64)
 _REAL_SHAPES = {
     #        name   gs   act    L  qkv                    o_proj (>1 split)       gate_up                down                   merge kernel
-    "7b":  ("7b", 128, False, 2, (4, 4, 2, 1, 0, 1), (4, 4, 2, 3, 1, 1), (4, 8, 2, 1, 2, 1), (4, 11, 2, 0, 1, 3), False),
+    # 7B o_proj at one KV split and down_proj: 256 tiles = one block per CU -> 16-wave blocks (2 / 6 row-blocks per wave)
+    "7b":  ("7b", 128, False, 2, (3, 4, 2, 1, 0, 1), (3, 4, 2, 3, 1, 1), (3, 8, 2, 1, 2, 1), (4, 6, 2, 0, 1, 2), False),
     # (U, NP) fits the row-blocks per wave exactly where it can: 13B 5 / 10 / 14, 33B 7 / 13 / 18, 65B 8 / 16 / 22, 70B 8 / 16 / 28
     # 13B act-order: q/k/v and gate/up gather through their maps (dec_stream_kernel); o_proj / down_proj get their input already
     # in row order (ring)
-    "13b": ("13b", 128, True, 1, (5, 1, 1, 1, 0, 2), (4, 5, 2, 0, 1, 2), (5, 2, 1, 1, 2, 2), (4, 14, 2, 0, 1, 6), True),
+    "13b": ("13b", 128, True, 1, (5, 1, 1, 1, 0, 2), (4, 5, 2, 0, 1, 2), (5, 2, 1, 1, 2, 2), (3, 14, 2, 0, 1, 6), True),
     "33b": ("33b", 32, True, 1, (4, 2, 0, 1, 0, 2), (4, 2, 0, 0, 1, 2), (7, 2, 0, 1, 2, 2), (6, 3, 0, 0, 1, 6), True),
-    "65b": ("65b", 128, False, 1, (4, 8, 2, 1, 0, 2), (4, 8, 2, 0, 1, 2), (4, 16, 2, 1, 2, 2), (4, 22, 2, 0, 1, 6), True),
+    "65b": ("65b", 128, False, 1, (3, 8, 2, 1, 0, 2), (3, 8, 2, 0, 1, 2), (3, 16, 2, 1, 2, 2), (3, 22, 2, 0, 1, 6), True),
     # Llama-2-70B: GQA (8 kv heads) and K = 28672 in down_proj -- 28 row-blocks per wave, 7 -> 8 vectors per thread
-    "70b": ("70b", 128, False, 1, (4, 8, 2, 1, 0, 2), (4, 8, 2, 0, 1, 2), (4, 16, 2, 1, 2, 2), (4, 28, 2, 0, 1, 8), True),
+    "70b": ("70b", 128, False, 1, (3, 8, 2, 1, 0, 2), (3, 8, 2, 0, 1, 2), (3, 16, 2, 1, 2, 2), (3, 28, 2, 0, 1, 8), True),
 }
+
+
+_PLAIN_O_PROJ = {"7b": (2, 2, 2, 0, 1, 1)}      # o_proj at ONE KV split where it differs from "the merge variant with PNORM 0"
 
 
 def _plan(model, cls):
@@ -407,7 +411,7 @@ def test_native_decode_executor_at_real_layer_shapes(key):
                     plans = {cls: _plan(model, j) for j, cls in enumerate(model.DECODER_CLASSES)}
                     nsplit = plans["attn"][1]
                     assert tuple(plans["qkv"][1:7]) == p_qkv and tuple(plans["gate_up"][1:7]) == p_gu and tuple(plans["down"][1:7]) == p_down
-                    exp_o = p_o if nsplit > 1 else p_o[:3] + (0,) + p_o[4:]          # one split: plain o_proj, nothing to merge
+                    exp_o = p_o if nsplit > 1 else _PLAIN_O_PROJ.get(key, p_o[:3] + (0,) + p_o[4:])   # one split: plain o_proj, nothing to merge
                     assert tuple(plans["o_proj"][1:7]) == exp_o, (plans["o_proj"], exp_o)
                     assert bool(plans["merge"][0]) == (merge_kernel and nsplit > 1)
                     seen.add(nsplit)
@@ -435,9 +439,9 @@ def test_ring_stream_equals_compiler_stream_bit_for_bit(key):
     """decode_ring.hip (every vector-memory instruction inline asm, every wait counted by hand) against dec_stream_kernel
     (ordinary loads, hipcc's waits) on the same decoder: same arithmetic in the same order, so the logits, the appended K/V
     rows and the greedy tokens must be IDENTICAL bit patterns -- at the real layer shapes (7B; 13B act-order, where the ring
-    takes o_proj / down_proj only; 65B two-pass gate/up), with and without the start-up barrier, in the one-split and the
-    many-split attention buckets, several tokens in a row (each step consumes what the previous one wrote).  A miscounted
-    wait shows up here as a different bit somewhere, not as a tolerance question."""
+    takes o_proj / down_proj only; 65B / 70B long units), over the ring's options (start-up barrier, depth 2 - 4), in the one-split and the many-split attention buckets, several tokens in a row (each step consumes
+    what the previous one wrote).  A miscounted wait shows up here as a different bit somewhere, not as a tolerance question.
+    (16-wave blocks split K differently: those runs are held to fp32-reordering noise instead.)"""
     import ctypes as C
     from exllama_amd import cuda_ext
     from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
@@ -457,14 +461,15 @@ def test_ring_stream_equals_compiler_stream_bit_for_bit(key):
         model.forward(ids[:, :P], cache, preprocess_only=True)
         toks = ids[0, P:P + 4].tolist()
         runs = {}
-        for mode in ((0, 0, 4), (15, 1, 4), (15, 0, 3), (15, 1, 2)):  # (ring classes, start-up barrier, loads in flight per lane)
+        # (ring classes, start-up barrier, loads in flight per lane, 16-wave blocks)
+        modes = ((0, 0, 4, 0), (15, 1, 4, 0), (15, 0, 3, 0), (15, 1, 2, 0), (15, 1, 4, 1), (15, 0, 3, 1))
+        for mode in modes:
             c = ExLlamaCache(model, copy_from=cache)
             c.current_seq_len = P
             model.enable_decode_graph(c, use_graph=False)
             for sg in model._decoder["stages"]:
-                cuda_ext.check(lib.exl_decoder_set_option(sg["handle"], 0, mode[0]), "set_option")
-                cuda_ext.check(lib.exl_decoder_set_option(sg["handle"], 1, mode[1]), "set_option")
-                cuda_ext.check(lib.exl_decoder_set_option(sg["handle"], 2, mode[2]), "set_option")
+                for opt, val in enumerate(mode):
+                    cuda_ext.check(lib.exl_decoder_set_option(sg["handle"], opt, val), "set_option")
             kinds = {cls: _plan(model, j)[3] for j, cls in enumerate(model.DECODER_CLASSES) if cls in ("qkv", "o_proj", "gate_up", "down")}
             if mode[0]:
                 assert 2 in kinds.values(), kinds                    # the ring really is what ran
@@ -473,14 +478,19 @@ def test_ring_stream_equals_compiler_stream_bit_for_bit(key):
             out = [model.forward(torch.tensor([[t]], device="cuda:0"), c)[0, 0].float().cpu().numpy().copy() for t in toks]
             kv = [c.key_states[l][0, :, P:P + 4].cpu().numpy().copy() for l in range(L)]
             runs[mode] = (out, kv)
-        ref_out, ref_kv = runs[(0, 0, 4)]
-        for mode in ((15, 1, 4), (15, 0, 3), (15, 1, 2)):
+        ref_out, ref_kv = runs[modes[0]]
+        scale = float(np.abs(np.stack(ref_out)).max())
+        for mode in modes[1:]:
             out, kv = runs[mode]
             for i in range(len(toks)):
                 assert np.isfinite(out[i]).all()
-                assert np.array_equal(out[i].view(np.uint32), ref_out[i].view(np.uint32)), (key, P, mode, i, float(np.abs(out[i] - ref_out[i]).max()))
-            for l in range(L):
-                assert np.array_equal(kv[l].view(np.uint16), ref_kv[l].view(np.uint16)), (key, P, mode, l)
+                if mode[3] == 0:                                     # same split of K over the waves: the same additions in the same order
+                    assert np.array_equal(out[i].view(np.uint32), ref_out[i].view(np.uint32)), (key, P, mode, i, float(np.abs(out[i] - ref_out[i]).max()))
+                else:                                                # 16-wave blocks sum 16 partial dot products instead of 8: fp32 rounding only
+                    assert float(np.abs(out[i] - ref_out[i]).max()) <= 2.0 ** -8 * scale, (key, P, mode, i, float(np.abs(out[i] - ref_out[i]).max()), scale)
+            if mode[3] == 0:
+                for l in range(L):
+                    assert np.array_equal(kv[l].view(np.uint16), ref_kv[l].view(np.uint16)), (key, P, mode, l)
     model.free_unmanaged()
 
 
