@@ -510,10 +510,10 @@ def decoder_roofline_probe(model, cache, dims, g, ctx, steps=6):
     dom = "gate_up"
     achieved = per_launch[dom] / (ms[dom] / L / 1e3) / 1e9
     # HBM traffic of the same kernel from the PMC counters: collected OFFLINE in separate rocprofv3 --pmc passes
-    # (scripts/gpu_r02_profiles.sh -> profiles/r02_pmc_traffic.json); only valid for the shapes it was measured on
+    # (scripts/gpu_r03_profiles.sh -> profiles/r03_pmc_traffic.json); only valid for the shapes it was measured on
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
             pmc = json.load(f)
         if (h, I, g) == (4096, 11008, 128):
             traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
@@ -522,8 +522,8 @@ def decoder_roofline_probe(model, cache, dims, g, ctx, steps=6):
     return {"bound": "hbm", "kernel": "dec_ring_kernel<PNORM=1, EMODE=2> (fused RMSNorm + gate/up projections + SiLU*mul, one launch per layer)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
-            "traffic_source": ("offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (scripts/gpu_r02_profiles.sh), FETCH_SIZE doubled per "
-                               "MI355X_MICROARCH.md, committed as profiles/r02_pmc_traffic.json; not re-measured in this run") if traffic else None,
+            "traffic_source": ("offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (scripts/gpu_r03_profiles.sh), FETCH_SIZE doubled per "
+                               "MI355X_MICROARCH.md, committed as profiles/r03_pmc_traffic.json; not re-measured in this run") if traffic else None,
             "launches": L * steps, "avg_launch_us": round(ms[dom] * 1e3 / L, 3),
             "algorithmic_bytes_per_launch": int(per_launch[dom]), "classes": classes,
             "token_ms_sum_of_classes": round(sum(ms.values()), 4),
