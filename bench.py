@@ -44,6 +44,8 @@ def parse_args():
     p.add_argument("--gen", type=int, default=128)
     p.add_argument("--layers", type=int, default=None, help="debug: truncate the model (INVALID as a benchmark)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-baseline-full", action="store_true",
+                   help="time the CPU oracle on ALL layers instead of 2 extrapolated (needs ~30 GB of host memory and ~2 minutes for 7B)")
     p.add_argument("--no-graph", action="store_true", help="decode eagerly instead of replaying the captured hipGraph")
     p.add_argument("--host-argmax", action="store_true", help="greedy argmax by torch between graph replays (the reference's loop) instead of inside the graph")
     p.add_argument("--no-roofline-probe", action="store_true")
@@ -472,7 +474,16 @@ def main():
             result["prefill_roofline"] = {"error": str(exc)}
     # ---- CPU baseline: the oracle ("port") on a bounded sample of the same workload ----------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(dims, args.groupsize, ctx=S)
+        result["cpu_baseline"] = cpu_baseline(dims, args.groupsize, ctx=S,
+                                              sample_layers=dims.num_hidden_layers if args.cpu_baseline_full else 2)
+    # ---- the drop-in path (the reference's unmodified model.py on the cuda_ext shim, its own -p loop): measured offline by
+    # scripts/bench_dropin.py (it executes reference code, which exists only where the archive was staged) and quoted here
+    if rank == 0 and args.model == "7b" and args.groupsize == 128:
+        try:
+            with open(os.path.join(ROOT, "profiles", "r03_dropin_reference_model_py.json")) as f:
+                result["dropin_reference_model_py"] = dict(json.load(f), source="offline: scripts/bench_dropin.py, committed under profiles/; not re-measured in this run")
+        except Exception:
+            pass
 
     if rank == 0:
         print(json.dumps(result))
@@ -646,9 +657,10 @@ def cpu_baseline(dims, groupsize, sample_layers=2, prompt=128, gen=4, ctx=2048):
     return {"value": round(1.0 / decode_s, 3), "unit": "tokens/s", "cores": int(threads), "kind": "port",
             "prefill_tokens_per_s": round(prompt / prefill_s, 2),
             "decode_context": ctx,
-            "sample": f"{sample_layers} of {Lfull} layers of the same shapes, {prompt}-token prompt, then {gen} decode tokens at context {ctx}, "
-                      f"numpy/OpenBLAS fp32 GEMMs on weights dequantised once (untimed), extrapolated x{Lfull / sample_layers:.0f} "
-                      f"layers + lm_head; CPU: {os.cpu_count()} logical cores visible"}
+            "sample": (f"{sample_layers} of {Lfull} layers of the same shapes, {prompt}-token prompt, then {gen} decode tokens at context {ctx}, "
+                       f"numpy/OpenBLAS fp32 GEMMs on weights dequantised once (untimed), "
+                       + (f"extrapolated x{Lfull / sample_layers:.0f} layers" if sample_layers < Lfull else "full depth, nothing extrapolated")
+                       + f" + lm_head; CPU: {os.cpu_count()} logical cores visible; full-depth cross-check: profiles/r03_cpu_baseline_full_depth.json")}
 
 
 if __name__ == "__main__":

@@ -55,6 +55,8 @@ SIGNATURES = {
     "exl_column_remap": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "exl_half_matmul": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "exl_rms_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p]),
+    "exl_embedding": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "exl_head_matmul": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "exl_rope": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "exl_silu_mul": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "exl_update_cache": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

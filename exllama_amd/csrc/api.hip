@@ -7,6 +7,7 @@
 #include <mutex>
 #include <string.h>
 #include <unordered_set>
+#include <unordered_map>
 #include <vector>
 
 // ---- errors -------------------------------------------------------------------------------------------
@@ -96,6 +97,7 @@ struct DeviceGuard {
 // ---- Q4 handles -----------------------------------------------------------------------------------------
 static std::vector<Q4Matrix*> g_matrices;
 static std::unordered_set<void*> g_live;
+static std::unordered_map<const void*, Q4Matrix*> g_by_qweight;   // last handle that rewrote the tensor at this address in place
 
 // Registry state (handles, re-tiled buffers, device pool) is guarded by g_reg_mutex: the reference is single-threaded by
 // contract, a loader thread next to a serving thread must not corrupt the tables all the same.
@@ -129,6 +131,7 @@ extern "C" int exl_cleanup(void)
     for (Q4Matrix* m : g_matrices) free_matrix(m);
     g_matrices.clear();
     g_live.clear();
+    g_by_qweight.clear();
     for (int d = 0; d < EXL_MAX_DEVICES; ++d) {
 
         DeviceBuffers* b = &g_buffers[d];
@@ -171,9 +174,38 @@ extern "C" int exl_make_q4(int device, int height, int width, int groups, uint32
     m->scales = (f16*) scales;
     m->x_map = nullptr;
     m->layout = EXL_LAYOUT_GPTQ;
-    // NOTE: make_q4 re-tiles (and, with act-order, repacks -- as the reference does, q4_matrix.cu:159) `qweight` IN PLACE; a
-    // second make_q4 on the same tensor would re-tile re-tiled words.  It cannot be refused by address: handles live until
-    // cleanup() while the caller's allocator recycles the addresses of freed tensors.  include/exl_amd.h documents it.
+    m->fp_valid = false;
+    // make_q4 re-tiles (and, with act-order, repacks -- as the reference does, q4_matrix.cu:159) `qweight` IN PLACE: a second
+    // make_q4 on the same tensor would re-tile re-tiled words and silently compute garbage.  The address alone cannot decide (handles
+    // live until cleanup() while the caller's allocator recycles the addresses of freed tensors), so a handle keeps a fingerprint of
+    // the rewritten tensor -- its first and last 16 bytes -- and a call on an address a live handle rewrote is refused when the
+    // tensor STILL holds exactly those bytes (a recycled address with a fresh checkpoint tensor does not).
+    auto fingerprint = [&](uint32_t (&fp)[8]) -> hipError_t {
+        const size_t words = (size_t) height / 8 * width;
+        DeviceGuard guard(device);
+        hipError_t e = hipMemcpyAsync(fp, qweight, 16, hipMemcpyDeviceToHost, (hipStream_t) stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(fp + 4, qweight + (words >= 4 ? words - 4 : 0), 16, hipMemcpyDeviceToHost, (hipStream_t) stream);
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t) stream);
+        return e;
+    };
+    {
+        Q4Matrix* prev_h = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(g_reg_mutex);
+            auto it = g_by_qweight.find(qweight);
+            if (it != g_by_qweight.end() && g_live.count(it->second)) prev_h = it->second;
+        }
+        if (prev_h && prev_h->fp_valid && prev_h->device == device && prev_h->height == height && prev_h->width == width) {
+            uint32_t now[8];
+            const hipError_t e = fingerprint(now);
+            if (e != hipSuccess) { delete m; EXL_FAIL((int) e, "make_q4: %s", hipGetErrorString(e)); }
+            if (memcmp(now, prev_h->fp, sizeof(now)) == 0) {
+                delete m;
+                EXL_FAIL(EXL_E_INVALID, "make_q4: this qweight tensor was already rewritten in place by a live handle (make_q4 consumes its "
+                         "tensor: build a second handle from a fresh copy of the checkpoint tensor)");
+            }
+        }
+    }
 
     if (g_idx_host) {
         // stable counting sort of rows by group -> x_map (new row -> old row); integer-exact restatement of
@@ -201,10 +233,16 @@ extern "C" int exl_make_q4(int device, int height, int width, int groups, uint32
         const int r = launch_retile_t16(m, (hipStream_t) stream);
         if (r) { free_matrix(m); return r; }
     }
+    if (m->x_map || m->layout == EXL_LAYOUT_T16) {                    // the tensor was rewritten: remember what it looks like now
+        const hipError_t e = fingerprint(m->fp);
+        if (e != hipSuccess) { free_matrix(m); EXL_FAIL((int) e, "make_q4: %s", hipGetErrorString(e)); }
+        m->fp_valid = true;
+    }
     {
         std::lock_guard<std::mutex> lock(g_reg_mutex);
         g_matrices.push_back(m);
         g_live.insert(m);
+        if (m->fp_valid) g_by_qweight[qweight] = m;
     }
     *out_handle = m;
     return 0;
@@ -219,6 +257,8 @@ extern "C" int exl_free_q4(void* handle)
         for (size_t i = 0; i < g_matrices.size(); ++i)
             if (g_matrices[i] == m) { g_matrices.erase(g_matrices.begin() + i); break; }
         g_live.erase(m);
+        auto it = g_by_qweight.find(m->qweight);
+        if (it != g_by_qweight.end() && it->second == m) g_by_qweight.erase(it);
     }
     free_matrix(m);
     return 0;
@@ -387,6 +427,18 @@ extern "C" int exl_rms_norm(const void* x, const void* w, void* out, float epsil
 {
     EXL_REQUIRE(x && w && out, EXL_E_INVALID, "rms_norm: null pointer");
     return launch_rms_norm((const f16*) x, (const f16*) w, (f16*) out, epsilon, rows, dim, (hipStream_t) stream);
+}
+
+extern "C" int exl_embedding(const int64_t* ids_dev, const void* table, void* out, int n_ids, int hidden, int vocab, void* stream)
+{
+    EXL_REQUIRE(ids_dev && table && out, EXL_E_INVALID, "embedding: null pointer");
+    return launch_embedding(ids_dev, (const f16*) table, (f16*) out, n_ids, hidden, vocab, (hipStream_t) stream);
+}
+
+extern "C" int exl_head_matmul(const void* x, const void* w, float* out, int rows, int hidden, int vocab, void* stream)
+{
+    EXL_REQUIRE(x && w && out, EXL_E_INVALID, "head_matmul: null pointer");
+    return launch_head_rows((const f16*) x, (const f16*) w, out, rows, hidden, vocab, (hipStream_t) stream);
 }
 
 extern "C" int exl_rope(void* x, const void* sin, const void* cos, int bsz, int rows_per_batch, int head_dim,

@@ -65,6 +65,8 @@ struct Q4Matrix {
     f16* scales;       // borrowed [G, N]
     uint32_t* x_map;   // owned   [K] or NULL (act-order)
     int layout;        // EXL_LAYOUT_GPTQ or EXL_LAYOUT_T16
+    uint32_t fp[8];    // first and last 16 bytes of qweight AFTER the in-place rewrite (make_q4's double-call guard); fp_valid: rewritten
+    bool fp_valid;
 };
 #define EXL_LAYOUT_GPTQ 0   // as loaded; kept only for shapes the T16 tiling cannot express (K % 128 or N % 16 != 0)
 #define EXL_LAYOUT_T16  1   // the product layout
@@ -113,6 +115,8 @@ int launch_half_gemm(const f16* x, const f16* w, f16* out, int M, int K, int N, 
 
 int launch_dec_sample(float* logits, float* probs, int64_t* history, int64_t* token_io, const int32_t* pos_dev, const float* uniforms,
                       float* prob_out, int vocab, const ExlSampler* s, hipStream_t stream);
+int launch_embedding(const int64_t* ids, const f16* table, f16* out, int n_ids, int hidden, int vocab, hipStream_t s);
+int launch_head_rows(const f16* x, const f16* w, float* out, int rows, int hidden, int vocab, hipStream_t s);   // 1 = not covered
 int launch_rms_norm(const f16* x, const f16* w, f16* out, float eps, int rows, int dim, hipStream_t s);
 int launch_rope(f16* x, const f16* sin, const f16* cos, int bsz, int rows_per_batch, int head_dim, int num_heads,
                 int past_len, const int32_t* past_len_dev, hipStream_t s);

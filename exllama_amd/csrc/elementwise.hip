@@ -201,3 +201,86 @@ int launch_update_cache(const f16* k, const f16* v, f16* kc, f16* vc, int bsz, i
     EXL_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Embedding lookup and the prompt pass' lm_head for a handful of rows (reference: torch ops, model.py:1002 embed_tokens and
+// :1077 lm_head -- ATen / cuBLAS there, ATen / hipBLASLt here until round 3; the decode executor has its own fused forms).
+//   embedding: one block per token, 16-byte copies of the table row.
+//   head: one wave per vocabulary row (128-bit streaming loads of the fp16 matrix: read exactly once), the activation rows
+//         staged in LDS; fp32 accumulate, rounded to fp16 like nn.Linear in fp16, returned as fp32 (model.py:1077-1080).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embedding_kernel(const int64_t* __restrict__ ids, const f16* __restrict__ table, f16* __restrict__ out,
+                                                        int hidden, int vocab)
+{
+    const int64_t id = ids[blockIdx.x];
+    const int64_t row = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);          // (torch raises on the host; here: clamp, never fault)
+    const uint4* src = (const uint4*) (table + (size_t) row * hidden);
+    uint4* dst = (uint4*) (out + (size_t) blockIdx.x * hidden);
+    for (int i = threadIdx.x; i < hidden / 8; i += 256) dst[i] = src[i];
+}
+
+int launch_embedding(const int64_t* ids, const f16* table, f16* out, int n_ids, int hidden, int vocab, hipStream_t s)
+{
+    if (n_ids <= 0) return 0;
+    EXL_REQUIRE(hidden % 8 == 0, EXL_E_UNSUPPORTED, "embedding: hidden size (%d) must be a multiple of 8", hidden);
+    hipLaunchKernelGGL(embedding_kernel, dim3(n_ids), dim3(256), 0, s, ids, table, out, hidden, vocab);
+    EXL_LAUNCH_CHECK();
+    return 0;
+}
+
+#define HEAD_MAX_ROWS 8
+template <int ROWS>
+__global__ __launch_bounds__(256) void head_rows_kernel(const f16* __restrict__ x, const f16* __restrict__ w, float* __restrict__ out,
+                                                        int hidden, int vocab, int rows_per_block)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4* xs = (uint4*) smem;                                               // [ROWS][hidden / 8]
+    const int nvec = hidden >> 3;
+    for (int i = threadIdx.x; i < ROWS * nvec; i += 256) xs[i] = ((const uint4*) x)[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row0 = blockIdx.x * rows_per_block;
+    for (int r = wave; r < rows_per_block; r += 4) {
+        const int v = row0 + r;
+        if (v >= vocab) break;
+        const f16* wr = w + (size_t) v * hidden;
+        float acc[ROWS];
+#pragma unroll
+        for (int m = 0; m < ROWS; ++m) acc[m] = 0.f;
+        for (int i = lane; i < nvec; i += 64) {
+            const uint4 wv = nt_load16(wr + i * 8);
+#pragma unroll
+            for (int m = 0; m < ROWS; ++m) {
+                const uint4 xv = xs[m * nvec + i];
+                acc[m] = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, wv.x), __builtin_bit_cast(f16x2, xv.x), acc[m], false);
+                acc[m] = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, wv.y), __builtin_bit_cast(f16x2, xv.y), acc[m], false);
+                acc[m] = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, wv.z), __builtin_bit_cast(f16x2, xv.z), acc[m], false);
+                acc[m] = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, wv.w), __builtin_bit_cast(f16x2, xv.w), acc[m], false);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < ROWS; ++m) {
+            float a = acc[m];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+            if (lane == 0) out[(size_t) m * vocab + v] = (float) (f16) a;
+        }
+    }
+}
+
+// 1 = not covered (more rows than the kernel stages: the caller uses its BLAS path)
+int launch_head_rows(const f16* x, const f16* w, float* out, int rows, int hidden, int vocab, hipStream_t s)
+{
+    if (rows <= 0) return 0;
+    if (rows > HEAD_MAX_ROWS || hidden % 8 != 0 || (size_t) HEAD_MAX_ROWS * hidden * 2 > 64 * 1024) return 1;
+    const int rpb = 32;
+    const dim3 grid((vocab + rpb - 1) / rpb);
+    const size_t smem = (size_t) rows * hidden * 2;
+    switch (rows) {
+#define HEAD_CASE(R) case R: hipLaunchKernelGGL(head_rows_kernel<R>, grid, dim3(256), smem, s, x, w, out, hidden, vocab, rpb); break;
+        HEAD_CASE(1) HEAD_CASE(2) HEAD_CASE(3) HEAD_CASE(4) HEAD_CASE(5) HEAD_CASE(6) HEAD_CASE(7) HEAD_CASE(8)
+#undef HEAD_CASE
+    }
+    EXL_LAUNCH_CHECK();
+    return 0;
+}

@@ -8,11 +8,11 @@
 //                            registers by every wave; the activation tile goes through LDS in the nibble order;
 //   q4_gemm_t16m_kernel      T16 layout, weights dequantised ONCE per block into an LDS tile, mid-step barrier schedule
 //                            (256 x 128 tile: the fallback of the next one; 128 x 128 tile, optionally with K cut in two:
-//                            EXL_GEMM_TILE128 / EXL_GEMM_SPLITK, see launch_q4_gemm);
+//                            257 .. 512 rows / EXL_GEMM_SPLITK, see launch_q4_gemm);
 //   q4_gemm_t16w_kernel<EPI> the default above 256 rows: 8 MFMA waves + 4 loader waves on a 256 x 128 tile; EPI 1 is the
 //                            q/k/v projection with RoPE and the KV-cache write as its epilogue (> 512 rows);
 //   q4_gemm_t16d2_kernel     gate and up projections of the MLP in one kernel with the SiLU epilogue, software-pipelined
-//                            (> 512 rows; q4_gemm_t16d_kernel is its un-pipelined predecessor);
+//                            (> 512 rows);
 //   (q4_gemm_skinny.hip)     <= 256 rows: the decode-shaped short-prompt kernel;
 //   half_gemm_kernel         plain fp16 GEMM of the LoRA path (correctness first).
 // Act-order weights: x is gathered through x_map by column_remap into the borrowed temp_state buffer first
@@ -268,7 +268,7 @@ __device__ unsigned long long g_gemm_probe[1024 * 8 * 4];
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------
-// Mid-step barrier schedule (the fallback of the wave-specialised kernel; 128-row tile variant behind EXL_GEMM_TILE128).  Stall attribution of its
+// Mid-step barrier schedule (the fallback of the wave-specialised kernel; 128-row tile variant for 257 .. 512 rows).  Stall attribution of its
 // predecessor, which loaded, dequantised and multiplied tile by tile (scripts/probe_gemm.hip, profiles/r01_gemm_ablation.txt):
 // of ~2100 cycles per K step only ~1000 were MFMA issue; after every barrier both waves of a
 // SIMD wait for their first fragments, and the dequant + LDS store (300 cycles) and the barrier (150-500) run with an
@@ -949,202 +949,11 @@ int launch_q4_qkv_rope_cache(const Q4Matrix* wq, const Q4Matrix* wk, const Q4Mat
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Dual-weight variant for the MLP up-projection of the prompt pass: out = silu(x @ Wgate) * (x @ Wup) (or both products)
-// in ONE kernel.  A block computes the SAME 256 x 128 output tile of both matrices from one activation tile: the
-// activation DMA and fragment reads are shared (24 instead of 32 LDS fragment reads per 64 MFMAs), there are 64 MFMAs
-// per wave between barriers instead of 32, and the gate / up products never travel through HBM.
-// Same pipeline as above with a 2-slot activation ring (a K step is twice as long): per step the wave issues the DMA of
-// tile t+1 (4 operations) and then the packed weights of tile t+2 of both matrices (6 operations); "vmcnt(6)" at the end
-// of the step therefore means: tile t+1's activations and tile t+1's weights have landed.
-// ---------------------------------------------------------------------------------------------------------------
-template <bool SILU>
-__global__ __launch_bounds__(512) void q4_gemm_t16d_kernel(const f16* __restrict__ x, const uint4* __restrict__ qw1,
-                                                           const uint32_t* __restrict__ qz1, const f16* __restrict__ sc1,
-                                                           const uint4* __restrict__ qw2, const uint32_t* __restrict__ qz2,
-                                                           const f16* __restrict__ sc2, f16* __restrict__ out1,
-                                                           f16* __restrict__ out2, int M, int K, int N, int gshift,
-                                                           int groupsize, int mtiles, int ntiles)
-{
-    constexpr int TBM = 256;
-    constexpr int A_BYTES = TBM * 128;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [2][A] then [2][B1 | B2]
-    unsigned char* const ldsB = lds + 2 * A_BYTES;
-
-    const int b = blockIdx.x;
-    const int xcd = b & 7;
-    const int idx = b >> 3;
-    const int nl = idx / mtiles;
-    const int mt = idx - nl * mtiles;
-    const int nt = nl * 8 + xcd;
-    if (nt >= ntiles) return;
-    const int m0 = mt * TBM;
-    const int n0 = nt * GT_BN;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int RB = K >> 7;
-    const int nk = K / GT_BK;                                         // even, >= 2
-
-    uint32_t a_off[4];                                                 // element offsets from x (M * K < 2^32 checked on the host)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = wave * 4 + i;
-        const int row = c * 8 + (lane >> 3);
-        const int slot = lane & 7;
-        const int grow = min(m0 + row, M - 1);
-        a_off[i] = (uint32_t) grow * (uint32_t) K + ((slot ^ (row & 7)) << 3);
-    }
-    auto stage_a = [&](int slot2, int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __attribute__((address_space(3))) unsigned char* dst =
-                (__attribute__((address_space(3))) unsigned char*) (lds + (size_t) slot2 * A_BYTES + (wave * 4 + i) * 1024);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (x + (size_t) (a_off[i] + (uint32_t) k0)), dst, 16, 0, 0);
-        }
-    };
-
-    const int pid = tid >> 1, ph = tid & 1;                            // half a T16 piece of EACH matrix per thread per K step
-    const int b_tile = pid >> 5;
-    const int b_rs = (pid >> 4) & 1;
-    const int b_col = pid & 15;
-    const int b_nloc = b_tile * 16 + b_col;
-    const int b_n = min(n0 + b_nloc, N - 1);
-    const size_t piece0 = ((size_t) (b_n >> 4) * RB) * 64 + (b_n & 15);
-    const uint32_t* b_src1 = (const uint32_t*) (qw1 + piece0) + ph * 2;
-    const uint32_t* b_src2 = (const uint32_t*) (qw2 + piece0) + ph * 2;
-    const int b_zsh = (b_n & 7) * 4;
-    const uint32_t magic = t16_magic();
-
-    struct BRegs { u32x2 wa; uint32_t za, sa; u32x2 wb; uint32_t zb, sb; };
-    auto issue_b = [&](int it, BRegs& r) {
-        const int rb = it >> 1, rsub = (it & 1) * 2 + b_rs;
-        const size_t po = ((size_t) rb * 64 + rsub * 16) * 4;
-        const int k = it * GT_BK + b_rs * 32;
-        const int grp = gshift >= 0 ? (k >> gshift) : (k / groupsize);
-        const size_t zo = (size_t) grp * (N >> 3) + (b_n >> 3), so = (size_t) grp * N + b_n;
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r.wa) : "v"(b_src1 + po) : "memory");
-        asm volatile("global_load_dword %0, %1, off" : "=v"(r.za) : "v"(qz1 + zo) : "memory");
-        asm volatile("global_load_ushort %0, %1, off" : "=v"(r.sa) : "v"(sc1 + so) : "memory");
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r.wb) : "v"(b_src2 + po) : "memory");
-        asm volatile("global_load_dword %0, %1, off" : "=v"(r.zb) : "v"(qz2 + zo) : "memory");
-        asm volatile("global_load_ushort %0, %1, off" : "=v"(r.sb) : "v"(sc2 + so) : "memory");
-    };
-#define GD_WAIT(NSTR, r) asm volatile("s_waitcnt vmcnt(" NSTR ")" : "+v"(r.wa), "+v"(r.za), "+v"(r.sa), "+v"(r.wb), "+v"(r.zb), "+v"(r.sb) :: "memory")
-    auto store_one = [&](int slot2, int which, u32x2 w, uint32_t zw, uint32_t scb) {
-        const int z = (int) ((zw >> b_zsh) & 0xFu) + 1;
-        const f16 za = (f16) (float) (-(1024 + z));
-        const f16 zb = (f16) (float) (-(64 + z));
-        const f16 bsc = __builtin_bit_cast(f16, (uint16_t) (scb & 0xFFFFu));
-        const f16x2 zc0 = {za, za}, zc1 = {zb, zb}, s2 = {bsc, bsc};
-        const uint32_t lbase = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned char*) (ldsB + (size_t) (slot2 * 2 + which) * GT_BTILE_BYTES);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const f16x8 d = t16_dequant_exact(w[j], magic, zc0, zc1);
-            const uint4 u = __builtin_bit_cast(uint4, d);
-            const u32x4 ov = {__builtin_bit_cast(uint32_t, as_h2(u.x) * s2), __builtin_bit_cast(uint32_t, as_h2(u.y) * s2),
-                              __builtin_bit_cast(uint32_t, as_h2(u.z) * s2), __builtin_bit_cast(uint32_t, as_h2(u.w) * s2)};
-            asm volatile("ds_write_b128 %0, %1" :: "v"(lbase + (uint32_t) gt_off(b_nloc, b_rs * 4 + ph * 2 + j)), "v"(ov) : "memory");
-        }
-    };
-    auto store_b = [&](int slot2, const BRegs& r) {
-        store_one(slot2, 0, r.wa, r.za, r.sa);
-        store_one(slot2, 1, r.wb, r.zb, r.sb);
-    };
-    auto block_barrier = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    };
-
-    f32x4 acc1[4][4], acc2[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-
-    const int fr = lane & 15, fk = lane >> 4;
-    auto compute = [&](int slot2) {
-        const unsigned char* at = lds + (size_t) slot2 * A_BYTES;
-        const unsigned char* b1 = ldsB + (size_t) (slot2 * 2) * GT_BTILE_BYTES;
-        const unsigned char* b2 = b1 + GT_BTILE_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            f16x8 xf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) xf[i] = *(const f16x8*) (at + gt_off((wm * 4 + i) * 16 + fr, kk * 4 + fk));
-#pragma unroll
-            for (int in = 0; in < 4; ++in) {                            // one weight fragment pair live at a time (register budget)
-                const f16x8 w1 = *(const f16x8*) (b1 + gt_off((wn * 4 + in) * 16 + fr, kk * 4 + fk));
-                const f16x8 w2 = *(const f16x8*) (b2 + gt_off((wn * 4 + in) * 16 + fr, kk * 4 + fk));
-#pragma unroll
-                for (int im = 0; im < 4; ++im) {
-                    acc1[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, xf[im], acc1[in][im], 0, 0, 0);
-                    acc2[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, xf[im], acc2[in][im], 0, 0, 0);
-                }
-            }
-        }
-    };
-
-    // ---- prologue ---------------------------------------------------------------------------------------------------
-    BRegs rX, rY;                                                         // X: even tiles, Y: odd tiles
-    stage_a(0, 0);
-    issue_b(0, rX);
-    issue_b(1, rY);
-    GD_WAIT("6", rX);                                                     // A(0) and B(0) landed
-    store_b(0, rX);
-    block_barrier();
-
-    int t = 0;
-    for (; t + 3 < nk; t += 2) {
-        stage_a(1, (t + 1) * GT_BK);  issue_b(t + 2, rX);  compute(0);  GD_WAIT("6", rY);  store_b(1, rY);  block_barrier();
-        stage_a(0, (t + 2) * GT_BK);  issue_b(t + 3, rY);  compute(1);  GD_WAIT("6", rX);  store_b(0, rX);  block_barrier();
-    }
-    // t = nk - 2: only the activation tile nk-1 is left to fetch
-    stage_a(1, (t + 1) * GT_BK);
-    compute(0);
-    GD_WAIT("0", rY);
-    store_b(1, rY);
-    block_barrier();
-    compute(1);
-#undef GD_WAIT
-
-    // ---- epilogue ------------------------------------------------------------------------------------------------------
-#pragma unroll
-    for (int im = 0; im < 4; ++im) {
-        const int row = m0 + (wm * 4 + im) * 16 + fr;
-        if (row < M) {
-#pragma unroll
-            for (int in = 0; in < 4; ++in) {
-                const int n = n0 + (wn * 4 + in) * 16 + fk * 4;
-                if (n < N) {
-                    const size_t o = (size_t) row * N + n;
-                    f16x4 g, u;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { g[j] = (f16) acc1[in][im][j]; u[j] = (f16) acc2[in][im][j]; }
-                    if constexpr (SILU) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {                 // exactly elementwise.hip: silu_mul_h on the fp16 values
-                            const f16 e = (f16) __expf((float) (f16) (-g[j]));
-                            const f16 sm = (f16) 1.0f + e;
-                            const f16 rc = (f16) (1.0f / (float) sm);
-                            const f16 v = g[j] * rc;
-                            g[j] = v * u[j];
-                        }
-                        *(f16x4*) (out1 + o) = g;
-                    } else {
-                        *(f16x4*) (out1 + o) = g;
-                        *(f16x4*) (out2 + o) = u;
-                    }
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// The dual kernel with the software pipeline of q4_gemm_t16m_kernel.  SQ counters of its predecessor above
-// (profiles/r02_pmc_dual_gemm.txt): matrix pipes busy 48 % of a launch, a wave 37 % of its life in s_waitcnt / s_barrier
+// Dual-weight kernel for the MLP up-projection of the prompt pass: out = silu(x @ Wgate) * (x @ Wup) (or both products) in ONE
+// kernel.  A block computes the SAME 256 x 128 output tile of both matrices from one activation tile: the activation DMA and
+// fragment reads are shared (24 instead of 32 LDS fragment reads per 64 MFMAs) and the gate / up products never travel through
+// HBM.  It carries the software pipeline of q4_gemm_t16m_kernel.  SQ counters of its un-pipelined predecessor (removed in round
+// 3; profiles/r02_pmc_dual_gemm.txt): matrix pipes busy 48 % of a launch, a wave 37 % of its life in s_waitcnt / s_barrier
 // and only 4 % of it waiting for LDS -- both waves of a SIMD walk the same phases (fragment reads -> 64 MFMAs -> wait ->
 // dequantise + store -> barrier) at the same time, so the matrix pipe idles through every wait, store and barrier.
 // Here a K step is cut into 8 groups of 8 MFMAs (one weight fragment pair x 4 activation fragments x 2 matrices); the
@@ -1153,7 +962,7 @@ __global__ __launch_bounds__(512) void q4_gemm_t16d_kernel(const f16* __restrict
 // back across the barrier: it runs while the first fragments of tile t + 1 are on their way.  Registers: 128 accumulators
 // + 56 fragment registers (two activation sets, three weight pairs) -- the full P / Q double set of the single-matrix
 // kernel (96) does not fit next to 128 accumulators.  3-slot activation ring + 2 x 2 weight tiles = 160 KiB of LDS.
-// Same values, same order of accumulation: bit-identical to q4_gemm_t16d_kernel.
+// (Bit-identical to its un-pipelined predecessor q4_gemm_t16d_kernel, removed in round 3.)
 // ---------------------------------------------------------------------------------------------------------------
 template <bool SILU>
 __global__ __launch_bounds__(512) void q4_gemm_t16d2_kernel(const f16* __restrict__ x, const uint4* __restrict__ qw1,
@@ -1405,17 +1214,11 @@ int launch_q4_gemm_dual(const Q4Matrix* w1, const Q4Matrix* w2, const f16* x, in
     const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
 #define GD_ARGS x, (const uint4*) w1->qweight, w1->qzeros, w1->scales, (const uint4*) w2->qweight, w2->qzeros, w2->scales, out1, out2, \
                 rows, K, N, gshift, w1->groupsize, mtiles, ntiles
-    static const bool unpipelined = getenv("EXL_GEMM_DUAL_UNPIPELINED") != nullptr;   // A/B switch: the predecessor (compiler-scheduled K step)
-    // the pipelined kernel: power-of-two groups (one shift), 32-bit byte offsets into the weight / scale / activation arrays
+    // power-of-two groups (one shift), 32-bit byte offsets into the weight / scale / activation arrays; anything else runs as the
+    // separate products
     const bool pipelined_ok = gshift >= 5 && (uint64_t) K * (uint64_t) N < (1ull << 32) && (uint64_t) rows * (uint64_t) K < (1ull << 31);
-    if (unpipelined || !pipelined_ok) {
-        const size_t smem = 2 * (size_t) 256 * 128 + 4 * GT_BTILE_BYTES;
-        static bool big_silu[EXL_MAX_DEVICES] = {}, big_pair[EXL_MAX_DEVICES] = {};
-        EXL_TRY(exl_lds_opt_in((const void*) q4_gemm_t16d_kernel<true>, big_silu));
-        EXL_TRY(exl_lds_opt_in((const void*) q4_gemm_t16d_kernel<false>, big_pair));
-        if (silu) hipLaunchKernelGGL(q4_gemm_t16d_kernel<true>, dim3(grid), dim3(512), smem, s, GD_ARGS);
-        else      hipLaunchKernelGGL(q4_gemm_t16d_kernel<false>, dim3(grid), dim3(512), smem, s, GD_ARGS);
-    } else {
+    if (!pipelined_ok) return 1;
+    {
         const size_t smem = 3 * (size_t) 256 * 128 + 4 * GT_BTILE_BYTES;              // 160 KiB: the whole LDS of a CU
         static bool big_silu[EXL_MAX_DEVICES] = {}, big_pair[EXL_MAX_DEVICES] = {};
         EXL_TRY(exl_lds_opt_in((const void*) q4_gemm_t16d2_kernel<true>, big_silu));
@@ -1473,7 +1276,8 @@ int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
     }
     // short prompts: the decode-shaped kernel, 32 rows x (16 .. 64) columns per block, waves split K (q4_gemm_skinny.hip)
     static const int skinny_max = getenv("EXL_GEMM_SKINNY_MAX") ? atoi(getenv("EXL_GEMM_SKINNY_MAX")) : 256;
-    if (w->layout == EXL_LAYOUT_T16 && rows <= skinny_max && !getenv("EXL_GEMM_REGISTER_B")) {
+    static const bool use_reg_b = getenv("EXL_GEMM_REGISTER_B") != nullptr;     // A/B switch: the generic register-B kernel
+    if (w->layout == EXL_LAYOUT_T16 && rows <= skinny_max && !use_reg_b) {
         const int r = launch_gemm_t16s(w, xin, rows, out, no_zero, s);
         if (r != 1) return r;
     }
@@ -1482,19 +1286,19 @@ int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
     const int mtiles = (rows + BM - 1) / BM;
     const int ntiles = (N + BN - 1) / BN;
     const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
-    static const bool use_reg_b = getenv("EXL_GEMM_REGISTER_B") != nullptr;     // A/B switch: the generic register-B kernel
     static const bool no_spec = getenv("EXL_GEMM_NO_LOADER_WAVES") != nullptr;   // A/B switch: mid-step kernel for every row count
     if (w->layout == EXL_LAYOUT_T16 && !use_reg_b && (uint64_t) rows * (uint64_t) K < (1ull << 31)) {    // 32-bit activation byte offsets
-        // 257 .. 512 rows take the 256-row kernels too: the 128 x 128 variant below corrupted accumulators at 400 rows x 11008
-        // columns (in-flight "redundant" fetches landing in registers the compiler had reused; fixed at the end of round 2 by tying
-        // the final wait to those registers, see q4_gemm_t16m_kernel and DESIGN.md 9.5), and the fix has not been re-run under the
-        // failing scenario yet.  EXL_GEMM_TILE128=1 selects the 128-row tile for 257 .. 512 rows (about 10 % faster at 300 - 384 rows).
-        static const bool tile128 = getenv("EXL_GEMM_TILE128") != nullptr;
+        // 257 .. 512 rows: the 128 x 128 tile (about 10 % faster than the 256-row kernels at 300 - 384 rows).  Round 2 found it
+        // corrupting accumulators at 400 rows x 11008 columns on cold launches (in-flight "redundant" fetches landing in registers the
+        // compiler had reused; fixed by tying the final wait to those registers) and routed around it; round 3
+        // validated the fix with the cold-launch stress test (tests/test_cold_launch_gpu.py: every hand-counted kernel as the first
+        // GEMM of a fresh process on poisoned memory) and scripts/isa_lint.py.  EXL_GEMM_NO_TILE128=1 restores the detour.
+        static const bool tile128 = getenv("EXL_GEMM_NO_TILE128") == nullptr;
         const int big_rows = tile128 ? 512 : 256;
         const bool spec = !no_spec && rows > big_rows && gshift >= 5 && (uint64_t) K * (uint64_t) N < (1ull << 32);   // loader waves: power-of-two groups, 32-bit weight offsets
         if (spec) return launch_gemm_t16w(w, xin, rows, out, no_zero, gshift, s);                 // 256 x 128, 8 MFMA waves + 4 loader waves
         if (rows > big_rows) return launch_gemm_t16m<4, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s);  // 256 x 128, 8 waves
-        // EXL_GEMM_SPLITK=1 (with EXL_GEMM_TILE128=1): K cut in two for 257 .. 512 rows, 2 x the blocks of half the length; fp32
+        // EXL_GEMM_SPLITK=1: K cut in two for 257 .. 512 rows, 2 x the blocks of half the length; fp32
         // slices in the workspace + a reduce kernel.  Measured 0.386 -> 0.303 ms per 7B layer at 300 rows in round 2 before the
         // kernel's in-flight-register defect was understood; off until it has been re-validated.
         static const bool splitk = getenv("EXL_GEMM_SPLITK") != nullptr;

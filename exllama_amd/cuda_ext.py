@@ -261,6 +261,30 @@ class _ExllamaExt:
             check(self._lib.exl_rms_norm(x.data_ptr(), w.data_ptr(), out.data_ptr(), float(epsilon), x.size(0), x.size(1),
                                          _stream(x)), "rms_norm")
 
+    # -- not exllama_ext functions (the reference calls torch here: model.py:1002, :1077): HIP forms of the embedding lookup and of the
+    #    prompt pass' lm_head for a few rows, so that the token path carries no ATen / BLAS kernel
+    def embedding(self, ids, table, out):
+        _req_dtype(ids, torch.int64, "ids"); _req_dtype(table, torch.float16, "table"); _req_dtype(out, torch.float16, "out")
+        for t, n in ((ids, "ids"), (table, "table"), (out, "out")):
+            _req_cuda(t, n)
+        _req(out.numel() == ids.numel() * table.size(1), "out does not hold ids.numel() rows of the table")
+        with _Guard(table.device):
+            check(self._lib.exl_embedding(ids.data_ptr(), table.data_ptr(), out.data_ptr(), ids.numel(), table.size(1), table.size(0),
+                                          _stream(table)), "embedding")
+
+    def head_matmul(self, x, w, out):
+        """out[r, v] = float(half(x[r] . w[v])); False (nothing launched) when x has more rows than the kernel stages."""
+        _req_dtype(x, torch.float16, "x"); _req_dtype(w, torch.float16, "w"); _req_dtype(out, torch.float32, "out")
+        for t, n in ((x, "x"), (w, "w"), (out, "out")):
+            _req_cuda(t, n)
+        _req(x.size(1) == w.size(1) and out.size(0) == x.size(0) and out.size(1) == w.size(0), "x, w and out have incompatible shapes")
+        with _Guard(x.device):
+            rc = self._lib.exl_head_matmul(x.data_ptr(), w.data_ptr(), out.data_ptr(), x.size(0), x.size(1), w.size(0), _stream(x))
+        if rc == 1:
+            return False
+        check(rc, "head_matmul")
+        return True
+
     # -- exllama_ext.cpp:647-680
     def rope_(self, x, sin, cos, past_len, num_heads, head_dim, past_len_dev=None):
         for t, n in ((x, "x"), (sin, "sin"), (cos, "cos")):

@@ -598,6 +598,9 @@ class ExLlama:
         fp32 logits [bsz, 1 or q_len, vocab] on `output_device` (default: input_ids' device), or None."""
         q_len = input_ids.shape[-1]
         bsz = input_ids.shape[0]
+        if lora is not None and self.config.tp is not None:
+            # an adapter's lora_A spans the full in_features; the row-split o_proj / down_proj of a shard see a slice of them
+            raise RuntimeError("LoRA adapters are not supported on a tensor-parallel shard")
         assert input_mask is None or (input_mask.shape[-1] >= input_ids.shape[-1] and input_mask.shape[-2] == input_ids.shape[-2])
         chunk_cap = max(1, self.config.max_input_len // bsz)
         result = None
@@ -655,6 +658,10 @@ class ExLlama:
     def embed(self, input_ids):
         cfg = self.config
         ids = _move_tensor(input_ids, cfg.device_map.embed_tokens, "input_ids", cfg)
+        if ids.is_cuda and self.embed_weight.is_cuda and self.embed_weight.dtype == torch.float16:
+            out = torch.empty(tuple(ids.shape) + (self.embed_weight.shape[1],), dtype=torch.float16, device=ids.device)
+            ext.embedding(ids.contiguous().to(torch.int64), self.embed_weight, out)      # HIP gather (reference: torch embedding, model.py:1002)
+            return out
         return torch.nn.functional.embedding(ids, self.embed_weight).contiguous()
 
     def forward_layers(self, hidden, cache, buffers=None, lora=None):
@@ -681,7 +688,15 @@ class ExLlama:
         if cfg.device_map.lm_head == "cpu":
             hidden = hidden.float()
         hidden = _move_tensor(hidden, cfg.device_map.lm_head, "hidden_states", cfg)
-        logits = torch.matmul(hidden, self.lm_head_weight.t()).float()
+        logits = None
+        rows = hidden.shape[0] * hidden.shape[1]
+        if hidden.is_cuda and hidden.dtype == torch.float16 and self.lm_head_weight.is_cuda and rows <= 8:
+            # the last-token logits of a prompt / a short prompt: HIP GEMV over the fp16 head (reference: nn.Linear, model.py:1077)
+            out = torch.empty((rows, self.lm_head_weight.shape[0]), dtype=torch.float32, device=hidden.device)
+            if ext.head_matmul(hidden.reshape(rows, -1).contiguous(), self.lm_head_weight, out):
+                logits = out.view(hidden.shape[0], hidden.shape[1], -1)
+        if logits is None:                                          # whole-sequence logits (perplexity, validation): the BLAS GEMM
+            logits = torch.matmul(hidden, self.lm_head_weight.t()).float()
         if cfg.tp is not None and self.lm_head_weight.shape[0] != cfg.vocab_size:      # this rank's vocabulary rows (tp.py): gather the rest
             logits = cfg.tp.all_gather_last(logits, cfg.tp.plan.vocab_sizes)
         return logits
@@ -931,8 +946,9 @@ class ExLlama:
         start = cache.current_seq_len
         if start + num_tokens > cache.max_seq_len:
             raise RuntimeError(f"sequence ({start} + {num_tokens}) exceeds the cache length {cache.max_seq_len}")
-        if "history" not in st:
+        if "history" not in st:                                      # shared with generate_sample, whichever runs first
             st["history"] = torch.zeros((cache.max_seq_len + 1,), dtype=torch.int64, device=st["dev"])
+        if "ggraphs" not in st:
             st["ggraphs"] = []
             torch.cuda.synchronize(st["dev"])
             keep_tok, keep_pos = st["tok"].clone(), st["pos"].clone()

@@ -85,7 +85,7 @@ def _is_act_order(g_idx, groupsize):
 
 def _cols(t, key, lo, hi, out):
     """Column range [lo, hi) of a GPTQ linear."""
-    out[key + ".qweight"] = t[key + ".qweight"][:, lo:hi].contiguous()
+    out[key + ".qweight"] = t[key + ".qweight"][:, lo:hi].clone()          # (a full-width slice would be the caller's tensor itself)
     out[key + ".qzeros"] = t[key + ".qzeros"][:, lo // 8:hi // 8].contiguous()
     out[key + ".scales"] = t[key + ".scales"][:, lo:hi].contiguous()
     if key + ".g_idx" in t:
@@ -101,17 +101,23 @@ def _rows(t, key, lo, hi, out, rank):
     gs = qw.shape[0] * 8 // groups
     if groups > 1 and (lo % gs or hi % gs):
         raise ValueError(f"{key}: rows {lo}:{hi} do not fall on quantisation-group boundaries (groupsize {gs})")
-    out[key + ".qweight"] = qw[lo // 8:hi // 8].contiguous()
+    # clone(): a row slice of a contiguous tensor is a VIEW, and make_q4 re-tiles qweight in place -- the shard must not share
+    # storage with the caller's checkpoint (column slices copy anyway)
+    out[key + ".qweight"] = qw[lo // 8:hi // 8].clone()
+    g_idx = t.get(key + ".g_idx")
+    # an all-zero g_idx is the "no act-order" placeholder some checkpoints carry (the reference and Ex4bitLinear treat it as
+    # absent): it is passed through unchanged; only a real sequential index is rebased to the shard's first group
+    placeholder = g_idx is not None and not bool((g_idx != 0).any())
     if groups > 1:
-        out[key + ".qzeros"] = t[key + ".qzeros"][lo // gs:hi // gs].contiguous()
-        out[key + ".scales"] = t[key + ".scales"][lo // gs:hi // gs].contiguous()
-        if key + ".g_idx" in t:
-            out[key + ".g_idx"] = (t[key + ".g_idx"][lo:hi] - lo // gs).contiguous()
+        out[key + ".qzeros"] = t[key + ".qzeros"][lo // gs:hi // gs].clone()
+        out[key + ".scales"] = t[key + ".scales"][lo // gs:hi // gs].clone()
+        if g_idx is not None:
+            out[key + ".g_idx"] = g_idx[lo:hi].clone() if placeholder else (g_idx[lo:hi] - lo // gs).contiguous()
     else:                                                           # one group for the whole K: every rank keeps it
         out[key + ".qzeros"] = t[key + ".qzeros"]
         out[key + ".scales"] = t[key + ".scales"]
-        if key + ".g_idx" in t:
-            out[key + ".g_idx"] = t[key + ".g_idx"][lo:hi].contiguous()
+        if g_idx is not None:
+            out[key + ".g_idx"] = g_idx[lo:hi].clone()
     if key + ".bias" in t and rank == 0:                             # a bias is added once
         out[key + ".bias"] = t[key + ".bias"]
 
@@ -148,7 +154,7 @@ def shard_tensors(tensors, config_dict, rank, world):
             out[k] = v                                               # embedding, norms: replicated
     # lm_head: this rank's vocabulary rows (0.26 of 3.6 GB per token at 7B, more than the layers' share at 8 ranks); the logits
     # are all-gathered (ExLlama.head / the executor's last piece)
-    out["lm_head.weight"] = tensors["lm_head.weight"][plan.vocab[0]:plan.vocab[1]].contiguous()
+    out["lm_head.weight"] = tensors["lm_head.weight"][plan.vocab[0]:plan.vocab[1]].clone()
     return out, plan
 
 

@@ -78,9 +78,8 @@ int exl_cleanup(void);
  * OWNERSHIP: the handle borrows the three tensors (the caller keeps them alive, as Ex4bitLinear does, model.py:141-143) and
  * REWRITES `qweight` IN PLACE: act-order repack (the reference does the same, q4_matrix.cu:159) and, for every Llama shape
  * (K % 128 == 0, N % 16 == 0, groupsize % 32 == 0), the re-tiling into the streaming layout -- so a tensor can back ONE handle,
- * once: calling make_q4 again on an already re-tiled tensor (e.g. reloading a model from a cached tensor dict) computes
- * garbage and cannot be detected by address (allocators recycle addresses of freed tensors while handles live until
- * cleanup). */
+ * once: calling make_q4 again on a tensor a live handle has already rewritten is refused (EXL_E_INVALID; the handle keeps a
+ * 32-byte fingerprint of the rewritten tensor, so a recycled address holding a fresh checkpoint tensor is accepted). */
 int exl_make_q4(int device, int height, int width, int groups, uint32_t* qweight, uint32_t* qzeros,
                 uint16_t* scales, const uint32_t* g_idx_host, void* stream, void** out_handle);
 int exl_free_q4(void* handle);
@@ -289,6 +288,14 @@ int exl_decoder_step_part(void* decoder, int layer, int part, const int64_t* tok
                           int advance, void* stream);
 int exl_decoder_set_tp(void* decoder, int residual_owner);
 int exl_decoder_free(void* decoder);
+
+/* ---- embedding lookup and the prompt pass' lm_head (reference: torch ops inside model.py, not exllama_ext functions:
+ * model.py:1002 `self.embed_tokens(input_ids)`, :1077 `self.lm_head(hidden_states)`) -- so that no BLAS / ATen kernel is left on
+ * the token path.  exl_embedding: out[i] = table[ids[i]] (fp16 rows, ids int64 in DEVICE memory, clamped to the table).
+ * exl_head_matmul: out[r][v] = float(half(x[r] . w[v])) for rows <= 8 (the last-token logits of a prompt, a short prompt);
+ * returns 1 (nothing launched) for more rows: the caller keeps its GEMM path for whole-sequence logits. */
+int exl_embedding(const int64_t* ids_dev, const void* table, void* out, int n_ids, int hidden, int vocab, void* stream);
+int exl_head_matmul(const void* x, const void* w, float* out, int rows, int hidden, int vocab, void* stream);
 
 /* ---- repetition penalty, HOST memory, fp32 (reference: exllama_ext.cpp:684-741, cpu_func/rep_penalty.cpp) */
 int exl_rep_penalty(int vocab_size, const uint64_t* sequence_host, float* rep_mask_host, float penalty_max,

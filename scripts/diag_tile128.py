@@ -1,4 +1,4 @@
-"""One-off: what exactly goes wrong in the 128 x 128 tile GEMM under torch's poisoned allocator (run with EXL_GEMM_TILE128=1)."""
+"""One-off: what exactly goes wrong in the 128 x 128 tile GEMM under torch's poisoned allocator (the default route for 257 - 512 rows since round 3)."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from exllama_amd import synth

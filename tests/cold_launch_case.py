@@ -49,7 +49,7 @@ def main():
     z = torch.zeros(64, dtype=torch.float16, device=DEV)
     ext.prepare_buffers(torch.device(DEV), tmp, z, torch.zeros((1, 64), dtype=torch.float32, device=DEV), z)
     ok = True
-    if case in ("t16m128", "t16m256", "t16w0", "t16s"):
+    if case in ("t16m128", "t16m128k", "t16m256", "t16w0", "t16s"):
         h, keep = handle(d, "w")
         N = int(d["w_scales"].shape[1])
         torch.cuda.synchronize()

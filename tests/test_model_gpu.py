@@ -1,5 +1,6 @@
 """GPU model-level parity: exllama_amd.model.ExLlama (HIP kernels through the C ABI) against the CPU oracle model and
 the committed golden logits, on the seeded synthetic checkpoints; plus the properties that hold at BASELINE sizes."""
+import json
 import math
 import os
 
@@ -26,6 +27,38 @@ def _build(name, gs, act, seed=11, max_seq_len=64, num_layers=None, zeros="rand"
     return model, ExLlamaCache(model), tensors, dims
 
 
+ORACLE_TOL = 4e-3        # HIP path vs CPU oracle: max |diff| <= 4e-3 x the largest reference logit (measured: ~1e-3)
+PATHS_TOL = 8e-3         # two HIP paths with different fp16 rounding points (MFMA prefill vs GEMV decode, fused vs op by op)
+
+
+def _model_close(got, ref, tol, tag=""):
+    """Whole-model comparison of logits / cache rows: an absolute bound at the scale of the largest reference value, plus -- because
+    that bound alone would let a wrong low-magnitude column or one bad KV split through -- the relative RMS error over the whole
+    array and over every 16-element block of it (the criteria of tests/test_ops_gpu.py:_close at model depth)."""
+    got = np.asarray(got.detach().cpu() if hasattr(got, "detach") else got, dtype=np.float64)
+    ref = np.asarray(ref.detach().cpu() if hasattr(ref, "detach") else ref, dtype=np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert np.isfinite(got).all(), tag
+    scale = max(float(np.abs(ref).max()), 1e-3)
+    err = float(np.abs(got - ref).max())
+    rms_ref = float(np.sqrt(np.mean(ref ** 2)))
+    rel = float(np.sqrt(np.mean((got - ref) ** 2))) / max(rms_ref, 1e-12)
+    worst_block = 0.0
+    nblk = ref.size // 16
+    if nblk >= 4:
+        fg, fr = got.reshape(-1)[:nblk * 16].reshape(nblk, 16), ref.reshape(-1)[:nblk * 16].reshape(nblk, 16)
+        eb = np.sqrt(np.mean((fg - fr) ** 2, axis=1))
+        rb = np.sqrt(np.mean(fr ** 2, axis=1))
+        worst_block = float((eb / np.maximum(rb, rms_ref / 8.0)).max())
+    stats = os.environ.get("EXL_TOL_STATS")
+    if stats:
+        with open(stats, "a") as f:
+            f.write(json.dumps({"tag": tag, "tol": tol, "err_over_scale": err / scale, "rms_rel": rel, "worst_block": worst_block}) + "\n")
+    assert err <= tol * scale, (tag, err, scale)
+    assert rel <= tol / 2, (tag, "rms(diff) / rms(ref)", rel)
+    assert worst_block <= 4 * tol, (tag, "16-element block", worst_block)
+
+
 def _ppl(logits, ids):
     """exp(-mean log p(target)) over positions (reference: perplexity.py:121-137)."""
     lp = torch.log_softmax(torch.as_tensor(logits).float(), dim=-1)
@@ -43,7 +76,7 @@ def test_tiny_model_matches_golden_and_oracle(name, gs, act, golden_dir):
     ref = g[f"{name}_logits"].astype(np.float32)
     scale = np.abs(ref).max()
     assert np.isfinite(logits).all()
-    assert np.abs(logits - ref).max() <= 2e-2 * scale, (np.abs(logits - ref).max(), scale)    # fp16 tolerance through 2 layers
+    _model_close(logits, ref, ORACLE_TOL, f"golden prefill {name}")
     # perplexity "equal to 2 dp" (north_star) on the same token stream
     assert abs(_ppl(logits, ids) - _ppl(ref, ids)) < 5e-3 * _ppl(ref, ids)
     # greedy continuation through the fused decode path reproduces the oracle's tokens (integer result)
@@ -51,7 +84,7 @@ def test_tiny_model_matches_golden_and_oracle(name, gs, act, golden_dir):
     toks = [tok]
     for i in range(4):
         lg = model.forward(torch.tensor([[tok]], device="cuda:0"), cache).cpu().numpy()
-        np.testing.assert_allclose(lg[0, 0], g[f"{name}_step_logits"][i].astype(np.float32), rtol=0, atol=2e-2 * scale)
+        _model_close(lg[0, 0], g[f"{name}_step_logits"][i].astype(np.float32), ORACLE_TOL, f"golden step {name} {i}")
         tok = int(np.argmax(lg[0, 0]))
         toks.append(tok)
     assert toks == g[f"{name}_tokens"].tolist()
@@ -69,12 +102,12 @@ def test_prefill_and_token_by_token_agree():
     cache2 = ExLlamaCache(model)
     b = torch.cat([model.forward(ids[:, i:i + 1], cache2, last_id_only=False).cpu() for i in range(ids.shape[1])], dim=1)
     scale = a.abs().max().item()
-    assert (a - b).abs().max().item() <= 2e-2 * scale
+    _model_close(b, a, PATHS_TOL, "prefill vs token by token")
     assert abs(_ppl(a, ids.cpu()) - _ppl(b, ids.cpu())) < 5e-3 * _ppl(a, ids.cpu())
     # KV caches written by the two paths agree too
     for l in range(len(cache.key_states)):
         ka, kb = cache.key_states[l][:, :, :40].float(), cache2.key_states[l][:, :, :40].float()
-        assert (ka - kb).abs().max().item() <= 2e-2 * ka.abs().max().item()
+        _model_close(kb, ka, PATHS_TOL, f"prefill vs token by token, K cache {l}")
     model.free_unmanaged()
 
 
@@ -89,7 +122,7 @@ def test_chunked_prefill_and_threshold_variants():
     c2 = ExLlamaCache(model)
     chunked = model.forward(ids, c2).cpu()
     assert c2.current_seq_len == 37
-    assert (full - chunked).abs().max().item() <= 2e-2 * full.abs().max().item()
+    _model_close(chunked, full, PATHS_TOL, "chunked prefill")
     model.config.max_input_len = 64
     # batched: two different prompts in one batch == each alone
     ids2 = torch.randint(1, dims.vocab_size, (2, 9), generator=torch.Generator().manual_seed(3)).to("cuda:0")
@@ -98,7 +131,7 @@ def test_chunked_prefill_and_threshold_variants():
     for r in range(2):
         c1 = ExLlamaCache(model)
         one = model.forward(ids2[r:r + 1], c1, last_id_only=False).cpu()
-        assert (both[r] - one[0]).abs().max().item() <= 2e-2 * one.abs().max().item()
+        _model_close(both[r], one[0], PATHS_TOL, f"batch row {r}")
     model.free_unmanaged()
 
 
@@ -136,7 +169,7 @@ def test_7b_layer_shapes_finite_and_consistent():
     model.forward(ids[:, :2047], c2, preprocess_only=True)
     b = model.forward(ids[:, 2047:], c2).cpu()
     scale = a.abs().max().item()
-    assert (a - b).abs().max().item() <= 3e-2 * scale, ((a - b).abs().max().item(), scale)
+    _model_close(b, a[:, -1:], PATHS_TOL, "7B shapes: 2048-token prefill vs 2047 + one decode step")
     assert int(a[0, -1].argmax()) == int(b[0, -1].argmax())
     with pytest.raises(RuntimeError, match="exceeds the cache length"):
         model.forward(ids[:, :1], cache)
@@ -179,7 +212,7 @@ def test_native_decode_executor_matches_op_path_and_oracle(name, gs, act, prompt
     graph, toks_graph, c_graph = run("graph", forced=toks_ops)
     scale = ops.abs().max().item()
     assert torch.isfinite(eager).all()
-    assert (eager - ops).abs().max().item() <= 2e-2 * scale, (eager - ops).abs().max().item()
+    _model_close(eager, ops, PATHS_TOL, f"executor vs op path {name} {prompt}")
     # same greedy choice wherever the op path's top-2 margin is not within the tolerance
     prev = torch.cat([model.forward(ids, ExLlamaCache(model))[0, -1:].float().cpu(), ops[:-1]])
     top2 = prev.topk(2, dim=-1).values
@@ -191,7 +224,7 @@ def test_native_decode_executor_matches_op_path_and_oracle(name, gs, act, prompt
     assert torch.equal(graph, graph2) and toks_graph == toks_graph2         # bit-reproducible run to run
     for l in range(len(c_ops.key_states)):
         ka, kb = c_ops.key_states[l][:, :, :prompt + n_new].float(), c_graph.key_states[l][:, :, :prompt + n_new].float()
-        assert (ka - kb).abs().max().item() <= 2e-2 * ka.abs().max().item()
+        _model_close(kb, ka, PATHS_TOL, f"executor vs op path, K cache {l}")
     # oracle model on the same tokens
     ref = OracleLlama(synth.config_dict(dims), tensors, max_seq_len=max_seq)
     rl = ref.forward(ids.cpu().numpy())
@@ -199,7 +232,7 @@ def test_native_decode_executor_matches_op_path_and_oracle(name, gs, act, prompt
     for t in toks_ops:
         ref_steps.append(ref.forward(np.array([[t]]))[0, 0])
     ref_steps = np.stack(ref_steps)
-    assert np.abs(graph.numpy() - ref_steps).max() <= 2e-2 * np.abs(ref_steps).max()
+    _model_close(graph.numpy(), ref_steps, ORACLE_TOL, f"executor vs oracle {name} {prompt}")
     # rewinding the cache on the host is picked up by the device-side position
     model.enable_decode_graph(c_graph, use_graph=True)
     c_graph.current_seq_len = prompt
@@ -236,6 +269,49 @@ def test_perplexity_module_chunk_and_token_modes_and_oracle():
     model.free_unmanaged()
 
 
+def test_perplexity_equal_to_two_decimals_on_a_peaked_model():
+    """north_star: "perplexity equal to 2 dp".  The reference prints perplexity with 4 decimals (perplexity.py:121-138); random
+    synthetic weights give near-uniform logits (perplexity ~ vocabulary size), where 2 dp of a number in the hundreds says little.
+    So: a model with a sharpened head (lm_head x 10) evaluated on text SAMPLED from its own next-token distribution, which lands the
+    perplexity (= e^entropy of that distribution) in the range of real text (3 .. 30).  The HIP whole-chunk path, the HIP
+    token-by-token path and the CPU oracle must then agree to |delta| < 0.005 ABSOLUTE."""
+    from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
+    from exllama_amd.perplexity import Perplexity
+    dims = synth.PRESETS["tiny_hd128"]
+    tensors = synth.make_checkpoint(dims, groupsize=128, act_order=False, seed=23, device="cpu", zeros="rand")
+    tensors["lm_head.weight"] = (tensors["lm_head.weight"].float() * 10.0).half()
+    cfg = ExLlamaConfig(synth.config_dict(dims))
+    cfg.max_seq_len = 160
+    cfg.max_input_len = 160
+    model = ExLlama(cfg, tensors={k: v.clone() for k, v in tensors.items()})
+    gen = torch.Generator().manual_seed(17)
+    cache = ExLlamaCache(model)
+    seq = torch.randint(1, dims.vocab_size, (4,), generator=gen).tolist()
+    lg = model.forward(torch.tensor([seq], device="cuda:0"), cache)
+    for _ in range(140):
+        nxt = int(torch.multinomial(torch.softmax(lg[0, -1].float().cpu(), -1), 1, generator=gen))
+        seq.append(nxt)
+        lg = model.forward(torch.tensor([[nxt]], device="cuda:0"), cache)
+    ids = torch.tensor([seq])
+    p = Perplexity(model=model, cache=ExLlamaCache(model))
+    p.add_tokens(ids.to("cuda:0"), chunk_size=144, overlap=0)
+    whole = p.test(quiet=True)
+    token = p.test(quiet=True, ppl_token=True)
+    orc = OracleLlama(synth.config_dict(dims), tensors, max_seq_len=160)
+    lp_sum, n = 0.0, 0
+    for c in p.dataset_chunks:
+        c = c.cpu()
+        orc.reset()
+        lgo = torch.from_numpy(np.asarray(orc.forward(c[:, :-1].numpy(), last_id_only=False), dtype=np.float32))
+        lp = torch.log_softmax(lgo, dim=-1).gather(-1, c[:, 1:].unsqueeze(-1))
+        lp_sum += lp.sum().item()
+        n += c.shape[1] - 1
+    ref = math.exp(-lp_sum / n)
+    assert 3.0 < ref < 30.0, ref
+    assert abs(whole - ref) < 0.005 and abs(token - ref) < 0.005 and abs(whole - token) < 0.005, (whole, token, ref)
+    model.free_unmanaged()
+
+
 @pytest.mark.parametrize("name,gs,act", [("tiny", 64, False), ("tiny_gqa", 128, True)])
 def test_lora_adapter_end_to_end(name, gs, act):
     """exllama_amd.lora.ExLlamaLora (PEFT layout in, transposed + pre-scaled halves out) through every projection of the
@@ -267,12 +343,12 @@ def test_lora_adapter_end_to_end(name, gs, act):
     orc.set_lora({k: v.cpu() for k, v in lora.tensors.items()})
     ref = torch.from_numpy(np.asarray(orc.forward(ids.numpy(), last_id_only=False), dtype=np.float32))
     scale = ref.abs().max().item()
-    assert (got - ref).abs().max().item() <= 2e-2 * scale, ((got - ref).abs().max().item(), scale)
+    _model_close(got, ref, ORACLE_TOL, f"LoRA prefill {name}")
     assert (got - base).abs().max().item() > 5e-2 * scale                    # the adapter is not a no-op
     tok = torch.tensor([[int(ref[0, -1].argmax())]])
     step = model.forward(tok.to("cuda:0"), cache2, lora=lora).float().cpu()   # rows == 1: fused decode ops with LoRA operands
     ref_step = torch.from_numpy(np.asarray(orc.forward(tok.numpy()), dtype=np.float32))
-    assert (step - ref_step).abs().max().item() <= 2e-2 * scale
+    _model_close(step, ref_step, ORACLE_TOL, f"LoRA step {name}")
     model.free_unmanaged()
 
 
@@ -404,8 +480,7 @@ def test_native_decode_executor_at_real_layer_shapes(key):
             for i, t in enumerate(toks):
                 lg = model.forward(torch.tensor([[t]], device="cuda:0"), c)[0, 0].float().cpu().numpy()
                 assert np.isfinite(lg).all()
-                err = float(np.abs(lg - ref_steps[i]).max())
-                assert err <= 2e-2 * scale, (key, P, mode, i, err, scale)
+                _model_close(lg, ref_steps[i], ORACLE_TOL, f"real shapes {key} ctx {P} {mode} step {i}")
                 if mode == "eager":                                  # which kernels this step launched
                     model._set_eager_splits(model._decoder, P + i)
                     plans = {cls: _plan(model, j) for j, cls in enumerate(model.DECODER_CLASSES)}
@@ -418,7 +493,7 @@ def test_native_decode_executor_at_real_layer_shapes(key):
             # the K/V rows the executor appended match the oracle's (RoPE + scatter inside the attention kernel)
             for l in range(L):
                 ka = c.key_states[l][0, :, P:P + n_new].float().cpu().numpy()
-                assert np.abs(ka - ref.kc[l][0, :, P:P + n_new].astype(np.float32)).max() <= 2e-2 * max(1.0, float(np.abs(ka).max()))
+                _model_close(ka, ref.kc[l][0, :, P:P + n_new].astype(np.float32), ORACLE_TOL, f"real shapes {key} ctx {P} K rows layer {l}")
             if mode == "graph":                                      # device-side greedy generation from the same state
                 c.current_seq_len = P
                 first = torch.tensor([[toks[0]]], device="cuda:0")
@@ -431,6 +506,38 @@ def test_native_decode_executor_at_real_layer_shapes(key):
                 l2 = model.forward(torch.tensor([[t1]], device="cuda:0"), c2)
                 assert got.tolist() == [t1, int(l2[0, -1].argmax())]
     assert len(seen) >= 3, seen                                      # 1 split, 4 splits and the decoder's maximum all ran
+    model.free_unmanaged()
+
+
+def test_real_shape_prefill_end_to_end_vs_oracle():
+    """BASELINE configs[1] shapes, two layers, the whole 2048-token prompt through the product's prefill path (fused q/k/v + RoPE +
+    cache GEMM -> flash attention -> o_proj GEMM -> dual gate/up GEMM + SiLU -> down GEMM), compared END TO END with the CPU
+    oracle model that ran the same prompt itself: last-token logits, K / V cache rows at sampled positions of both layers, and
+    the next token's logits through the decode executor continuing from that cache -- nothing is seeded from the GPU.
+    (test_native_decode_executor_at_real_layer_shapes isolates the decode step by copying the GPU's cache into the oracle.)"""
+    from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
+    dims, L, S = synth.PRESETS["7b"], 2, 2048
+    tensors = synth.make_checkpoint(dims, groupsize=128, act_order=False, seed=13, device="cpu", zeros="rand", num_layers=L)
+    cfg = ExLlamaConfig(synth.config_dict(dims, L))
+    cfg.max_seq_len = S + 128
+    cfg.max_input_len = S
+    model = ExLlama(cfg, tensors=tensors)
+    ref = OracleLlama(synth.config_dict(dims, L), tensors, max_seq_len=cfg.max_seq_len)
+    ref.prepare()
+    ids = np.random.RandomState(6).randint(1, dims.vocab_size, size=(1, S))
+    want = ref.forward(ids)[0, 0]                                      # fp32 BLAS on the reconstructed weights, fp16 at the reference's points
+    cache = ExLlamaCache(model)
+    got = model.forward(torch.from_numpy(ids).to("cuda:0"), cache)[0, 0].float().cpu().numpy()
+    _model_close(got, want, ORACLE_TOL, "7B shapes, 2048-token prefill, last-token logits")
+    rows = [0, 1, 255, 256, 1023, 1024, 2046, 2047]
+    for l in range(L):
+        _model_close(cache.key_states[l][0, :, rows].float().cpu().numpy(), ref.kc[l][0, :, rows].astype(np.float32), ORACLE_TOL, f"K rows layer {l}")
+        _model_close(cache.value_states[l][0, :, rows].float().cpu().numpy(), ref.vc[l][0, :, rows].astype(np.float32), ORACLE_TOL, f"V rows layer {l}")
+    tok = int(np.argmax(want))
+    want2 = ref.forward(np.array([[tok]]))[0, 0]
+    model.enable_decode_graph(cache, use_graph=True)
+    got2 = model.forward(torch.tensor([[tok]], device="cuda:0"), cache)[0, 0].float().cpu().numpy()
+    _model_close(got2, want2, ORACLE_TOL, "7B shapes, decode step after the 2048-token prefill")
     model.free_unmanaged()
 
 

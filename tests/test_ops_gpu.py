@@ -104,6 +104,25 @@ def test_make_q4_and_reconstruct_bit_exact(ce, K, N, gs, act):
     assert np.array_equal(w16.cpu().numpy().view(np.uint16), ref.view(np.uint16))      # bit-exact fp16 weights
 
 
+def test_make_q4_refuses_a_tensor_it_already_rewrote(ce):
+    """make_q4 re-tiles qweight in place (the reference rewrites it too for act-order, q4_matrix.cu:159): a second handle on the
+    SAME tensor would re-tile re-tiled words and compute garbage without a sound.  The library keeps a fingerprint of every tensor
+    it rewrote and refuses; a fresh copy of the checkpoint tensor -- also one the allocator puts at the same address -- is fine."""
+    lin, _ = _lin(512, 256, 128, False, seed=31)
+    d = _to_dev(lin)
+    h1 = ce.ext_make_q4(d["qweight"], d["qzeros"], d["scales"], None, 0)
+    with pytest.raises(RuntimeError, match="already rewritten"):
+        ce.ext_make_q4(d["qweight"], d["qzeros"], d["scales"], None, 0)
+    addr = d["qweight"].data_ptr()
+    d["qweight"].copy_(lin["qweight"])                                   # the checkpoint words again, at the same address
+    h2 = ce.ext_make_q4(d["qweight"], d["qzeros"], d["scales"], None, 0)
+    assert d["qweight"].data_ptr() == addr and h2 != h1
+    w16 = torch.empty((512, 256), dtype=torch.float16, device=DEV)
+    ce.exllama_ext.q4_reconstruct(h2, w16)
+    ow = _oracle_w(lin)
+    assert np.array_equal(w16.cpu().numpy().view(np.uint16), O.dequant_w16(ow["qweight"], ow["qzeros"], ow["scales"]).view(np.uint16))
+
+
 def test_make_q4_golden_fixture(ce, golden_dir):
     g = np.load(os.path.join(golden_dir, "ops_small.npz"))
     for tag in ("a", "c"):
@@ -351,6 +370,27 @@ def test_q4_qkv_rope_cache_equals_separate_ops(ce, hidden, heads, kvh, gs, bsz, 
     assert float(kc2[:, :, past + q_len:].float().min()) == 7.0 and float(vc2[:, :, past + q_len:].float().max()) == -3.0     # beyond the prompt: untouched
     # declines short prompts and act-order
     assert not ext.q4_qkv_rope_cache(x[:256].contiguous(), hq, hk, hv, q2.view(-1, heads * hd)[:256], sin, cos, kc2, vc2, 256 // bsz, 0, heads, kvh, hd, max_seq)
+
+
+@pytest.mark.parametrize("hidden,vocab,rows", [(512, 640, 1), (4096, 32000, 1), (4096, 32000, 5), (1024, 777, 8)])
+def test_embedding_and_head_matmul(ce, hidden, vocab, rows):
+    """The HIP forms of the two torch ops on the token path (reference: model.py:1002 embedding, :1077 lm_head): the gather is a
+    bit copy; the head is an fp16 GEMV with fp32 accumulation rounded to fp16 (nn.Linear in fp16, then .float())."""
+    gen = torch.Generator().manual_seed(hidden + rows)
+    table = (torch.randn(vocab, hidden, generator=gen) * 0.05).half()
+    ids = torch.randint(0, vocab, (2, 7), generator=gen)
+    out = torch.full((2, 7, hidden), float("nan"), dtype=torch.float16, device=DEV)
+    ce.exllama_ext.embedding(ids.to(DEV), table.to(DEV), out)
+    assert np.array_equal(out.cpu().numpy().view(np.uint16), table[ids].numpy().view(np.uint16))
+    x = torch.randn(rows, hidden, generator=gen).half()
+    logits = torch.full((rows, vocab), float("nan"), dtype=torch.float32, device=DEV)
+    assert ce.exllama_ext.head_matmul(x.to(DEV), table.to(DEV), logits)
+    ref = O.half_matmul(x.numpy(), table.t().contiguous().numpy())          # fp32 products and sums, one rounding to fp16
+    _close(logits.cpu().numpy(), ref, ulps=1.5)
+    big = torch.randn(9, hidden, generator=gen).half().to(DEV)              # more rows than the kernel stages: declined, nothing written
+    sentinel = torch.full((9, vocab), 7.0, dtype=torch.float32, device=DEV)
+    assert not ce.exllama_ext.head_matmul(big, table.to(DEV), sentinel)
+    assert float(sentinel.min()) == 7.0
 
 
 def test_q4_matmul_lora(ce):

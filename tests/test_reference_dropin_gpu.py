@@ -88,7 +88,7 @@ def test_reference_model_py_runs_on_the_shim(ref_model_module, tmp_path, name, g
     scale = float(np.abs(c_logits).max())
     for got, want in ((r_logits, c_logits), (r_step, c_step), (short, c_short), (r_logits, o_logits), (r_step, o_step)):
         assert np.isfinite(got).all()
-        assert np.abs(got - want).max() <= 2e-2 * scale, (np.abs(got - want).max(), scale)
+        assert np.abs(got - want).max() <= 4e-3 * scale, (np.abs(got - want).max(), scale)
     top2 = np.sort(c_step[0, -1])[-2:]
     assert int(np.argmax(r_step[0, -1])) == int(np.argmax(c_step[0, -1])) or top2[1] - top2[0] < 4e-2 * scale
 

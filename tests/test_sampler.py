@@ -192,4 +192,13 @@ def test_generate_sample_inside_the_graph_equals_the_host_loop():
     model.enable_decode_graph(cache)                              # (the executor was bound to cache2 for the host loop)
     more = model.generate_sample(torch.tensor([prompt[0].cpu().tolist() + got]), cache, 3, settings=_lib.ExlSampler(top_k=1, rep_penalty_max=1.0))
     assert more.numel() == 3 and cache.current_seq_len == 149 + n + 3
+    # generate_greedy on the SAME decoder after generate_sample (round-2 defect: the greedy graphs were only captured when no
+    # sampler had created the shared history buffer first -> KeyError 'ggraphs'); top_k = 1 sampling is greedy decoding
+    start = cache.current_seq_len
+    last_tok = more[-1].view(1, 1)
+    greedy = model.generate_greedy(last_tok, cache, 4)
+    cache.current_seq_len = start
+    again = model.generate_sample(torch.tensor([prompt[0].cpu().tolist() + got + more.cpu().tolist()]), cache, 4,
+                                  settings=_lib.ExlSampler(top_k=1, rep_penalty_max=1.0))
+    assert greedy.tolist() == again.tolist()
     model.free_unmanaged()

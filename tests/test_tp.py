@@ -56,6 +56,31 @@ def test_shards_tile_the_full_matrices(preset, gs, act, world):
         assert s[p + "mlp.gate_proj.qweight"].shape[1] == c["intermediate_size"]
 
 
+def test_placeholder_g_idx_and_storage_independence():
+    """(a) Checkpoints without act-order may still carry an all-zero g_idx (the reference and Ex4bitLinear treat it as absent): the
+    row-split o_proj / down_proj shards must pass it through as zeros on EVERY rank -- rebasing it would hand ranks > 0 a constant
+    negative index that make_q4 rejects.  (b) No shard tensor that make_q4 rewrites in place (qweight) shares storage with the
+    caller's checkpoint, also with world == 1 where every slice is the whole tensor."""
+    dims, cfg, t = _ckpt("tiny_hd128", 128, False)
+    p = "model.layers.0."
+    for name, K in (("self_attn.o_proj", dims.hidden_size), ("mlp.down_proj", dims.intermediate_size)):
+        t[p + name + ".g_idx"] = torch.zeros(K, dtype=torch.int32)
+    for world in (1, 2):
+        for r in range(world):
+            s, pl = tp.shard_tensors(t, cfg, r, world)
+            for name in ("self_attn.o_proj", "mlp.down_proj"):
+                g = s[p + name + ".g_idx"]
+                assert g.numel() == s[p + name + ".qweight"].shape[0] * 8 and not bool((g != 0).any()), (world, r, name)
+            for key, v in s.items():
+                if key.endswith(".qweight") or key == "lm_head.weight":
+                    assert v.untyped_storage().data_ptr() != t[key].untyped_storage().data_ptr(), (world, r, key)
+    # a real sequential index IS rebased to the shard's first group
+    gs = 128
+    t[p + "mlp.down_proj.g_idx"] = (torch.arange(dims.intermediate_size) // gs).to(torch.int32)
+    s1, pl1 = tp.shard_tensors(t, cfg, 1, 2)
+    assert int(s1[p + "mlp.down_proj.g_idx"].min()) == 0
+
+
 def test_bad_partitions_are_refused():
     dims, cfg, t = _ckpt("tiny_hd128", 128, False)
     with pytest.raises(ValueError):

@@ -10,6 +10,7 @@ import torch
 from exllama_amd import synth, tp
 from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
 
+from oracle.model_oracle import OracleLlama
 from tp_emul import LocalGroup
 
 pytestmark = pytest.mark.gpu
@@ -79,7 +80,18 @@ def test_tensor_parallel_ranks_reproduce_the_unsharded_model(preset, layers, gs,
             # (one extra rounding per rank and half layer)
             scale = float(b.abs().max())
             err = float((a - b).abs().max())
-            assert err <= 0.02 * scale + 1e-3, (r, err, scale)
+            assert err <= 6e-3 * scale, (r, err, scale)
+    # ... and the CPU oracle on the same tokens, not only the product's own unsharded model: the sharded ranks compute what the
+    # reference algorithm computes (the extra fp16 rounding of the per-rank partial sums included in the tolerance)
+    orc = OracleLlama(cfg_dict, tensors, max_seq_len=256)
+    orc.prepare()                                                        # dequantise once
+    want = [np.asarray(orc.forward(prompt.numpy(), last_id_only=False), dtype=np.float32)]
+    for i in range(steps):
+        want.append(np.asarray(orc.forward(tokens[i].numpy()), dtype=np.float32))
+    for a, b in zip(rank_outs[0], want):
+        scale = float(np.abs(b).max())
+        err = float(np.abs(a.numpy() - b).max())
+        assert err <= 6e-3 * scale, ("vs oracle", err, scale)
     for r in range(1, world):                                            # the replicas of the residual stream agree exactly
         for a, b in zip(rank_outs[r], rank_outs[0]):
             assert torch.equal(a, b)
