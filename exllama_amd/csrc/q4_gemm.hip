@@ -8,7 +8,7 @@
 //                            registers by every wave; the activation tile goes through LDS in the nibble order;
 //   q4_gemm_t16m_kernel      T16 layout, weights dequantised ONCE per block into an LDS tile, mid-step barrier schedule
 //                            (256 x 128 tile: the fallback of the next one; 128 x 128 tile, optionally with K cut in two:
-//                            257 .. 512 rows / EXL_GEMM_SPLITK, see launch_q4_gemm);
+//                            257 .. 512 rows, see launch_q4_gemm);
 //   q4_gemm_t16w_kernel<EPI> the default above 256 rows: 8 MFMA waves + 4 loader waves on a 256 x 128 tile; EPI 1 is the
 //                            q/k/v projection with RoPE and the KV-cache write as its epilogue (> 512 rows);
 //   q4_gemm_t16d2_kernel     gate and up projections of the MLP in one kernel with the SiLU epilogue, software-pipelined
@@ -1298,10 +1298,11 @@ int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
         const bool spec = !no_spec && rows > big_rows && gshift >= 5 && (uint64_t) K * (uint64_t) N < (1ull << 32);   // loader waves: power-of-two groups, 32-bit weight offsets
         if (spec) return launch_gemm_t16w(w, xin, rows, out, no_zero, gshift, s);                 // 256 x 128, 8 MFMA waves + 4 loader waves
         if (rows > big_rows) return launch_gemm_t16m<4, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s);  // 256 x 128, 8 waves
-        // EXL_GEMM_SPLITK=1: K cut in two for 257 .. 512 rows, 2 x the blocks of half the length; fp32
-        // slices in the workspace + a reduce kernel.  Measured 0.386 -> 0.303 ms per 7B layer at 300 rows in round 2 before the
-        // kernel's in-flight-register defect was understood; off until it has been re-validated.
-        static const bool splitk = getenv("EXL_GEMM_SPLITK") != nullptr;
+        // K cut in two for 257 .. 512 rows: 2 x the blocks at half the length (the 128-row tile alone leaves 344 blocks of a 7B
+        // down projection on 256 CUs), fp32 slices in the workspace + a reduce kernel.  Round 3, 7B layer at 300 / 384 / 512 rows:
+        // 0.397 / 0.405 / 0.423 ms without, 0.318 / 0.327 / 0.355 ms with (profiles/r03_tile128_validation.txt); validated by the
+        // GEMM op tests and the cold-launch case t16m128k.  EXL_GEMM_NO_SPLITK=1 is the A/B switch.
+        static const bool splitk = getenv("EXL_GEMM_NO_SPLITK") == nullptr;
         if (splitk && rows > 256 && K % 256 == 0 && N % 4 == 0 && (size_t) 2 * rows * N <= exl_buffers(w->device)->workspace_floats)
             return launch_gemm_t16m<2, 2, 4, 4, 2>(w, xin, rows, out, no_zero, gshift, s);
         return launch_gemm_t16m<2, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s);                // 128 x 128, 4 waves

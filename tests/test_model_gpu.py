@@ -27,14 +27,44 @@ def _build(name, gs, act, seed=11, max_seq_len=64, num_layers=None, zeros="rand"
     return model, ExLlamaCache(model), tensors, dims
 
 
-ORACLE_TOL = 4e-3        # HIP path vs CPU oracle: max |diff| <= 4e-3 x the largest reference logit (measured: ~1e-3)
+ORACLE_TOL = 4e-3        # HIP path vs CPU oracle: max |diff| <= 4e-3 x the largest reference logit (measured: 6e-4 .. 1.2e-3 typical,
+                         # gpurun_out tol_stats of round 3); decode steps add the oracle's OWN conditioning, see _oracle_steps
 PATHS_TOL = 8e-3         # two HIP paths with different fp16 rounding points (MFMA prefill vs GEMV decode, fused vs op by op)
 
 
-def _model_close(got, ref, tol, tag=""):
+def _oracle_steps(ref, toks, past):
+    """Teacher-forced decode steps of the oracle from cache position `past`: (logits per step, conditioning per step).
+    The conditioning is how far the ORACLE's logits move when the RoPE'd q and k of the step move by one fp16 ulp on a quarter of
+    their elements (a second pass with oracle.exl_oracle.rope perturbed).  A random-weight model has steps whose attention
+    scores are large and nearly tied; there one ulp in q / k moves every logit by ~1e-2 x scale, for the oracle as for any
+    kernel (measured in round 3 on the 13B act-order layer: seven steps in eight 6e-4, one 4.8e-3 in all three HIP paths, which
+    agree with each other to one logit ulp; scripts/debug/ulp_sensitivity.py reproduces the oracle's share on the CPU).  The
+    parity bound of such a step is ORACLE_TOL plus that movement; a well-conditioned step adds one logit ulp."""
+    from oracle import exl_oracle as O
+    rope0, nrs = O.rope, np.random.RandomState(11)
+
+    def noisy(*a, **kw):
+        y = rope0(*a, **kw)
+        bump = nrs.rand(*y.shape) < 0.25
+        toward = np.where(nrs.rand(*y.shape) < 0.5, np.float16(np.inf), np.float16(-np.inf)).astype(np.float16)
+        return np.where(bump, np.nextafter(y, toward), y)
+
+    O.rope = noisy
+    try:
+        ref.past = past
+        moved = [ref.forward(np.array([[t]]))[0, 0] for t in toks]
+    finally:
+        O.rope = rope0
+    ref.past = past                                                  # the clean pass runs last: its K / V rows are the ones left in ref
+    clean = [ref.forward(np.array([[t]]))[0, 0] for t in toks]
+    return clean, [np.abs(m.astype(np.float64) - c) for m, c in zip(moved, clean)]
+
+
+def _model_close(got, ref, tol, tag="", cond=None):
     """Whole-model comparison of logits / cache rows: an absolute bound at the scale of the largest reference value, plus -- because
     that bound alone would let a wrong low-magnitude column or one bad KV split through -- the relative RMS error over the whole
-    array and over every 16-element block of it (the criteria of tests/test_ops_gpu.py:_close at model depth)."""
+    array and over every 16-element block of it (the criteria of tests/test_ops_gpu.py:_close at model depth).  `cond` (same shape,
+    from _oracle_steps) widens each bound by the oracle's own movement under one-ulp noise."""
     got = np.asarray(got.detach().cpu() if hasattr(got, "detach") else got, dtype=np.float64)
     ref = np.asarray(ref.detach().cpu() if hasattr(ref, "detach") else ref, dtype=np.float64)
     assert got.shape == ref.shape, (got.shape, ref.shape)
@@ -54,9 +84,14 @@ def _model_close(got, ref, tol, tag=""):
     if stats:
         with open(stats, "a") as f:
             f.write(json.dumps({"tag": tag, "tol": tol, "err_over_scale": err / scale, "rms_rel": rel, "worst_block": worst_block}) + "\n")
-    assert err <= tol * scale, (tag, err, scale)
-    assert rel <= tol / 2, (tag, "rms(diff) / rms(ref)", rel)
-    assert worst_block <= 4 * tol, (tag, "16-element block", worst_block)
+    c_max = c_rel = 0.0
+    if cond is not None:
+        cond = np.asarray(cond, dtype=np.float64)
+        assert cond.shape == ref.shape
+        c_max, c_rel = float(cond.max()), float(np.sqrt(np.mean(cond ** 2))) / max(rms_ref, 1e-12)
+    assert err <= tol * scale + c_max, (tag, err, scale, c_max)
+    assert rel <= tol / 2 + c_rel, (tag, "rms(diff) / rms(ref)", rel, c_rel)
+    assert worst_block <= 4 * (tol + c_rel), (tag, "16-element block", worst_block, c_rel)
 
 
 def _ppl(logits, ids):
@@ -228,11 +263,9 @@ def test_native_decode_executor_matches_op_path_and_oracle(name, gs, act, prompt
     # oracle model on the same tokens
     ref = OracleLlama(synth.config_dict(dims), tensors, max_seq_len=max_seq)
     rl = ref.forward(ids.cpu().numpy())
-    ref_steps = []
-    for t in toks_ops:
-        ref_steps.append(ref.forward(np.array([[t]]))[0, 0])
-    ref_steps = np.stack(ref_steps)
-    _model_close(graph.numpy(), ref_steps, ORACLE_TOL, f"executor vs oracle {name} {prompt}")
+    ref_steps, cond = _oracle_steps(ref, toks_ops, prompt)
+    for i in range(n_new):
+        _model_close(graph[i].numpy(), ref_steps[i], ORACLE_TOL, f"executor vs oracle {name} {prompt} step {i}", cond=cond[i])
     # rewinding the cache on the host is picked up by the device-side position
     model.enable_decode_graph(c_graph, use_graph=True)
     c_graph.current_seq_len = prompt
@@ -271,33 +304,40 @@ def test_perplexity_module_chunk_and_token_modes_and_oracle():
 
 def test_perplexity_equal_to_two_decimals_on_a_peaked_model():
     """north_star: "perplexity equal to 2 dp".  The reference prints perplexity with 4 decimals (perplexity.py:121-138); random
-    synthetic weights give near-uniform logits (perplexity ~ vocabulary size), where 2 dp of a number in the hundreds says little.
-    So: a model with a sharpened head (lm_head x 10) evaluated on text SAMPLED from its own next-token distribution, which lands the
-    perplexity (= e^entropy of that distribution) in the range of real text (3 .. 30).  The HIP whole-chunk path, the HIP
-    token-by-token path and the CPU oracle must then agree to |delta| < 0.005 ABSOLUTE."""
+    synthetic weights give near-uniform logits (perplexity ~ vocabulary size), where 2 dp of a number in the thousands says little.
+    So: BASELINE configs[1] layer shapes (two layers, vocabulary 32000) with a sharpened head (lm_head x 3) evaluated on 1536
+    tokens SAMPLED from the model's own next-token distribution, which lands the perplexity (= e^entropy) in the range of real
+    text.  The HIP whole-chunk path (MFMA GEMMs, flash attention), the HIP token-by-token path (decode kernels) and the CPU oracle
+    must agree to |delta| < 0.005 ABSOLUTE.
+    Why these sizes: two paths whose logits differ by noise of standard deviation s (in nats) differ in mean log-probability by
+    ~s / sqrt(tokens) at random plus ~s^2 / 2 systematically for whichever path the text was sampled from (its own perplexity is the
+    entropy, every other path pays the KL divergence).  At real layer shapes s ~ 1e-3 x the logit scale (~17 here): 4e-4 and 1.5e-4
+    nats, i.e. ~0.003 in a perplexity of ~6.  (Round 3 first tried the 512-wide tiny preset with the head x 10: s ~ 4e-3 x scale there and
+    144 tokens gave 6.704 / 6.560 / 6.692 -- the 2 % low value being the sampling path's own -- which is the formula above, not a defect.)"""
     from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
     from exllama_amd.perplexity import Perplexity
-    dims = synth.PRESETS["tiny_hd128"]
-    tensors = synth.make_checkpoint(dims, groupsize=128, act_order=False, seed=23, device="cpu", zeros="rand")
-    tensors["lm_head.weight"] = (tensors["lm_head.weight"].float() * 10.0).half()
-    cfg = ExLlamaConfig(synth.config_dict(dims))
-    cfg.max_seq_len = 160
-    cfg.max_input_len = 160
+    dims, L, S = synth.PRESETS["7b"], 2, 1536
+    tensors = synth.make_checkpoint(dims, groupsize=128, act_order=False, seed=23, device="cpu", zeros="rand", num_layers=L)
+    tensors["lm_head.weight"] = (tensors["lm_head.weight"].float() * 3.0).half()
+    cfg = ExLlamaConfig(synth.config_dict(dims, L))
+    cfg.max_seq_len = S + 64
+    cfg.max_input_len = 2048
     model = ExLlama(cfg, tensors={k: v.clone() for k, v in tensors.items()})
     gen = torch.Generator().manual_seed(17)
     cache = ExLlamaCache(model)
     seq = torch.randint(1, dims.vocab_size, (4,), generator=gen).tolist()
     lg = model.forward(torch.tensor([seq], device="cuda:0"), cache)
-    for _ in range(140):
+    while len(seq) < S:
         nxt = int(torch.multinomial(torch.softmax(lg[0, -1].float().cpu(), -1), 1, generator=gen))
         seq.append(nxt)
         lg = model.forward(torch.tensor([[nxt]], device="cuda:0"), cache)
     ids = torch.tensor([seq])
     p = Perplexity(model=model, cache=ExLlamaCache(model))
-    p.add_tokens(ids.to("cuda:0"), chunk_size=144, overlap=0)
+    p.add_tokens(ids.to("cuda:0"), chunk_size=S, overlap=0)
     whole = p.test(quiet=True)
     token = p.test(quiet=True, ppl_token=True)
-    orc = OracleLlama(synth.config_dict(dims), tensors, max_seq_len=160)
+    orc = OracleLlama(synth.config_dict(dims, L), tensors, max_seq_len=cfg.max_seq_len)
+    orc.prepare()
     lp_sum, n = 0.0, 0
     for c in p.dataset_chunks:
         c = c.cpu()
@@ -307,7 +347,11 @@ def test_perplexity_equal_to_two_decimals_on_a_peaked_model():
         lp_sum += lp.sum().item()
         n += c.shape[1] - 1
     ref = math.exp(-lp_sum / n)
-    assert 3.0 < ref < 30.0, ref
+    stats = os.environ.get("EXL_TOL_STATS")
+    if stats:
+        with open(stats, "a") as f:
+            f.write(json.dumps({"tag": "perplexity whole / token / oracle", "values": [whole, token, ref], "tokens": n}) + "\n")
+    assert 2.0 < ref < 30.0, ref
     assert abs(whole - ref) < 0.005 and abs(token - ref) < 0.005 and abs(whole - token) < 0.005, (whole, token, ref)
     model.free_unmanaged()
 
@@ -469,10 +513,8 @@ def test_native_decode_executor_at_real_layer_shapes(key):
         for i in range(L):
             ref.kc[i][0, :, :P] = cache.key_states[i][0, :, :P].cpu().numpy()
             ref.vc[i][0, :, :P] = cache.value_states[i][0, :, :P].cpu().numpy()
-        ref.past = P
         toks = ids[0, P:P + n_new].tolist()
-        ref_steps = [ref.forward(np.array([[t]]))[0, 0] for t in toks]
-        scale = float(np.abs(np.stack(ref_steps)).max())
+        ref_steps, cond = _oracle_steps(ref, toks, P)
         for mode in ("eager", "graph"):
             c = ExLlamaCache(model, copy_from=cache)
             c.current_seq_len = P
@@ -480,7 +522,7 @@ def test_native_decode_executor_at_real_layer_shapes(key):
             for i, t in enumerate(toks):
                 lg = model.forward(torch.tensor([[t]], device="cuda:0"), c)[0, 0].float().cpu().numpy()
                 assert np.isfinite(lg).all()
-                _model_close(lg, ref_steps[i], ORACLE_TOL, f"real shapes {key} ctx {P} {mode} step {i}")
+                _model_close(lg, ref_steps[i], ORACLE_TOL, f"real shapes {key} ctx {P} {mode} step {i}", cond=cond[i])
                 if mode == "eager":                                  # which kernels this step launched
                     model._set_eager_splits(model._decoder, P + i)
                     plans = {cls: _plan(model, j) for j, cls in enumerate(model.DECODER_CLASSES)}
@@ -531,8 +573,8 @@ def test_real_shape_prefill_end_to_end_vs_oracle():
     _model_close(got, want, ORACLE_TOL, "7B shapes, 2048-token prefill, last-token logits")
     rows = [0, 1, 255, 256, 1023, 1024, 2046, 2047]
     for l in range(L):
-        _model_close(cache.key_states[l][0, :, rows].float().cpu().numpy(), ref.kc[l][0, :, rows].astype(np.float32), ORACLE_TOL, f"K rows layer {l}")
-        _model_close(cache.value_states[l][0, :, rows].float().cpu().numpy(), ref.vc[l][0, :, rows].astype(np.float32), ORACLE_TOL, f"V rows layer {l}")
+        _model_close(cache.key_states[l][0][:, rows].float().cpu().numpy(), ref.kc[l][0][:, rows].astype(np.float32), ORACLE_TOL, f"K rows layer {l}")
+        _model_close(cache.value_states[l][0][:, rows].float().cpu().numpy(), ref.vc[l][0][:, rows].astype(np.float32), ORACLE_TOL, f"V rows layer {l}")
     tok = int(np.argmax(want))
     want2 = ref.forward(np.array([[tok]]))[0, 0]
     model.enable_decode_graph(cache, use_graph=True)
