@@ -33,7 +33,6 @@ struct DecGemvArgs {
     int ablate;                   // measurement only (EXL_DEC_ABLATE): 1 = skip the dequant + MFMA work, 3 = also the scale / zero loads, 4 = also the activation loads
     int nblocks;                  // = gridDim.x (passed explicitly: the implicit-argument load is one more scalar round trip)
     int units_lo, units_rem;      // unit count per block: units_lo + (block < units_rem)
-    int early_weights;            // 1 (default): first weight batch issued before the activation has landed; 0: EXL_DEC_X_FIRST=1
     int ring_flags;               // decode_ring.hip: bit 0 = barrier between the activation loads and the first weight loads of a block
     // act-order (reference: column_remap.cu:7-36 gathers x through x_map before every matmul):
     const uint16_t* map16[DEC_MAX_MATS];   // gather maps of the matrices of this launch as 16-bit indices (K < 65536), or NULL:

@@ -142,8 +142,6 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_MIN_WAVES(U, NP, G16, PNORM, EMODE
     const f16* a_vec = dec_pin_ptr(a.vec); const f16* a_norm_w = dec_pin_ptr(a.norm_w); const int64_t* a_tok = dec_pin_ptr(a.tok);
     int te0 = a.tile_end[0], te1 = a.tile_end[1], te2 = a.tile_end[2], a_nmat = a.nmat;
     int a_rbw = a.rb_per_wave, a_images = a.xs_images, nb = a.nblocks, units_lo = a.units_lo, units_rem = a.units_rem;
-    int early_w = a.early_weights;
-    DEC_PIN_S(early_w);
 #ifdef EXL_DEC_ABLATE_BUILD                                           // measurement builds only (-DEXL_DEC_ABLATE_BUILD): run-time ablation levels
     int abl = a.ablate;
     DEC_PIN_S(abl);
@@ -250,9 +248,8 @@ __global__ __launch_bounds__(DEC_THREADS, DEC_MIN_WAVES(U, NP, G16, PNORM, EMODE
     mA = dec_pick(M0, M1, M2, miA); mB = mA;
     uA = dec_unit(mA, tileA, rb_lo, rb_hi);
     SP_CLK(7);                                                       // first unit described
-    // A/B (EXL_DEC_X_FIRST=1): wait for the activation to land before the weight stream starts.  Measured on 7B: slower
-    // (599 / 712 vs 619 / 731 tokens/s worst / best case), so the default issues the first weight batch right away.
-    if (!early_w) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // The first weight batch is issued before the activation has landed (waiting for it first measured slower on 7B in round 2:
+    // 599 / 712 vs 619 / 731 tokens/s worst / best case; the switch is gone).
     dec_unit_issue<U, G16>(mA, uA, 0, lane, wv0, ep0);               // addresses: scalar arithmetic + one VALU
     SP_CLK(8);                                                       // first weight batch issued (entries / residual loads follow)
     if constexpr (G16) { if (abl < 3) dec_unit_entries<NSLOT>(mA, uA, lane, entA); }
@@ -1148,8 +1145,6 @@ static int launch_dec_gemv(const Decoder* dcfg, int cls, int pnorm, int emode, c
     a.xs_images = any_map ? nmat : 1;                                // act-order: every matrix gathers x through its own map
     static const int ablate = getenv("EXL_DEC_ABLATE") ? atoi(getenv("EXL_DEC_ABLATE")) : 0;
     a.ablate = ablate;
-    static const int x_first = getenv("EXL_DEC_X_FIRST") ? atoi(getenv("EXL_DEC_X_FIRST")) : 0;
-    a.early_weights = !x_first;
     const size_t smem = (size_t) a.xs_images * (K / 8) * 16 + (2 * DEC_WAVES * 16 + DEC_WAVES + 16) * sizeof(float) + (any_map ? (size_t) K * 2 : 0);
     EXL_REQUIRE(smem <= 160 * 1024, EXL_E_UNSUPPORTED, "decoder: activation stage (%zu bytes of LDS) exceeds the 160 KiB of a CU", smem);
     const int nv = (K / 8 + DEC_THREADS - 1) / DEC_THREADS;
@@ -1199,11 +1194,10 @@ static int launch_dec_gemv(const Decoder* dcfg, int cls, int pnorm, int emode, c
 // where the boundary is also a smaller share of the layer.
 // (Round 2 re-test with a ROLLED merge loop writing straight to LDS, no spill: 13B o_proj 7.3 + 2.8 (merge kernel) -> 14.7 us
 // folded, 65B 10.0 + 3.0 -> 19.7: every one of the 320-512 o_proj blocks re-reads all split partials (two dependent round
-// trips of 16 x 16 bytes per thread).  EXL_DEC_FOLD_WIDE=1 keeps it reachable.)
+// trips of 16 x 16 bytes per thread); the switch that kept the wide fold reachable is gone.)
 static bool dec_folds_merge(const Decoder* d)
 {
-    static const bool wide = getenv("EXL_DEC_FOLD_WIDE") != nullptr;
-    return !d->separate_merge && d->qd() <= (wide ? 2 : 1) * DEC_THREADS * 8;
+    return !d->separate_merge && d->qd() <= DEC_THREADS * 8;
 }
 
 // One kernel class of one layer (EXL_DEC_* in include/exl_amd.h); EXL_DEC_HEAD ignores `i`.
