@@ -165,10 +165,17 @@ __global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 
     constexpr int NT = NW * 64;
     static_assert(ring_valid(U, UL), "one raw entry set: see ring_valid");
     constexpr int WPT = EMODE == 2 ? NW / 2 : NW;                    // waves per tile
+    constexpr bool ACT = PNORM == 2;                                 // RMSNorm + act-order: one gathered image per matrix, permuted gate/up store
     constexpr int EL0 = 2 + (EMODE == 1 ? 1 : 0);                    // entry loads of chunk 0 (with the residual value of the column)
+    constexpr int MAXP = 4;                                          // ACT, EMODE 2: units per block whose store indices are fetched in the prologue
+    constexpr int NIMG = !ACT ? 1 : EMODE == 2 ? 2 : 3;              // act-order: q / k / v (gate / up) each gather through their own map
+    constexpr int GT = (ACT && EMODE == 2) ? WPT * 64 : NT;          // threads that build one image (gate: waves 0-3, up: waves 4-7)
+    constexpr int GV = NV * (NT / GT);                               // packed rows per thread and image
+    constexpr int NMAP = !ACT ? 1 : EMODE == 2 ? GV : 3 * GV;
     constexpr int IMG_ROWS = WPT * UL * 16 > NV * NT ? WPT * UL * 16 : NV * NT;   // packed rows of the image (zero padded)
     constexpr int MS = PNORM == 3 ? DEC_MAX_NSPLIT : 1;
     static_assert(PNORM != 3 || NV == 1, "the merge prologue holds one 8-dim vector per thread");
+    static_assert(!ACT || EMODE != 1, "a residual launch reads a producer-permuted vector: nothing to gather");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef EXL_RING_PROBE
     unsigned long long rp_t[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -178,11 +185,39 @@ __global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 
     // ---- 0. the few kernel arguments the activation requests need; the matrix views follow once those requests are out (each
     // group of pinned scalars is a scalar-cache round trip: with all three matrix views first, q/k/v issued its activation loads
     // 3,000 cycles into the block)
+    // Round 3, second pass: EVERY scalar argument the kernel uses is requested in ONE batch.  The pins used to be one asm
+    // statement per field; hipcc then loaded the kernarg segment lazily, group by group, with an `s_waitcnt lgkmcnt(0)` between
+    // the groups: five dependent round trips to a scalar cache that is cold for every dispatch (the phase stamps put the ring
+    // issue of q/k/v 2,500 cycles after its activation requests).  One asm statement with all fields as operands leaves the
+    // compiler no place to wait in between.
     int K = a.mat[0].K, flags = a.ring_flags;
-    const f16* a_vec = dec_pin_ptr(a.vec); const f16* a_norm_w = dec_pin_ptr(a.norm_w); const int64_t* a_tok = dec_pin_ptr(a.tok);
-    DEC_PIN_S(K); DEC_PIN_S(flags);
-    uint4* xs = (uint4*) smem;                                       // [IMG_ROWS]
-    float* red = (float*) (smem + (size_t) IMG_ROWS * 16);           // [2][NW][16] + [NW]
+    T16Matrix M0 = a.mat[0], M1 = a.mat[1], M2 = a.mat[2];
+    int te0 = a.tile_end[0], te1 = a.tile_end[1], te2 = a.tile_end[2], a_nmat = a.nmat;
+    int a_rbw = a.rb_per_wave, nb = a.nblocks, units_lo = a.units_lo, units_rem = a.units_rem;
+    uint64_t p_vec = (uint64_t) a.vec, p_nw = (uint64_t) a.norm_w, p_tok = (uint64_t) a.tok, p_res = (uint64_t) a.res_in;
+    uint64_t p_q0 = (uint64_t) M0.qw, p_z0 = (uint64_t) M0.qzeros, p_s0 = (uint64_t) M0.scales;
+    uint64_t p_q1 = (uint64_t) M1.qw, p_z1 = (uint64_t) M1.qzeros, p_s1 = (uint64_t) M1.scales;
+    uint64_t p_q2 = (uint64_t) M2.qw, p_z2 = (uint64_t) M2.qzeros, p_s2 = (uint64_t) M2.scales;
+    asm volatile("; kernel arguments: one batch"
+                 : "+s"(K), "+s"(flags), "+s"(p_vec), "+s"(p_nw), "+s"(p_tok), "+s"(p_res),
+                   "+s"(p_q0), "+s"(p_z0), "+s"(p_s0), "+s"(M0.N), "+s"(M0.RB), "+s"(M0.gprows), "+s"(M0.gshift),
+                   "+s"(p_q1), "+s"(p_z1), "+s"(p_s1), "+s"(M1.N), "+s"(M1.RB), "+s"(M1.gprows), "+s"(M1.gshift),
+                   "+s"(p_q2), "+s"(p_z2), "+s"(p_s2), "+s"(M2.N), "+s"(M2.RB), "+s"(M2.gprows), "+s"(M2.gshift),
+                   "+s"(te0), "+s"(te1), "+s"(te2));
+    uint64_t p_g0 = (uint64_t) a.map16[0], p_g1 = (uint64_t) a.map16[1], p_g2 = (uint64_t) a.map16[2], p_op = (uint64_t) a.out_perm;
+    asm volatile("" : "+s"(a_nmat), "+s"(a_rbw), "+s"(nb), "+s"(units_lo), "+s"(units_rem), "+s"(p_g0), "+s"(p_g1), "+s"(p_g2), "+s"(p_op));
+#define RING_GPTR(T, v) ((T) (std::remove_pointer_t<T> __attribute__((address_space(1)))*) (v))
+    const f16* a_vec = RING_GPTR(const f16*, p_vec); const f16* a_norm_w = RING_GPTR(const f16*, p_nw);
+    const int64_t* a_tok = RING_GPTR(const int64_t*, p_tok); const f16* a_res = RING_GPTR(const f16*, p_res);
+    const uint16_t* a_g0 = RING_GPTR(const uint16_t*, p_g0); const uint16_t* a_g1 = RING_GPTR(const uint16_t*, p_g1);
+    const uint16_t* a_g2 = RING_GPTR(const uint16_t*, p_g2); const uint16_t* a_operm = RING_GPTR(const uint16_t*, p_op);
+    M0.qw = RING_GPTR(const uint4*, p_q0); M0.qzeros = RING_GPTR(const uint32_t*, p_z0); M0.scales = RING_GPTR(const f16*, p_s0);
+    M1.qw = RING_GPTR(const uint4*, p_q1); M1.qzeros = RING_GPTR(const uint32_t*, p_z1); M1.scales = RING_GPTR(const f16*, p_s1);
+    M2.qw = RING_GPTR(const uint4*, p_q2); M2.qzeros = RING_GPTR(const uint32_t*, p_z2); M2.scales = RING_GPTR(const f16*, p_s2);
+#undef RING_GPTR
+    uint4* xs = (uint4*) smem;                                       // [NIMG][IMG_ROWS]
+    float* red = (float*) (smem + (size_t) NIMG * IMG_ROWS * 16);    // [2][NW][16] + [NW]
+    uint4* xlin = (uint4*) (smem + (size_t) NIMG * IMG_ROWS * 16 + (2 * NW * 16 + NW) * sizeof(float));   // ACT: the normalised vector in its own order, [K / 8]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rsub = lane >> 4, col = lane & 15;
@@ -191,11 +226,11 @@ __global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 
 
     // ---- 1. activation loads (all waves), then the ring of the first unit -----------------------------------------------------
     const f16* src = a_vec;
-    if constexpr (PNORM == 1) { if (a_tok) src = a_vec + (size_t) (*a_tok) * K; }
-    u32x4 xraw[NV], wraw[NV];
+    if constexpr (PNORM == 1 || ACT) { if (a_tok) src = a_vec + (size_t) (*a_tok) * K; }
+    u32x4 xraw[NV], wraw[NV], mraw[NMAP];
     u32x4 praw[MS];
     uint64_t pml = 0;
-    if constexpr (PNORM == 1) {
+    if constexpr (PNORM == 1 || ACT) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + i * NT;
@@ -207,6 +242,26 @@ __global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 
             const int idx = tid + i * NT;
             const int ci = idx < nvec ? idx : 0;
             rg_ld16(wraw[i], a_norm_w + ci * 8);
+        }
+        if constexpr (ACT) {                                         // the gather maps of the images this thread builds: 8 16-bit indices per packed row
+            if constexpr (EMODE == 2) {
+                const uint16_t* gm = (wave / WPT) ? a_g1 : a_g0;
+#pragma unroll
+                for (int i = 0; i < GV; ++i) {
+                    const int idx = tid % GT + i * GT;
+                    rg_ld16(mraw[i], gm + (idx < nvec ? idx : 0) * 8);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const uint16_t* gm = k == 0 ? a_g0 : k == 1 ? a_g1 : a_g2;
+#pragma unroll
+                    for (int i = 0; i < GV; ++i) {
+                        const int idx = tid + i * NT;
+                        rg_ld16(mraw[k * GV + i], gm + (idx < nvec ? idx : 0) * 8);
+                    }
+                }
+            }
         }
     } else if constexpr (PNORM == 3) {
         // 16 consecutive 8-dim vectors = one head; lane (l & 15) also fetches (max, sum) of split l & 15 of that head
@@ -227,14 +282,6 @@ __global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 
         }
     }
     RP_CLK(0);                                                       // activation requests issued
-    // ---- the rest of the kernel arguments into SGPRs ---------------------------------------------------------------------------
-    T16Matrix M0 = a.mat[0], M1 = a.mat[1], M2 = a.mat[2];
-    dec_pin(M0); dec_pin(M1); dec_pin(M2);
-    const f16* a_res = dec_pin_ptr(a.res_in);
-    int te0 = a.tile_end[0], te1 = a.tile_end[1], te2 = a.tile_end[2], a_nmat = a.nmat;
-    int a_rbw = a.rb_per_wave, nb = a.nblocks, units_lo = a.units_lo, units_rem = a.units_rem;
-    DEC_PIN_S(te0); DEC_PIN_S(te1); DEC_PIN_S(te2); DEC_PIN_S(a_nmat); DEC_PIN_S(a_rbw);
-    DEC_PIN_S(nb); DEC_PIN_S(units_lo); DEC_PIN_S(units_rem);
     const int RB = M0.RB;
     const int nunits = EMODE == 2 ? te0 : (a_nmat == 1 ? te0 : a_nmat == 2 ? te1 : te2);
     const int b = blockIdx.x;
@@ -265,7 +312,9 @@ __global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 
 
     // ---- ring state ---------------------------------------------------------------------------------------------------------
     u32x4 ring[U];
-    uint32_t rz = 0, rs = 0, rres = 0;                               // raw zero / scale word of the chunk in flight (and the residual)
+    uint32_t rz = 0, rs = 0, rres = 0;                               // raw zero / scale word of the chunk in flight (and the residual, or the store index)
+    uint32_t pr[MAXP] = {0u, 0u, 0u, 0u};                            // ACT, EMODE 2: out_perm[n] of this lane's column in unit i (fetched once, ahead of the ring:
+                                                                     // a per-unit request in flight across the loop back-edge made hipcc copy the register it lands in)
     uint32_t ent = 0;                                                // entries of the chunk being consumed: lane (rsub, col) holds row-block 4 c + rsub
     float res_cur = 0.f;
     auto issue_entries = [&](const RingUnit& u, int chunk) {         // ring_entry_loads(4 * chunk) loads, in this order
@@ -290,6 +339,13 @@ __global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 
         rg_ldw(ring[t % U], lane16, u.wbase + (size_t) (uint32_t) rb * 1024u);
     };
 
+    if constexpr (ACT && EMODE == 2) {                               // column n of silu(gate) * up is stored at out_perm[n] (the consumer's inverse gather map)
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const RingUnit u = describe(i < n_my ? i : 0);
+            rg_ld2(pr[i], a_operm + u.n0 + col);
+        }
+    }
     if (flags & 1) asm volatile("s_barrier" ::: "memory");           // every wave's activation request is queued before any weight request
     RingUnit cur = describe(0);
     // PRE of the U ring requests go out now; the rest follows the image barrier: a wave that is still queueing requests cannot
@@ -298,12 +354,19 @@ __global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 
     RP_CLK(1);                                                       // first ring requests issued
     // zero padding of the image: slots past a wave's range read it (finite x, scale 0)
     for (int idx = tid; idx < IMG_ROWS; idx += NT)
-        if (idx >= nvec && (PNORM != 0 || idx >= NV * NT)) xs[idx] = make_uint4(0u, 0u, 0u, 0u);
+        if (idx >= nvec && (PNORM != 0 || idx >= NV * NT)) {
+#pragma unroll
+            for (int k = 0; k < NIMG; ++k) xs[k * IMG_ROWS + idx] = make_uint4(0u, 0u, 0u, 0u);
+        }
 
     // ---- 2. activation image --------------------------------------------------------------------------------------------------
     rg_wait<ring_prologue_ops(U, UL, EL0, PRE)>();                   // everything older than the ring requests has landed
     RP_CLK(2);                                                       // activation landed
-    if constexpr (PNORM == 1) {
+    if constexpr (ACT && EMODE == 2) {
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) rg_tie(pr[i]);
+    }
+    if constexpr (PNORM == 1 || ACT) {
         f16x8 xv[NV];
         float ss = 0.f;
 #pragma unroll
@@ -330,7 +393,34 @@ __global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const f16 t = xv[i][j] * rm; xv[i][j] = t * nw[j]; }
             const int idx = tid + i * NT;
-            if (idx < nvec) xs[idx] = __builtin_bit_cast(uint4, xv[i]);
+            if (idx < nvec) (ACT ? xlin : xs)[idx] = __builtin_bit_cast(uint4, xv[i]);
+        }
+        if constexpr (ACT) {                                         // reference: column_remap.cu:7-36, x'[c] = x[x_map[c]], per matrix
+            rg_barrier();
+            const f16* xl = (const f16*) xlin;
+            auto gather_row = [&](u32x4& m, uint4* dst) {
+                rg_tie(m);
+                f16x8 g;
+                g[0] = xl[m[0] & 0xFFFFu]; g[1] = xl[m[0] >> 16]; g[2] = xl[m[1] & 0xFFFFu]; g[3] = xl[m[1] >> 16];
+                g[4] = xl[m[2] & 0xFFFFu]; g[5] = xl[m[2] >> 16]; g[6] = xl[m[3] & 0xFFFFu]; g[7] = xl[m[3] >> 16];
+                *dst = __builtin_bit_cast(uint4, g);
+            };
+            if constexpr (EMODE == 2) {
+                uint4* img = xs + (wave / WPT) * IMG_ROWS;
+#pragma unroll
+                for (int i = 0; i < GV; ++i) {
+                    const int idx = tid % GT + i * GT;
+                    if (idx < nvec) gather_row(mraw[i], img + idx);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int i = 0; i < GV; ++i) {
+                        const int idx = tid + i * NT;
+                        if (idx < nvec) gather_row(mraw[k * GV + i], xs + k * IMG_ROWS + idx);
+                    }
+            }
         }
     } else if constexpr (PNORM == 3) {
         // log-sum-exp merge of the attention splits, per head inside its 16-lane group (dec_stream_kernel, PNORM 3)
@@ -367,6 +457,7 @@ __global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 
     auto unit_body = [&](auto last_tag, const RingUnit& uc, const RingUnit& un, int i) {
         constexpr bool LAST = decltype(last_tag)::value;
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        const uint4* xr = ACT ? xrow + uc.mi * IMG_ROWS : xrow;      // act-order: the image gathered through this matrix' map
         static_for<0, UL>([&](auto lic) {
             constexpr int li = decltype(lic)::value;
             rg_wait<ring_younger(U, UL, EL0, LAST, li)>(ring[li % U]);
@@ -376,13 +467,14 @@ __global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 
 #ifdef EXL_RING_ABLATE                                               /* measurement builds: the loads without the arithmetic */
             c[0] += __uint_as_float((w.x ^ w.w) & 0x3fffffffu) + __uint_as_float(e & 0x3fffffffu);
 #else
-            t16_rowblock<true>(w, e, magic, xrow + li * 16, c);
+            t16_rowblock<true>(w, e, magic, xr + li * 16, c);
 #endif
             if constexpr (li + U < UL) issue_step(uc, std::integral_constant<int, li + U>{});
             else if constexpr (!LAST) issue_step(un, std::integral_constant<int, li % U>{});
         });
         float* rp = red + (i & 1) * NW * 16;
         const float res = res_cur;                                   // (the next unit's entries may already be on their way: res_cur is this unit's)
+        const uint32_t perm = (i == 0 ? pr[0] : i == 1 ? pr[1] : i == 2 ? pr[2] : pr[3]) & 0xFFFFu;
         if (lane < 16) rp[wave * 16 + lane] = c[0];
         if (i == 0) RP_CLK(4);                                       // unit 0 consumed
         rg_barrier();
@@ -393,7 +485,7 @@ __global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 
                 float g = 0.f, u = 0.f;
 #pragma unroll
                 for (int k = 0; k < WPT; ++k) { g += rp[k * 16 + tid]; u += rp[(WPT + k) * 16 + tid]; }
-                a.out[0][n] = silu_mul_f16((f16) g, (f16) u);
+                a.out[0][ACT ? (int) perm : n] = silu_mul_f16((f16) g, (f16) u);
             } else {
                 float v = 0.f;
 #pragma unroll
@@ -413,7 +505,7 @@ __global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 
 #ifdef EXL_RING_PROBE
     RP_CLK(6);
     if (tid == 0 && b < 512) {
-        constexpr int cls = PNORM == 3 ? 1 : EMODE == 2 ? 2 : PNORM == 1 ? 0 : 3;
+        constexpr int cls = PNORM == 3 ? 1 : EMODE == 2 ? 2 : (PNORM == 1 || ACT) ? 0 : 3;
         unsigned long long* dst = g_ring_probe + ((size_t) cls * 512 + b) * 8;
 #pragma unroll
         for (int q = 0; q < 7; ++q) dst[q] = rp_t[q] - rp_t0;
@@ -425,11 +517,12 @@ __global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------------------
-static size_t dec_ring_smem(int UL, int emode, int nv, int nw)
+static size_t dec_ring_smem(int UL, int pnorm, int emode, int nv, int nw, int K)
 {
     const int wpt = emode == 2 ? nw / 2 : nw;
     const int rows = wpt * UL * 16 > nv * nw * 64 ? wpt * UL * 16 : nv * nw * 64;
-    return (size_t) rows * 16 + (2 * nw * 16 + nw) * sizeof(float);
+    const int nimg = pnorm != 2 ? 1 : emode == 2 ? 2 : 3;
+    return (size_t) nimg * rows * 16 + (2 * nw * 16 + nw) * sizeof(float) + (pnorm == 2 ? (size_t) K * 2 : 0);
 }
 
 template <int U, int UL, int PNORM, int EMODE, int NV, int NW>
@@ -438,7 +531,8 @@ static int ring_go(int grid, int rbw, const DecGemvArgs& a0, hipStream_t s, int*
     // (PRE < U -- part of the ring requested only after the activation image is staged -- measured within noise of PRE = U on
     // every 7B class, round 3: the template parameter stays, one value is instantiated)
     auto kfn = dec_ring_kernel<U, UL, PNORM, EMODE, NV, NW, U>;
-    const size_t smem = dec_ring_smem(UL, EMODE, NV, NW);
+    const size_t smem = dec_ring_smem(UL, PNORM, EMODE, NV, NW, a0.mat[0].K);
+    if (smem > 160 * 1024 / (NW == 8 ? 2 : 1) && PNORM == 2) return 1;   // two blocks per CU must fit: otherwise the compiler stream
     if (plan) {                                                      // exl_decoder_plan: [0] launched, [1] U, [2] UL, [3] 2 = ring kernel, [4] PNORM, [5] EMODE, [6] NV, [9] waves per block
         plan[0] = 1; plan[1] = U; plan[2] = UL; plan[3] = 2; plan[4] = PNORM; plan[5] = EMODE; plan[6] = NV;
         plan[7] = grid; plan[8] = (int) smem; plan[9] = NW;
@@ -487,9 +581,17 @@ static int ring_cfg(int depth, int rbw, int grid, const DecGemvArgs& a, hipStrea
 
 int launch_dec_ring(int pnorm, int emode, bool g16, int K, int grid, int depth, bool wide_blocks, const DecGemvArgs& a, hipStream_t s, int* plan)
 {
-    if (!g16 || a.out_perm) return 1;
-    for (int i = 0; i < DEC_MAX_MATS; ++i)
-        if (a.map16[i]) return 1;
+    if (!g16) return 1;
+    bool any_map = false, all_maps = true;
+    for (int i = 0; i < a.nmat && i < DEC_MAX_MATS; ++i) { any_map = any_map || a.map16[i]; all_maps = all_maps && a.map16[i]; }
+    if (any_map || a.out_perm) {
+        // act-order: the RMSNorm launches gather one image per matrix (q / k / v: 3, gate / up: 2 + the permuted store for down_proj);
+        // everything else (a permuted store without a gather, a partial set of maps) stays on the compiler stream
+        const bool qkv = emode == 0 && a.nmat == 3 && !a.out_perm, gate_up = emode == 2 && a.nmat == 2 && a.out_perm;
+        if (pnorm != 1 || !all_maps || !(qkv || gate_up)) return 1;
+        if (gate_up && a.units_lo + (a.units_rem ? 1 : 0) > 4) return 1;      // the store indices of <= 4 units per block are fetched in the prologue
+        pnorm = 2;
+    }
     const int RB = K / 128;
     const bool wide = wide_blocks && pnorm == 0 && emode == 1 && RB >= 32;   // 16 waves: at least two row-blocks per wave
     const int nw = wide ? 16 : DEC_WAVES;
@@ -506,6 +608,8 @@ int launch_dec_ring(int pnorm, int emode, bool g16, int K, int grid, int depth, 
 #else
     if (pnorm == 1 && emode == 0) { if (nv <= 1) RING_GO(1, 0, 1, 8); if (nv <= 2) RING_GO(1, 0, 2, 8); }
     if (pnorm == 1 && emode == 2) { if (nv <= 1) RING_GO(1, 2, 1, 8); if (nv <= 2) RING_GO(1, 2, 2, 8); }
+    if (pnorm == 2 && emode == 0) { if (nv <= 1) RING_GO(2, 0, 1, 8); if (nv <= 2) RING_GO(2, 0, 2, 8); }
+    if (pnorm == 2 && emode == 2) { if (nv <= 1) RING_GO(2, 2, 1, 8); if (nv <= 2) RING_GO(2, 2, 2, 8); }
     if (pnorm == 3 && emode == 1 && nv <= 1) RING_GO(3, 1, 1, 8);
     if (pnorm == 0 && emode == 1 && !wide) {
         if (nv <= 1) RING_GO(0, 1, 1, 8);

@@ -471,9 +471,9 @@ _REAL_SHAPES = {
     # 7B o_proj at one KV split and down_proj: 256 tiles = one block per CU -> 16-wave blocks (2 / 6 row-blocks per wave)
     "7b":  ("7b", 128, False, 2, (3, 4, 2, 1, 0, 1), (3, 4, 2, 3, 1, 1), (3, 8, 2, 1, 2, 1), (4, 6, 2, 0, 1, 2), False),
     # (U, NP) fits the row-blocks per wave exactly where it can: 13B 5 / 10 / 14, 33B 7 / 13 / 18, 65B 8 / 16 / 22, 70B 8 / 16 / 28
-    # 13B act-order: q/k/v and gate/up gather through their maps (dec_stream_kernel); o_proj / down_proj get their input already
-    # in row order (ring)
-    "13b": ("13b", 128, True, 1, (5, 1, 1, 1, 0, 2), (4, 5, 2, 0, 1, 2), (5, 2, 1, 1, 2, 2), (3, 14, 2, 0, 1, 6), True),
+    # 13B act-order: q/k/v and gate/up gather one image per matrix through their maps (ring kernel, PNORM 2; gate/up also stores
+    # through down_proj's inverse map); o_proj / down_proj get their input already in row order
+    "13b": ("13b", 128, True, 1, (4, 5, 2, 2, 0, 2), (4, 5, 2, 0, 1, 2), (3, 10, 2, 2, 2, 2), (3, 14, 2, 0, 1, 6), True),
     "33b": ("33b", 32, True, 1, (4, 2, 0, 1, 0, 2), (4, 2, 0, 0, 1, 2), (7, 2, 0, 1, 2, 2), (6, 3, 0, 0, 1, 6), True),
     "65b": ("65b", 128, False, 1, (3, 8, 2, 1, 0, 2), (3, 8, 2, 0, 1, 2), (3, 16, 2, 1, 2, 2), (3, 22, 2, 0, 1, 6), True),
     # Llama-2-70B: GQA (8 kv heads) and K = 28672 in down_proj -- 28 row-blocks per wave, 7 -> 8 vectors per thread
