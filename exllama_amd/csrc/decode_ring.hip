@@ -54,6 +54,16 @@ __device__ __forceinline__ void rg_ldw(u32x4& d, uint32_t voff, const void* sbas
     // instruction reads that SGPR as its base; hipcc pads its own instructions, never the inside of an asm statement
     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt" : "=v"(d) : "v"(voff), "s"(sb) : "memory");
 }
+// wave-uniform base + 32-bit lane offset for the small loads too (GM: three requests per step; 64-bit per-lane addresses for each of
+// them, computed ahead by the scheduler, were what spilled the long units)
+__device__ __forceinline__ const void* rg_uniform(const void* p)
+{
+    const uint64_t b = (uint64_t) p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t) b), hi = __builtin_amdgcn_readfirstlane((uint32_t) (b >> 32));
+    return (const void*) (((uint64_t) hi << 32) | lo);
+}
+__device__ __forceinline__ void rg_ld4s(uint32_t& d, uint32_t voff, const void* sbase) { asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(d) : "v"(voff), "s"(rg_uniform(sbase)) : "memory"); }
+__device__ __forceinline__ void rg_ld2s(uint32_t& d, uint32_t voff, const void* sbase) { asm volatile("s_nop 4\n\tglobal_load_ushort %0, %1, %2" : "=v"(d) : "v"(voff), "s"(rg_uniform(sbase)) : "memory"); }
 __device__ __forceinline__ void rg_ld16(u32x4& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
 // (8 bytes travel as one uint64_t: hipcc 7.2 reads element 0 for BOTH elements of a 2 x 32-bit ext_vector that comes out of an asm)
 __device__ __forceinline__ void rg_ld8(uint64_t& d, const void* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
@@ -118,26 +128,28 @@ extern "C" int exl_debug_ring_probe(int cls, unsigned long long* out8)     // su
 // last unit).  The first U steps of a unit are therefore requested in the order of the previous unit's last U steps (the
 // prologue uses the same order for the first unit).  A request for a step that opens a chunk of 4 row-blocks (step % 4 == 0) is
 // preceded by the chunk's entry loads: 2, plus the residual load with chunk 0 when the epilogue adds the residual (EL0).
-constexpr int ring_entry_loads(int step, int el0) { return step % 4 == 0 ? (step == 0 ? el0 : 2) : 0; }
+// GM (group sizes 32 / 64: every lane fetches the scale / zero pair of its own k-group with every piece): 2 per step instead.
+constexpr int ring_entry_loads(int step, int el0, bool gm) { return gm ? 2 + (step == 0 ? el0 - 2 : 0) : step % 4 == 0 ? (step == 0 ? el0 : 2) : 0; }
 // One raw entry set: the words of a chunk must have been combined before the next chunk's words are requested.  Inside a unit that
 // holds for every U <= 4 (chunk c + 1 is requested at step 4 (c + 1) - U >= 4 c); across units the next unit's chunk 0 goes out at
 // the last use of slot 0, which must not come before the last chunk of this unit is combined.
-constexpr bool ring_valid(int U, int UL) { return U >= 1 && U <= 4 && UL >= U && ((UL - 1) / U) * U >= ((UL - 1) / 4) * 4; }
+// (GM keeps one raw pair per ring slot: every U <= 4 is valid)
+constexpr bool ring_valid(int U, int UL, bool gm = false) { return U >= 1 && U <= 4 && UL >= U && (gm || ((UL - 1) / U) * U >= ((UL - 1) / 4) * 4); }
 // vector-memory instructions the first `n` ring requests of the prologue make up (entries included)
-constexpr int ring_prologue_ops(int U, int UL, int el0, int n)
+constexpr int ring_prologue_ops(int U, int UL, int el0, int n, bool gm)
 {
     int ops = 0;
-    for (int j = 0; j < n; ++j) ops += ring_entry_loads((UL - U + j) % U, el0) + 1;
+    for (int j = 0; j < n; ++j) ops += ring_entry_loads((UL - U + j) % U, el0, gm) + 1;
     return ops;
 }
 // vector-memory instructions issued after the load of step `li` and before step `li` is consumed = the N of its `s_waitcnt vmcnt(N)`
-constexpr int ring_younger(int U, int UL, int el0, bool last, int li)
+constexpr int ring_younger(int U, int UL, int el0, bool last, int li, bool gm)
 {
     int issued = 0;                 // instructions issued so far
     int pos = -1;                   // issue index of the load of (this unit, li)
     for (int j = 0; j < U; ++j) {   // the previous unit's tail (or the prologue): this unit's steps (UL - U + j) % U
         const int t = (UL - U + j) % U;
-        issued += ring_entry_loads(t, el0);
+        issued += ring_entry_loads(t, el0, gm);
         if (t == li) pos = issued;
         issued += 1;
     }
@@ -145,11 +157,11 @@ constexpr int ring_younger(int U, int UL, int el0, bool last, int li)
         if (s == li) return issued - (pos + 1);
         const int T = s + U;
         if (T < UL) {
-            issued += ring_entry_loads(T, el0);
+            issued += ring_entry_loads(T, el0, gm);
             if (T == li) pos = issued;
             issued += 1;
         } else if (!last) {
-            issued += ring_entry_loads(s % U, el0) + 1;          // next unit's step s % U
+            issued += ring_entry_loads(s % U, el0, gm) + 1;      // next unit's step s % U
         }
     }
     return 0;
@@ -158,12 +170,14 @@ constexpr int ring_younger(int U, int UL, int el0, bool last, int li)
 // NW: waves per block (8; 16 for the plain-vector launches that leave one block per CU: twice the requests in flight per CU, half
 // the serial chain per wave).  Register budget: two 8-wave blocks or one 16-wave block per CU (128 VGPRs); the longest unrolled
 // units (UL >= 24) and the merge prologue (hidden <= 4096: never more blocks than CUs) are allowed 256.
-template <int U, int UL, int PNORM, int EMODE, int NV, int NW, int PRE>
+template <int U, int UL, int PNORM, int EMODE, int NV, int NW, int PRE, int GM>
 __global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 : 4) void dec_ring_kernel(const DecGemvArgs a)
 {
     static_assert(PRE >= 0 && PRE <= U, "ring requests ahead of the activation image");
     constexpr int NT = NW * 64;
-    static_assert(ring_valid(U, UL), "one raw entry set: see ring_valid");
+    static_assert(ring_valid(U, UL, GM != 0), "one raw entry set: see ring_valid");
+    static_assert(GM == 0 || PNORM != 3, "group sizes 32 / 64: the merge stays its own kernel");
+    constexpr int NRAW = GM ? U : 1;                                 // raw scale / zero words in flight: per ring slot (GM) or one chunk
     constexpr int WPT = EMODE == 2 ? NW / 2 : NW;                    // waves per tile
     constexpr bool ACT = PNORM == 2;                                 // RMSNorm + act-order: one gathered image per matrix, permuted gate/up store
     constexpr int EL0 = 2 + (EMODE == 1 ? 1 : 0);                    // entry loads of chunk 0 (with the residual value of the column)
@@ -218,6 +232,7 @@ __global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 
     uint4* xs = (uint4*) smem;                                       // [NIMG][IMG_ROWS]
     float* red = (float*) (smem + (size_t) NIMG * IMG_ROWS * 16);    // [2][NW][16] + [NW]
     uint4* xlin = (uint4*) (smem + (size_t) NIMG * IMG_ROWS * 16 + (2 * NW * 16 + NW) * sizeof(float));   // ACT: the normalised vector in its own order, [K / 8]
+    uint4* zpad = xlin + (ACT ? K >> 3 : 0);                          // GM: 64 bytes of zeros (the A rows of the lanes that carry no k-group)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rsub = lane >> 4, col = lane & 15;
@@ -312,7 +327,9 @@ __global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 
 
     // ---- ring state ---------------------------------------------------------------------------------------------------------
     u32x4 ring[U];
-    uint32_t rz = 0, rs = 0, rres = 0;                               // raw zero / scale word of the chunk in flight (and the residual, or the store index)
+    uint32_t rz[NRAW], rs[NRAW], rres = 0;                           // raw zero / scale words in flight (and the residual)
+#pragma unroll
+    for (int q = 0; q < NRAW; ++q) { rz[q] = 0; rs[q] = 0; }
     uint32_t pr[MAXP] = {0u, 0u, 0u, 0u};                            // ACT, EMODE 2: out_perm[n] of this lane's column in unit i (fetched once, ahead of the ring:
                                                                      // a per-unit request in flight across the loop back-edge made hipcc copy the register it lands in)
     uint32_t ent = 0;                                                // entries of the chunk being consumed: lane (rsub, col) holds row-block 4 c + rsub
@@ -321,20 +338,33 @@ __global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 
         const int n = u.n0 + col;
         const int rb = min(rb_lo + 4 * chunk + rsub, RB - 1);
         const int g = u.gshift >= 0 ? ((rb * 16) >> u.gshift) : ((rb * 16) / u.gprows);
-        rg_ld4(rz, u.qzeros + (size_t) g * (u.N >> 3) + (n >> 3));
-        rg_ld2(rs, u.scales + (size_t) g * u.N + n);
+        rg_ld4(rz[0], u.qzeros + (size_t) g * (u.N >> 3) + (n >> 3));
+        rg_ld2(rs[0], u.scales + (size_t) g * u.N + n);
         if (EMODE == 1 && chunk == 0) rg_ld2(rres, (const uint16_t*) a_res + n);
     };
+    // GM (group size 32 / 64, gshift 2 / 3): the pair of lane (k-group rsub, column col) for step t, into slot t % U.  Group of the
+    // lane = first group of the row-block (uniform) + (4 rsub >> gshift): uniform base per step, 32-bit lane offset per unit.
+    auto issue_entries_gm = [&](const RingUnit& u, auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const int rb = min(rb_lo + t, RB - 1);
+        const uint32_t gb = (uint32_t) (rb * 16) >> (uint32_t) u.gshift;     // uniform
+        const uint32_t gl = (uint32_t) (rsub * 4) >> (uint32_t) u.gshift;
+        const uint32_t n8 = (uint32_t) u.N >> 3;
+        rg_ld4s(rz[t % NRAW], (gl * n8 + ((uint32_t) col >> 3)) * 4u, u.qzeros + (size_t) gb * n8 + ((uint32_t) u.n0 >> 3));
+        rg_ld2s(rs[t % NRAW], (gl * (uint32_t) u.N + (uint32_t) col) * 2u, u.scales + (size_t) gb * (uint32_t) u.N + (uint32_t) u.n0);
+        if (EMODE == 1 && t == 0) rg_ld2(rres, (const uint16_t*) a_res + u.n0 + col);
+    };
     auto combine_entries = [&](int chunk) {                          // after the wait that covers the raw words
-        rg_tie(rz); rg_tie(rs);
-        const uint32_t e = (rs & 0xFFFFu) | ((0xE401u + ((rz >> (uint32_t) ((col & 7) * 4)) & 0xFu)) << 16);
+        rg_tie(rz[0]); rg_tie(rs[0]);
+        const uint32_t e = (rs[0] & 0xFFFFu) | ((0xE401u + ((rz[0] >> (uint32_t) ((col & 7) * 4)) & 0xFu)) << 16);
         ent = (rb_lo + 4 * chunk + rsub < rb_hi) ? e : 0u;           // rows past the wave's range: scale 0 -> contribute nothing
         if (EMODE == 1 && chunk == 0) { rg_tie(rres); res_cur = (float) __builtin_bit_cast(f16, (uint16_t) rres); }
     };
     // request step `t` (a compile-time constant) of unit u into its slot, entries of its chunk first when it opens one
     auto issue_step = [&](const RingUnit& u, auto tc) {
         constexpr int t = decltype(tc)::value;
-        if constexpr (t % 4 == 0) issue_entries(u, t / 4);
+        if constexpr (GM != 0) issue_entries_gm(u, tc);
+        else if constexpr (t % 4 == 0) issue_entries(u, t / 4);
         const int rb = min(rb_lo + t, RB - 1);                        // clamped: always a valid address
         rg_ldw(ring[t % U], lane16, u.wbase + (size_t) (uint32_t) rb * 1024u);
     };
@@ -360,7 +390,8 @@ __global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 
         }
 
     // ---- 2. activation image --------------------------------------------------------------------------------------------------
-    rg_wait<ring_prologue_ops(U, UL, EL0, PRE)>();                   // everything older than the ring requests has landed
+    if constexpr (GM != 0) { if (tid < 4) zpad[tid] = make_uint4(0u, 0u, 0u, 0u); }
+    rg_wait<ring_prologue_ops(U, UL, EL0, PRE, GM != 0)>();          // everything older than the ring requests has landed
     RP_CLK(2);                                                       // activation landed
     if constexpr (ACT && EMODE == 2) {
 #pragma unroll
@@ -458,21 +489,36 @@ __global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 
         constexpr bool LAST = decltype(last_tag)::value;
         f32x4 c = {0.f, 0.f, 0.f, 0.f};
         const uint4* xr = ACT ? xrow + uc.mi * IMG_ROWS : xrow;      // act-order: the image gathered through this matrix' map
+        // GM: the A operand carries the activation in four masked rows -- lane (rsub, col) with col == 4 rsub reads its k-group, every other
+        // lane the zero pad (gemv_t16.h: t16_rowblock_groups); D[4 g][col] is then the exact-integer sum of k-group g for the lane that holds its scale
+        const bool live = col == 4 * rsub;
+        const uint4* xg = live ? xr : zpad;
+        const int xstep = live ? 16 : 0;
         static_for<0, UL>([&](auto lic) {
             constexpr int li = decltype(lic)::value;
-            rg_wait<ring_younger(U, UL, EL0, LAST, li)>(ring[li % U]);
-            if constexpr (li % 4 == 0) combine_entries(li / 4);
-            const uint32_t e = (uint32_t) __shfl((int) ent, ((li & 3) << 4) | col, 64);
+            rg_wait<ring_younger(U, UL, EL0, LAST, li, GM != 0)>(ring[li % U]);
+            uint32_t e;
+            if constexpr (GM != 0) {
+                rg_tie(rz[li % NRAW]); rg_tie(rs[li % NRAW]);
+                const uint32_t eg = (rs[li % NRAW] & 0xFFFFu) | ((0xE401u + ((rz[li % NRAW] >> (uint32_t) ((col & 7) * 4)) & 0xFu)) << 16);
+                e = rb_lo + li < rb_hi ? eg : 0u;                    // (uniform) rows past the wave's range: scale 0
+                if constexpr (EMODE == 1 && li == 0) { rg_tie(rres); res_cur = (float) __builtin_bit_cast(f16, (uint16_t) rres); }
+            } else {
+                if constexpr (li % 4 == 0) combine_entries(li / 4);
+                e = (uint32_t) __shfl((int) ent, ((li & 3) << 4) | col, 64);
+            }
             const uint4 w = make_uint4(ring[li % U][0], ring[li % U][1], ring[li % U][2], ring[li % U][3]);
 #ifdef EXL_RING_ABLATE                                               /* measurement builds: the loads without the arithmetic */
             c[0] += __uint_as_float((w.x ^ w.w) & 0x3fffffffu) + __uint_as_float(e & 0x3fffffffu);
 #else
-            t16_rowblock<true>(w, e, magic, xr + li * 16, c);
+            if constexpr (GM != 0) t16_rowblock_groups(w, e, magic, xg + li * xstep, c);
+            else t16_rowblock<true>(w, e, magic, xr + li * 16, c);
 #endif
             if constexpr (li + U < UL) issue_step(uc, std::integral_constant<int, li + U>{});
             else if constexpr (!LAST) issue_step(un, std::integral_constant<int, li % U>{});
         });
         float* rp = red + (i & 1) * NW * 16;
+        if constexpr (GM != 0) { c[0] += __shfl_xor(c[0], 16, 64); c[0] += __shfl_xor(c[0], 32, 64); }   // the four k-groups of a column (same order as dec_stream_kernel)
         const float res = res_cur;                                   // (the next unit's entries may already be on their way: res_cur is this unit's)
         const uint32_t perm = (i == 0 ? pr[0] : i == 1 ? pr[1] : i == 2 ? pr[2] : pr[3]) & 0xFFFFu;
         if (lane < 16) rp[wave * 16 + lane] = c[0];
@@ -517,21 +563,22 @@ __global__ __launch_bounds__(NW * 64, ((UL >= 24 && NW == 8) || PNORM == 3) ? 2 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------------------
-static size_t dec_ring_smem(int UL, int pnorm, int emode, int nv, int nw, int K)
+static size_t dec_ring_smem(int UL, int pnorm, int emode, int nv, int nw, int K, int gm = 0)
 {
+    if (gm) return dec_ring_smem(UL, pnorm, emode, nv, nw, K) + 64;
     const int wpt = emode == 2 ? nw / 2 : nw;
     const int rows = wpt * UL * 16 > nv * nw * 64 ? wpt * UL * 16 : nv * nw * 64;
     const int nimg = pnorm != 2 ? 1 : emode == 2 ? 2 : 3;
     return (size_t) nimg * rows * 16 + (2 * nw * 16 + nw) * sizeof(float) + (pnorm == 2 ? (size_t) K * 2 : 0);
 }
 
-template <int U, int UL, int PNORM, int EMODE, int NV, int NW>
+template <int U, int UL, int PNORM, int EMODE, int NV, int NW, int GM>
 static int ring_go(int grid, int rbw, const DecGemvArgs& a0, hipStream_t s, int* plan)
 {
     // (PRE < U -- part of the ring requested only after the activation image is staged -- measured within noise of PRE = U on
     // every 7B class, round 3: the template parameter stays, one value is instantiated)
-    auto kfn = dec_ring_kernel<U, UL, PNORM, EMODE, NV, NW, U>;
-    const size_t smem = dec_ring_smem(UL, PNORM, EMODE, NV, NW, a0.mat[0].K);
+    auto kfn = dec_ring_kernel<U, UL, PNORM, EMODE, NV, NW, U, GM>;
+    const size_t smem = dec_ring_smem(UL, PNORM, EMODE, NV, NW, a0.mat[0].K, GM);
     if (smem > 160 * 1024 / (NW == 8 ? 2 : 1) && PNORM == 2) return 1;   // two blocks per CU must fit: otherwise the compiler stream
     if (plan) {                                                      // exl_decoder_plan: [0] launched, [1] U, [2] UL, [3] 2 = ring kernel, [4] PNORM, [5] EMODE, [6] NV, [9] waves per block
         plan[0] = 1; plan[1] = U; plan[2] = UL; plan[3] = 2; plan[4] = PNORM; plan[5] = EMODE; plan[6] = NV;
@@ -553,9 +600,9 @@ static int ring_go(int grid, int rbw, const DecGemvArgs& a0, hipStream_t s, int*
 #ifdef EXL_DEC_FAST_BUILD                                            /* ISA inspection / experiment builds: the 7B shapes */
 #define RING_ULS(X) X(2) X(4) X(6) X(8) X(11)
 #else
-#define RING_ULS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(28) X(32)
+#define RING_ULS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(16) X(18) X(20) X(22) X(24) X(28) X(32)
 #endif
-template <int PNORM, int EMODE, int NV, int NW>
+template <int PNORM, int EMODE, int NV, int NW, int GM>
 static int ring_cfg(int depth, int rbw, int grid, const DecGemvArgs& a, hipStream_t s, int* plan)
 {
     constexpr int WPT = EMODE == 2 ? NW / 2 : NW;
@@ -568,9 +615,9 @@ static int ring_cfg(int depth, int rbw, int grid, const DecGemvArgs& a, hipStrea
     if constexpr (((ULV) >= RBW_LO && (ULV) <= RBW_HI) || ((ULV) <= 4 && RBW_LO <= 4 && (ULV) >= 2)) {                         \
         if (rbw > prev && rbw <= (ULV)) {                                                                                      \
             constexpr int UMAX = (ULV) < 4 ? (ULV) : 4;                                                                        \
-            if (depth <= 2) return ring_go<2, ULV, PNORM, EMODE, NV, NW>(grid, rbw, a, s, plan);                              \
-            if constexpr (UMAX >= 3 && ring_valid(3, ULV)) { if (depth == 3) return ring_go<3, ULV, PNORM, EMODE, NV, NW>(grid, rbw, a, s, plan); } \
-            return ring_go<UMAX, ULV, PNORM, EMODE, NV, NW>(grid, rbw, a, s, plan);                                            \
+            if (depth <= 2) return ring_go<2, ULV, PNORM, EMODE, NV, NW, GM>(grid, rbw, a, s, plan);                          \
+            if constexpr (UMAX >= 3 && ring_valid(3, ULV, GM != 0)) { if (depth == 3) return ring_go<3, ULV, PNORM, EMODE, NV, NW, GM>(grid, rbw, a, s, plan); } \
+            return ring_go<UMAX, ULV, PNORM, EMODE, NV, NW, GM>(grid, rbw, a, s, plan);                                        \
         }                                                                                                                      \
         prev = (ULV);                                                                                                          \
     }
@@ -581,7 +628,11 @@ static int ring_cfg(int depth, int rbw, int grid, const DecGemvArgs& a, hipStrea
 
 int launch_dec_ring(int pnorm, int emode, bool g16, int K, int grid, int depth, bool wide_blocks, const DecGemvArgs& a, hipStream_t s, int* plan)
 {
-    if (!g16) return 1;
+    const bool gm = !g16;                                            // group sizes 32 / 64: per-piece scale / zero pairs
+    if (gm) {
+        for (int i = 0; i < a.nmat && i < DEC_MAX_MATS; ++i)
+            if (a.mat[i].gshift != 2 && a.mat[i].gshift != 3) return 1;     // other group sizes: the compiler stream
+    }
     bool any_map = false, all_maps = true;
     for (int i = 0; i < a.nmat && i < DEC_MAX_MATS; ++i) { any_map = any_map || a.map16[i]; all_maps = all_maps && a.map16[i]; }
     if (any_map || a.out_perm) {
@@ -593,12 +644,25 @@ int launch_dec_ring(int pnorm, int emode, bool g16, int K, int grid, int depth, 
         pnorm = 2;
     }
     const int RB = K / 128;
-    const bool wide = wide_blocks && pnorm == 0 && emode == 1 && RB >= 32;   // 16 waves: at least two row-blocks per wave
+    const bool wide = wide_blocks && pnorm == 0 && emode == 1 && RB >= 32 && !gm;   // 16 waves: at least two row-blocks per wave
     const int nw = wide ? 16 : DEC_WAVES;
     const int wpt = emode == 2 ? nw / 2 : nw;
     const int rbw = (RB + wpt - 1) / wpt;
     const int nv = (K / 8 + nw * 64 - 1) / (nw * 64);
-#define RING_GO(P, E, N, W) return ring_cfg<P, E, N, W>(depth, rbw, grid, a, s, plan)
+#define RING_GO(P, E, N, W) return ring_cfg<P, E, N, W, 0>(depth, rbw, grid, a, s, plan)
+#define RING_GM(P, E, N) return ring_cfg<P, E, N, 8, 1>(depth, rbw, grid, a, s, plan)
+#ifndef EXL_DEC_FAST_BUILD
+    if (gm) {
+        if (pnorm == 1 && emode == 0) { if (nv <= 1) RING_GM(1, 0, 1); if (nv <= 2) RING_GM(1, 0, 2); }
+        if (pnorm == 1 && emode == 2) { if (nv <= 1) RING_GM(1, 2, 1); if (nv <= 2) RING_GM(1, 2, 2); }
+        if (pnorm == 2 && emode == 0) { if (nv <= 1) RING_GM(2, 0, 1); if (nv <= 2) RING_GM(2, 0, 2); }
+        if (pnorm == 2 && emode == 2) { if (nv <= 1) RING_GM(2, 2, 1); if (nv <= 2) RING_GM(2, 2, 2); }
+        if (pnorm == 0 && emode == 1) { if (nv <= 1) RING_GM(0, 1, 1); if (nv <= 2) RING_GM(0, 1, 2); if (nv <= 3) RING_GM(0, 1, 3); if (nv <= 6) RING_GM(0, 1, 6); }
+        return 1;
+    }
+#else
+    if (gm) return 1;
+#endif
 #ifdef EXL_DEC_FAST_BUILD
     if (pnorm == 1 && emode == 0 && nv == 1) RING_GO(1, 0, 1, 8);
     if (pnorm == 1 && emode == 2 && nv == 1) RING_GO(1, 2, 1, 8);
@@ -626,5 +690,6 @@ int launch_dec_ring(int pnorm, int emode, bool g16, int K, int grid, int depth, 
     }
 #endif
 #undef RING_GO
+#undef RING_GM
     return 1;
 }

@@ -474,7 +474,8 @@ _REAL_SHAPES = {
     # 13B act-order: q/k/v and gate/up gather one image per matrix through their maps (ring kernel, PNORM 2; gate/up also stores
     # through down_proj's inverse map); o_proj / down_proj get their input already in row order
     "13b": ("13b", 128, True, 1, (4, 5, 2, 2, 0, 2), (4, 5, 2, 0, 1, 2), (3, 10, 2, 2, 2, 2), (3, 14, 2, 0, 1, 6), True),
-    "33b": ("33b", 32, True, 1, (4, 2, 0, 1, 0, 2), (4, 2, 0, 0, 1, 2), (7, 2, 0, 1, 2, 2), (6, 3, 0, 0, 1, 6), True),
+    # 33B group size 32 act-order: the ring kernel's GM form (a scale / zero pair per lane and piece), gathers as for 13B
+    "33b": ("33b", 32, True, 1, (3, 7, 2, 2, 0, 2), (3, 7, 2, 0, 1, 2), (3, 13, 2, 2, 2, 2), (3, 18, 2, 0, 1, 6), True),
     "65b": ("65b", 128, False, 1, (3, 8, 2, 1, 0, 2), (3, 8, 2, 0, 1, 2), (3, 16, 2, 1, 2, 2), (3, 22, 2, 0, 1, 6), True),
     # Llama-2-70B: GQA (8 kv heads) and K = 28672 in down_proj -- 28 row-blocks per wave, 7 -> 8 vectors per thread
     "70b": ("70b", 128, False, 1, (3, 8, 2, 1, 0, 2), (3, 8, 2, 0, 1, 2), (3, 16, 2, 1, 2, 2), (3, 28, 2, 0, 1, 8), True),
@@ -588,12 +589,12 @@ def test_real_shape_prefill_end_to_end_vs_oracle():
     model.free_unmanaged()
 
 
-@pytest.mark.parametrize("key", ["7b", "13b", "65b", "70b"])
+@pytest.mark.parametrize("key", ["7b", "13b", "33b", "65b", "70b"])
 def test_ring_stream_equals_compiler_stream_bit_for_bit(key):
     """decode_ring.hip (every vector-memory instruction inline asm, every wait counted by hand) against dec_stream_kernel
     (ordinary loads, hipcc's waits) on the same decoder: same arithmetic in the same order, so the logits, the appended K/V
-    rows and the greedy tokens must be IDENTICAL bit patterns -- at the real layer shapes (7B; 13B act-order, where the ring
-    takes o_proj / down_proj only; 65B / 70B long units), over the ring's options (start-up barrier, depth 2 - 4), in the one-split and the many-split attention buckets, several tokens in a row (each step consumes
+    rows and the greedy tokens must be IDENTICAL bit patterns -- at the real layer shapes (7B; 13B act-order: gathered images and the permuted
+    gate/up store; 33B group size 32 act-order: a scale / zero pair per lane and piece; 65B / 70B long units), over the ring's options (start-up barrier, depth 2 - 4), in the one-split and the many-split attention buckets, several tokens in a row (each step consumes
     what the previous one wrote).  A miscounted wait shows up here as a different bit somewhere, not as a tolerance question.
     (16-wave blocks split K differently: those runs are held to fp32-reordering noise instead.)"""
     import ctypes as C
