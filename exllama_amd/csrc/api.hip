@@ -512,12 +512,22 @@ extern "C" int exl_q4_attn(int device, const void* x, const void* rms_norm_weigh
     f16* temp_x = bufs->temp_state;                              // [rows, dim]
     f16* remap_tmp = bufs->temp_state + (size_t) rows * dim;     // act-order gather scratch for the GEMM path
     const size_t remap_numel = bufs->temp_state_numel - (size_t) rows * dim;
-    EXL_TRY(launch_rms_norm((const f16*) x, (const f16*) rms_norm_weight, temp_x, epsilon, rows, dim, s));
+    bool fused = false;
+    if (rows == 1 && !(q_a && q_rank > 0) && !(k_a && k_rank > 0) && !(v_a && v_rank > 0)) {
+        // one token, no adapter: RMSNorm + q / k / v as ONE launch of the decode executor's kernel (decode_fused.hip: dec_op_gemv)
+        Q4Matrix* mats[3] = {qm, km, vm};
+        f16* outs[3] = {(f16*) query_states, (f16*) key_states, (f16*) value_states};
+        const int r = dec_op_gemv(device, 0, 1, 0, (const f16*) x, (const f16*) rms_norm_weight, epsilon, 3, mats, outs, nullptr, s);
+        if (r > 1) return r;
+        fused = r == 0;
+    }
+    if (!fused) EXL_TRY(launch_rms_norm((const f16*) x, (const f16*) rms_norm_weight, temp_x, epsilon, rows, dim, s));
 
     struct Proj { Q4Matrix* m; void* out; const void* a; const void* b; int rank; };
     const Proj projs[3] = {{qm, query_states, q_a, q_b, q_rank}, {km, key_states, k_a, k_b, k_rank},
                            {vm, value_states, v_a, v_b, v_rank}};
     for (const Proj& p : projs) {
+        if (fused) break;
         int no_zero = 0;
         if (p.a && p.b && p.rank > 0) {
             EXL_REQUIRE(lora_temp, EXL_E_INVALID, "q4_attn: lora_temp missing");
@@ -528,12 +538,10 @@ extern "C" int exl_q4_attn(int device, const void* x, const void* rms_norm_weigh
         if (rows <= 8) EXL_TRY(q4_gemv(p.m, temp_x, rows, p.out, no_zero, s));
         else           EXL_TRY(q4_gemm(p.m, temp_x, rows, p.out, no_zero, remap_tmp, remap_numel, s));
     }
-    EXL_TRY(launch_rope((f16*) query_states, (const f16*) sin, (const f16*) cos, bsz, q_len * num_heads, head_dim,
-                        num_heads, past_len, past_len_dev, s));
-    EXL_TRY(launch_rope((f16*) key_states, (const f16*) sin, (const f16*) cos, bsz, q_len * num_kv_heads, head_dim,
-                        num_kv_heads, past_len, past_len_dev, s));
-    return launch_update_cache((const f16*) key_states, (const f16*) value_states, (f16*) key_cache, (f16*) value_cache,
-                               bsz, q_len, num_kv_heads, head_dim, max_seq_len, past_len, past_len_dev, s);
+    // RoPE on q, RoPE on k, K / V rows into the cache: one launch (three in the reference, q4_attn.cu:160-204)
+    return launch_rope_qk_cache((f16*) query_states, (f16*) key_states, (const f16*) value_states, (f16*) key_cache, (f16*) value_cache,
+                                (const f16*) sin, (const f16*) cos, bsz, q_len, num_heads, num_kv_heads, head_dim, max_seq_len,
+                                past_len, past_len_dev, s);
 }
 
 extern "C" int exl_q4_attn_2(void* x, const void* attn_output, void* o_proj, int height, const void* o_a,
@@ -549,6 +557,11 @@ extern "C" int exl_q4_attn_2(void* x, const void* attn_output, void* o_proj, int
         EXL_REQUIRE(lora_temp, EXL_E_INVALID, "q4_attn_2: lora_temp missing");
         EXL_TRY(launch_half_gemm((const f16*) attn_output, (const f16*) o_a, (f16*) lora_temp, height, om->height, o_rank, 0, s));
         EXL_TRY(launch_half_gemm((const f16*) lora_temp, (const f16*) o_b, (f16*) x, height, o_rank, om->width, 1, s));
+    }
+    if (height == 1 && !(o_a && o_b && o_rank > 0)) {             // one token, no adapter: o_proj + residual through the executor's kernel
+        Q4Matrix* mats[1] = {om};
+        const int r = dec_op_gemv(om->device, 1, 0, 1, (const f16*) attn_output, nullptr, 0.f, 1, mats, nullptr, (f16*) x, s);
+        if (r != 1) return r;
     }
     if (height <= 8) return q4_gemv(om, attn_output, height, x, 1, s);
     return q4_gemm(om, attn_output, height, x, 1, bufs->temp_state, bufs->temp_state_numel, s);
@@ -581,6 +594,19 @@ extern "C" int exl_q4_mlp(int device, void* x, const void* rms_norm_weight, floa
     const size_t remap_numel = bufs->temp_state_numel - (size_t) height * dim;
     f16* t0 = bufs->temp_mlp;
     f16* t1 = bufs->temp_mlp + (size_t) height * inter;
+    if (height == 1 && !(gate_a && gate_rank > 0) && !(up_a && up_rank > 0) && !(down_a && down_rank > 0)) {
+        // one token, no adapter: RMSNorm + gate / up + SiLU in one launch, down_proj + residual in the next (the executor's kernels)
+        Q4Matrix* gu[2] = {gm, um};
+        f16* outs[1] = {t0};
+        const int r = dec_op_gemv(device, 2, 1, 2, (const f16*) x, (const f16*) rms_norm_weight, epsilon, 2, gu, outs, nullptr, s);
+        if (r > 1) return r;
+        if (r == 0) {
+            Q4Matrix* dn[1] = {dm};
+            const int r2 = dec_op_gemv(device, 3, 0, 1, t0, nullptr, 0.f, 1, dn, nullptr, (f16*) x, s);
+            if (r2 != 1) return r2;
+            return q4_gemv(dm, t0, height, x, 1, s);                 // (down_proj alone not covered: its own GEMV on the fused activation)
+        }
+    }
     EXL_TRY(launch_rms_norm((const f16*) x, (const f16*) rms_norm_weight, temp_x, epsilon, height, dim, s));
 
     int gz = 0, uz = 0;

@@ -118,9 +118,14 @@ int launch_dec_sample(float* logits, float* probs, int64_t* history, int64_t* to
 int launch_embedding(const int64_t* ids, const f16* table, f16* out, int n_ids, int hidden, int vocab, hipStream_t s);
 int launch_head_rows(const f16* x, const f16* w, float* out, int rows, int hidden, int vocab, hipStream_t s);   // 1 = not covered
 int launch_rms_norm(const f16* x, const f16* w, f16* out, float eps, int rows, int dim, hipStream_t s);
+// decode_fused.hip: one fused executor launch for the op-level entry points (0 done, 1 not covered, > 1 error)
+int dec_op_gemv(int device, int cls, int pnorm, int emode, const f16* vec, const f16* norm_w, float eps, int nmat,
+                Q4Matrix* const* mats, f16* const* outs, f16* hid_io, hipStream_t s);
 int launch_rope(f16* x, const f16* sin, const f16* cos, int bsz, int rows_per_batch, int head_dim, int num_heads,
                 int past_len, const int32_t* past_len_dev, hipStream_t s);
 int launch_silu_mul(f16* x, const f16* y, int height, int width, hipStream_t s);
+int launch_rope_qk_cache(f16* q, f16* k, const f16* v, f16* kc, f16* vc, const f16* sin, const f16* cos, int bsz, int q_len,
+                         int heads, int kvh, int hd, int max_seq, int past_len, const int32_t* past_len_dev, hipStream_t s);
 int launch_update_cache(const f16* k, const f16* v, f16* kc, f16* vc, int bsz, int q_len, int kvh, int hd,
                         int max_seq, int past_len, const int32_t* past_len_dev, hipStream_t s);
 int launch_attention(const f16* q, const f16* kc, const f16* vc, f16* out, const f16* mask, int bsz, int q_len,

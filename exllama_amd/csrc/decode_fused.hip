@@ -1187,6 +1187,47 @@ static int launch_dec_gemv(const Decoder* dcfg, int cls, int pnorm, int emode, c
     EXL_FAIL(EXL_E_INVALID, "decoder: unsupported kernel combination");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The executor's fused GEMV launches behind the reference's fused OPS (api.hip: exl_q4_attn / exl_q4_attn_2 / exl_q4_mlp with one
+// row and no LoRA -- what the reference's unmodified model.py calls per token and layer, model.py:254-289): RMSNorm + q / k / v in
+// one launch, o_proj + residual in one, RMSNorm + gate / up + SiLU in one, down_proj + residual in one -- 4 launches where the
+// op-by-op form needs 11 (norm, three GEMVs, ..., norm, two GEMVs, SiLU, GEMV).  Returns 1 when the shapes are not covered
+// (act-order without the executor's 16-bit maps, a layout other than T16, K beyond the kernel classes): the caller keeps its path.
+// ---------------------------------------------------------------------------------------------------------------------------
+int dec_op_gemv(int device, int cls, int pnorm, int emode, const f16* vec, const f16* norm_w, float eps, int nmat,   // cls: ring class bit (0 q/k/v, 1 o_proj, 2 gate/up, 3 down_proj)
+                Q4Matrix* const* mats, f16* const* outs, f16* hid_io, hipStream_t s)
+{
+    static Decoder cfg[EXL_MAX_DEVICES];
+    static bool ready[EXL_MAX_DEVICES] = {};
+    if (device < 0 || device >= EXL_MAX_DEVICES) return 1;
+    static const bool off = getenv("EXL_OPS_UNFUSED") != nullptr;    // A/B switch: the op-by-op launches
+    if (off) return 1;
+    if (!ready[device]) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 1;
+        Decoder& d = cfg[device];
+        d.device = device;
+        d.ring = getenv("EXL_DEC_RING") ? atoi(getenv("EXL_DEC_RING")) : 15;
+        d.ring_fence = getenv("EXL_DEC_RING_FENCE") ? atoi(getenv("EXL_DEC_RING_FENCE")) : 1;
+        d.ring_depth = getenv("EXL_DEC_RING_DEPTH") ? atoi(getenv("EXL_DEC_RING_DEPTH")) : 3;
+        d.ring_wide = getenv("EXL_DEC_RING_WIDE") ? atoi(getenv("EXL_DEC_RING_WIDE")) : 1;
+        d.max_blocks = (cus > 0 ? cus : 256) * 2;
+        ready[device] = true;
+    }
+    const int K = mats[0]->height;
+    if (K % 128 != 0 || K >= 65536) return 1;
+    const int wpt = emode == 2 ? DEC_WAVES / 2 : DEC_WAVES;
+    const int rbw = (K / 128 + wpt - 1) / wpt;
+    const int nv = (K / 8 + DEC_THREADS - 1) / DEC_THREADS;
+    if (rbw > (pnorm == 0 && emode == 1 ? 36 : 24) || nv > (pnorm == 0 ? 8 : 2)) return 1;
+    for (int i = 0; i < nmat; ++i) {
+        const Q4Matrix* m = mats[i];
+        if (m->device != device || m->layout != EXL_LAYOUT_T16 || m->x_map != nullptr || m->height != K || m->width % 16 != 0) return 1;
+        if (m->groupsize % 32 != 0 || (m->groupsize % 128 == 0) != (mats[0]->groupsize % 128 == 0)) return 1;
+    }
+    return launch_dec_gemv(&cfg[device], cls, pnorm, emode, vec, nullptr, norm_w, eps, nullptr, nmat, mats, outs, hid_io, s);
+}
+
 // The split merge rides in the o_proj prologue when a thread owns ONE 8-dim vector of the attention output (hidden <= 4096:
 // 16 split loads = 64 registers); wider models keep it as its own kernel (with 2+ vectors per thread hipcc keeps every
 // vector's loads live and o_proj, which needs two blocks per CU from hidden 5120 on, drops to one; a rolled loop under a

@@ -190,6 +190,72 @@ __global__ __launch_bounds__(256) void update_cache_kernel(const f16* __restrict
     *(uint4*) (vc + dst) = *(const uint4*) (v + src);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// q4_attn's tail in ONE launch (reference: rope_cuda on q, rope_cuda on k, update_cache_kernel; q4_attn.cu:160-204): RoPE on
+// the q heads in place, RoPE on the k heads in place AND into the cache row, v into the cache row.  One thread = the 8 + 8
+// paired columns of one head of one token; same arithmetic as rope_kernel, same bytes as update_cache_kernel.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_qk_cache_kernel(f16* __restrict__ q, f16* __restrict__ k, const f16* __restrict__ v,
+                                                            f16* __restrict__ kc, f16* __restrict__ vc,
+                                                            const f16* __restrict__ sin, const f16* __restrict__ cos, int q_len,
+                                                            int heads, int kvh, int hd, int max_seq, int past_len,
+                                                            const int32_t* __restrict__ past_len_dev, long total)
+{
+    const long gid = (long) blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int vec_per_row = hd >> 4;
+    const int vv = (int) (gid % vec_per_row);
+    long rest = gid / vec_per_row;
+    const int slot = (int) (rest % (heads + kvh)); rest /= (heads + kvh);
+    const int t = (int) (rest % q_len);
+    const int b = (int) (rest / q_len);
+    const int past = past_len_dev ? *past_len_dev : past_len;
+    const int pos = past + t;
+    const int hd2 = hd >> 1;
+    const bool is_k = slot >= heads;
+    const int h = is_k ? slot - heads : slot;
+    f16* xp = (is_k ? k + (((size_t) b * q_len + t) * kvh + h) * hd : q + (((size_t) b * q_len + t) * heads + h) * hd) + vv * 8;
+    const f16* sp = sin + (size_t) pos * hd + vv * 8;
+    const f16* cp = cos + (size_t) pos * hd + vv * 8;
+    const f16x8 l = *(const f16x8*) xp;
+    const f16x8 r = *(const f16x8*) (xp + hd2);
+    const f16x8 sl = *(const f16x8*) sp;
+    const f16x8 sr = *(const f16x8*) (sp + hd2);
+    const f16x8 cl = *(const f16x8*) cp;
+    const f16x8 cr = *(const f16x8*) (cp + hd2);
+    f16x8 nl, nr;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const f16 ls = r[j] * (-sl[j]);
+        const f16 rs = l[j] * sr[j];
+        nl[j] = __builtin_fmaf16(l[j], cl[j], ls);
+        nr[j] = __builtin_fmaf16(r[j], cr[j], rs);
+    }
+    *(f16x8*) xp = nl;
+    *(f16x8*) (xp + hd2) = nr;
+    if (is_k) {
+        const size_t src = (((size_t) b * q_len + t) * kvh + h) * hd + vv * 8;
+        const size_t dst = (((size_t) b * kvh + h) * max_seq + pos) * hd + vv * 8;
+        *(f16x8*) (kc + dst) = nl;
+        *(f16x8*) (kc + dst + hd2) = nr;
+        *(uint4*) (vc + dst) = *(const uint4*) (v + src);
+        *(uint4*) (vc + dst + hd2) = *(const uint4*) (v + src + hd2);
+    }
+}
+
+int launch_rope_qk_cache(f16* q, f16* k, const f16* v, f16* kc, f16* vc, const f16* sin, const f16* cos, int bsz, int q_len,
+                         int heads, int kvh, int hd, int max_seq, int past_len, const int32_t* past_len_dev, hipStream_t s)
+{
+    EXL_REQUIRE(hd % 16 == 0, EXL_E_UNSUPPORTED, "rope: head_dim (%d) must be a multiple of 16", hd);
+    EXL_REQUIRE(heads > 0 && kvh > 0, EXL_E_INVALID, "rope: num_heads must be > 0");
+    const long total = (long) bsz * q_len * (heads + kvh) * (hd / 16);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(rope_qk_cache_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, s, q, k, v, kc, vc, sin, cos,
+                       q_len, heads, kvh, hd, max_seq, past_len, past_len_dev, total);
+    EXL_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_update_cache(const f16* k, const f16* v, f16* kc, f16* vc, int bsz, int q_len, int kvh, int hd,
                         int max_seq, int past_len, const int32_t* past_len_dev, hipStream_t s)
 {

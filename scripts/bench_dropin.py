@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--length", type=int, default=2048)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--profile", default=None, help="write a cProfile listing of 64 more decode steps (host time by function) to this file")
     args = ap.parse_args()
     archive = os.path.join(ROOT, "oracle", "_ref", "refpy.tgz")
     if not os.path.exists(archive):
@@ -88,6 +89,20 @@ def main():
     if args.out:
         with open(args.out, "w") as f:
             json.dump(out, f, indent=1)
+    if args.profile:                                           # where the HOST time of a token goes (the path is host-bound)
+        import cProfile, io, pstats
+        pr = cProfile.Profile()
+        sync()
+        pr.enable()
+        for _ in range(64):
+            token = torch.argmax(logits[0, -1, :])
+            logits = model.forward(token.view(1, 1), cache, True)
+        sync()
+        pr.disable()
+        buf = io.StringIO()
+        pstats.Stats(pr, stream=buf).sort_stats("tottime").print_stats(30)
+        with open(args.profile, "w") as f:
+            f.write(buf.getvalue())
     model.free_unmanaged()
 
 
