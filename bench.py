@@ -144,9 +144,11 @@ def layer_split_main(args, dims, L, S, G, rank, world, dev, dist):
     mean = lambda v: sum(v) / len(v)
     pre = mean([e[0].elapsed_time(e[1]) for e in events])
     dec = mean([e[1].elapsed_time(e[2]) for e in events])
+    ranks = per_rank_report([elapsed * 1e3 / args.steps, pre, dec / G], dist, dev, ("ms_per_step", "prefill_ms", "decode_ms_per_token"))
     elapsed, pre, dec = reduce_over_ranks([elapsed, pre, dec], dist, dev)
     if rank == 0:
         print(json.dumps({
+            **ranks,
             "metric": "single-token decode tokens/s at full context (prefill tokens/s alongside), Llama GPTQ 4-bit",
             "value": round(G / (dec / 1e3), 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -197,9 +199,13 @@ def tensor_parallel_main(args, dims, L, S, G, rank, world, dev, dist):
         e[0].record()
         logits = model.forward(ids, cache)
         e[1].record()
-        for _ in range(G):
-            tok = logits[0, -1].argmax().view(1, 1)               # identical logits on every rank: no token broadcast needed
-            logits = model.forward(tok, cache)
+        tok = logits[0, -1].argmax().view(1, 1)                   # identical logits on every rank: no token broadcast needed
+        if model._decoder is not None:
+            model.generate_greedy(tok, cache, G)                   # every rank picks its own (identical) tokens on the device
+        else:
+            for _ in range(G):
+                logits = model.forward(tok, cache)
+                tok = logits[0, -1].argmax().view(1, 1)
         e[2].record()
         if record is not None:
             record.append(e)
@@ -222,12 +228,14 @@ def tensor_parallel_main(args, dims, L, S, G, rank, world, dev, dist):
     mean = lambda v: sum(v) / len(v)
     pre = mean([e[0].elapsed_time(e[1]) for e in events])
     dec = mean([e[1].elapsed_time(e[2]) for e in events])
+    ranks = per_rank_report([elapsed * 1e3 / args.steps, pre, dec / G], dist, dev, ("ms_per_step", "prefill_ms", "decode_ms_per_token"))
     elapsed, pre, dec = reduce_over_ranks([elapsed, pre, dec], dist, dev)
     if rank == 0:
         st = model._decoder
         mode = ("op-by-op path (act-order o_proj / down_proj shards: gather mode)" if gather_mode else
                 "native executor in half-layer pieces, " + ("captured in one hipGraph per token" if (st and st["graph"] is not None) else "eager launches"))
         print(json.dumps({
+            **ranks,
             "metric": "single-token decode tokens/s at full context (prefill tokens/s alongside), Llama GPTQ 4-bit",
             "value": round(G / (dec / 1e3), 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -264,6 +272,24 @@ def device_state():
         return keep
     except Exception as e:                                            # noqa: BLE001
         return {"unavailable": str(e)[:120]}
+
+
+def per_rank_report(local_values, dist, device, names):
+    """What every rank measured, gathered on all ranks (rank 0 prints it): the multi-GPU modes report the communicator they ran on
+    (`rccl_ranks`) and each rank's own timings next to the MAX the contract asks for, so one command on an N-GPU node yields the
+    whole picture (a slow rank, a slow link)."""
+    t = torch.tensor(list(local_values), dtype=torch.float64, device=device)
+    if dist is None:
+        rows = [t.tolist()]
+        info = {"rccl_ranks": 0, "backend": None}
+    else:
+        out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, t)
+        rows = [o.tolist() for o in out]
+        info = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}
+    info["per_rank"] = [{"rank": r, **{n: round(v, 3) for n, v in zip(names, row)}} for r, row in enumerate(rows)]
+    info["device"] = torch.cuda.get_device_name(device)
+    return info
 
 
 def reduce_over_ranks(local_values, dist, device):

@@ -936,10 +936,8 @@ class ExLlama:
         leaves the last step's logits in the executor's buffer (self.last_decoder_logits()).  Needs
         enable_decode_graph(cache, use_graph=True) on a model that sits on one device."""
         st = self._decoder
-        if st is None or st["cache"] is not cache or st["graph"] is None:
+        if st is None or st["cache"] is not cache or (st["graph"] is None and self.config.tp is None):
             raise RuntimeError("generate_greedy needs enable_decode_graph(cache) with graph replay")
-        if self.config.tp is not None:
-            raise RuntimeError("generate_greedy / generate_sample: not available on a tensor-parallel shard (use forward())")
         if len(st["stages"]) != 1 or not (st["has_embed"] and st["has_head"]):
             raise RuntimeError("generate_greedy needs the whole model in one executor stage (one device)")
         self._check_cache_storage(st, cache)
@@ -948,6 +946,9 @@ class ExLlama:
             raise RuntimeError(f"sequence ({start} + {num_tokens}) exceeds the cache length {cache.max_seq_len}")
         if "history" not in st:                                      # shared with generate_sample, whichever runs first
             st["history"] = torch.zeros((cache.max_seq_len + 1,), dtype=torch.int64, device=st["dev"])
+        if self.config.tp is not None:
+            st["tok"].copy_(first_token.view(1, 1), non_blocking=True)
+            return self._generate_tp(st, cache, num_tokens)
         if "ggraphs" not in st:
             st["ggraphs"] = []
             torch.cuda.synchronize(st["dev"])
@@ -989,10 +990,8 @@ class ExLlama:
         from ._lib import ExlSampler
         import ctypes as C
         st = self._decoder
-        if st is None or st["cache"] is not cache or st["graph"] is None:
+        if st is None or st["cache"] is not cache or (st["graph"] is None and self.config.tp is None):
             raise RuntimeError("generate_sample needs enable_decode_graph(cache) with graph replay")
-        if self.config.tp is not None:
-            raise RuntimeError("generate_greedy / generate_sample: not available on a tensor-parallel shard (use forward())")
         if len(st["stages"]) != 1 or not (st["has_embed"] and st["has_head"]):
             raise RuntimeError("generate_sample needs the whole model in one executor stage (one device)")
         self._check_cache_storage(st, cache)
@@ -1006,6 +1005,9 @@ class ExLlama:
         if "history" not in st:
             st["history"] = torch.zeros((cache.max_seq_len + 1,), dtype=torch.int64, device=st["dev"])
         st["history"][:start + 1].copy_(seq)
+        if self.config.tp is not None:
+            st["tok"].copy_(seq[-1:].view(1, 1), non_blocking=True)
+            return self._generate_tp(st, cache, num_tokens, settings=settings, uniforms=uniforms)
         key = (bytes(settings), None if uniforms is None else uniforms.data_ptr())
         if st.get("sgraphs_key") != key:                             # the settings are kernel arguments: one set of graphs per setting
             st["sgraphs"], st["sgraphs_key"], st["sampler"], st["uniforms"] = [], key, settings, uniforms
@@ -1037,6 +1039,33 @@ class ExLlama:
         cache.current_seq_len = start + num_tokens
         st["dev_pos"] = cache.current_seq_len
         return st["history"][start + 1:start + num_tokens + 1].clone()
+
+    def _generate_tp(self, st, cache, num_tokens, settings=None, uniforms=None):
+        """Token loop of ONE RANK of a tensor-parallel model (reference for the single-process form: generate_greedy / generate_sample).
+        Every rank ends a step with the same all-gathered fp32 logits (bit-identical: tests/test_tp_gpu.py), so every rank picks the
+        token itself -- torch.argmax, or the sampler kernel (csrc/sampler.hip) with the same settings and the same draw per position
+        (Philox(seed, position) or the caller's `uniforms`) -- and no token travels between ranks.  The loop is sequenced by the host
+        (the collectives sit between the kernels of a step) but never synchronises with the device: the token stays there."""
+        import ctypes as C
+        start = cache.current_seq_len
+        lib = ext._lib
+        if settings is not None and "probs" not in st:
+            st["probs"] = torch.empty((self.config.vocab_size,), dtype=torch.float32, device=st["dev"])
+        hist = st["history"]
+        for i in range(num_tokens):
+            self._run_token(st, cache)                               # advances cache.current_seq_len and the device-side position
+            p = start + i + 1                                         # position of the token chosen now
+            if settings is None:
+                tok = st["logits"].view(-1).argmax()
+                hist[p] = tok
+                st["tok"].copy_(tok.view(1, 1))
+            else:
+                with cuda_ext._Guard(st["dev"]):
+                    cuda_ext.check(lib.exl_sample(st["dev"].index, st["logits"].data_ptr(), st["probs"].data_ptr(), self.config.vocab_size,
+                                                  hist.data_ptr(), st["tok"].data_ptr(), st["stages"][0]["pos"].data_ptr(),
+                                                  None if uniforms is None else uniforms.data_ptr(), None, C.byref(settings),
+                                                  torch.cuda.current_stream(st["dev"]).cuda_stream), "sample")
+        return hist[start + 1:start + num_tokens + 1].clone()
 
     def last_decoder_logits(self):
         """fp32 logits [1, 1, vocab] of the most recent executor step (a copy)."""

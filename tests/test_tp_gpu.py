@@ -95,3 +95,56 @@ def test_tensor_parallel_ranks_reproduce_the_unsharded_model(preset, layers, gs,
     for r in range(1, world):                                            # the replicas of the residual stream agree exactly
         for a, b in zip(rank_outs[r], rank_outs[0]):
             assert torch.equal(a, b)
+
+
+def test_generation_on_tensor_parallel_ranks():
+    """generate_greedy / generate_sample on the ranks of a tensor-parallel model: every rank picks the token itself from the
+    all-gathered logits (argmax, or the sampler kernel with the same draw per position), so the ranks must produce IDENTICAL token
+    streams without exchanging a token -- and the stream of the unsharded model, except where that model's own top-2 margin is
+    inside the tolerance the sharded logits are held to (then the first such step is where the comparison ends)."""
+    from exllama_amd import _lib
+    dims = synth.PRESETS["tiny_hd128"]
+    layers, world, n = 3, 2, 10
+    cfg_dict = synth.config_dict(dims, num_layers=layers)
+    tensors = synth.make_checkpoint(dims, groupsize=128, act_order=False, seed=19, num_layers=layers)
+    prompt = torch.randint(3, dims.vocab_size, (1, 29), generator=torch.Generator().manual_seed(8))
+    settings = _lib.ExlSampler(temperature=0.9, top_k=40, top_p=0.8, rep_penalty_max=1.15, rep_sustain=16, rep_decay=8)
+    uniforms = torch.rand(257, generator=torch.Generator().manual_seed(3)).to(DEV)
+
+    def program(tpobj_for, local_tensors, cfgd):
+        def run():
+            model, cache = _build(cfgd, local_tensors, tpobj_for)
+            keep.append((model, cache))
+            model.forward(prompt[:, :-1].to(DEV), cache, preprocess_only=True)
+            model.enable_decode_graph(cache, use_graph=tpobj_for is None)
+            # greedy, with the logits of every step kept for the margin rule
+            c = cache.current_seq_len
+            greedy = model.generate_greedy(prompt[:, -1:].to(DEV), cache, n).cpu().tolist()
+            cache.current_seq_len = c                                       # rewind: the same positions again, sampled
+            sampled = model.generate_sample(prompt.to(DEV), cache, n, settings=settings, uniforms=uniforms).cpu().tolist()
+            cache.current_seq_len = c
+            steps, tok = [], prompt[:, -1:].to(DEV)
+            for t in greedy:                                                # teacher-forced logits of the greedy stream
+                lg = model.forward(tok, cache).float().cpu()[0, -1]
+                steps.append(lg)
+                tok = torch.tensor([[t]], device=DEV)
+            return greedy, sampled, steps
+        return run
+
+    keep = []
+    full_greedy, full_sampled, full_steps = program(None, tensors, cfg_dict)()
+    group = LocalGroup(world)
+    progs = []
+    for r in range(world):
+        local, plan = tp.shard_tensors(tensors, cfg_dict, r, world)
+        progs.append(program(tp.TensorParallel(plan, group.comm(r)), local, tp.shard_config_dict(cfg_dict, plan)))
+    outs = group.run(progs)
+    keep[0][0].free_unmanaged()
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1], "the ranks of one model disagree on a token"
+    assert len(set(outs[0][0])) > 1
+    for got, want, what in ((outs[0][0], full_greedy, "greedy"),):
+        for i, (a, b) in enumerate(zip(got, want)):
+            if a != b:                                                       # allowed only at a near-tie of the unsharded model
+                lg = full_steps[i]
+                assert float(lg[b] - lg[a]) <= 1.2e-2 * float(lg.abs().max()), (what, i, a, b)
+                break
