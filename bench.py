@@ -146,8 +146,9 @@ def layer_split_main(args, dims, L, S, G, rank, world, dev, dist):
     dec = mean([e[1].elapsed_time(e[2]) for e in events])
     ranks = per_rank_report([elapsed * 1e3 / args.steps, pre, dec / G], dist, dev, ("ms_per_step", "prefill_ms", "decode_ms_per_token"))
     elapsed, pre, dec = reduce_over_ranks([elapsed, pre, dec], dist, dev)
+    line = None
     if rank == 0:
-        print(json.dumps({
+        line = json.dumps(dict(**{
             **ranks,
             "metric": "single-token decode tokens/s at full context (prefill tokens/s alongside), Llama GPTQ 4-bit",
             "value": round(G / (dec / 1e3), 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -163,6 +164,8 @@ def layer_split_main(args, dims, L, S, G, rank, world, dev, dist):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None:                                           # the contract's ONE JSON line is the last thing on stdout (RCCL prints its
+        print(line, flush=True)                                    # version banner there when the communicator goes, if NCCL_DEBUG asks for it)
 
 
 def tensor_parallel_main(args, dims, L, S, G, rank, world, dev, dist):
@@ -230,11 +233,12 @@ def tensor_parallel_main(args, dims, L, S, G, rank, world, dev, dist):
     dec = mean([e[1].elapsed_time(e[2]) for e in events])
     ranks = per_rank_report([elapsed * 1e3 / args.steps, pre, dec / G], dist, dev, ("ms_per_step", "prefill_ms", "decode_ms_per_token"))
     elapsed, pre, dec = reduce_over_ranks([elapsed, pre, dec], dist, dev)
+    line = None
     if rank == 0:
         st = model._decoder
         mode = ("op-by-op path (act-order o_proj / down_proj shards: gather mode)" if gather_mode else
                 "native executor in half-layer pieces, " + ("captured in one hipGraph per token" if (st and st["graph"] is not None) else "eager launches"))
-        print(json.dumps({
+        line = json.dumps(dict(**{
             **ranks,
             "metric": "single-token decode tokens/s at full context (prefill tokens/s alongside), Llama GPTQ 4-bit",
             "value": round(G / (dec / 1e3), 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -250,6 +254,8 @@ def tensor_parallel_main(args, dims, L, S, G, rank, world, dev, dist):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None:                                           # the contract's ONE JSON line is the last thing on stdout (RCCL prints its
+        print(line, flush=True)                                    # version banner there when the communicator goes, if NCCL_DEBUG asks for it)
 
 
 def device_state():
@@ -511,11 +517,11 @@ def main():
         except Exception:
             pass
 
-    if rank == 0:
-        print(json.dumps(result))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:                                                  # the ONE JSON line last (after RCCL's teardown output, if any)
+        print(json.dumps(result), flush=True)
 
 
 def decoder_roofline_probe(model, cache, dims, g, ctx, steps=6):
