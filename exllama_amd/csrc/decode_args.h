@@ -97,6 +97,20 @@ __device__ __forceinline__ float dec_row_max(float v)
     return v;
 }
 __device__ __forceinline__ float dec_lane(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
+// v + (the same lane of the other 16-lane row of its pair) and then + (the other half of the wave): gfx950's v_permlane16_swap /
+// v_permlane32_swap on the vector ALU instead of two ds_bpermute round trips.  Association per lane l < 16: (v_l + v_l+16) + (v_l+32 + v_l+48).
+__device__ __forceinline__ float dec_rows_sum(float v)               // every lane: sum over the 4 lanes with its (lane % 16)
+{
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float s = __builtin_bit_cast(float, (unsigned) a[0]) + __builtin_bit_cast(float, (unsigned) a[1]);
+    const unsigned w = __builtin_bit_cast(unsigned, s);
+    const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __builtin_bit_cast(float, (unsigned) b[0]) + __builtin_bit_cast(float, (unsigned) b[1]);
+}
+// block barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its outstanding global loads (__syncthreads
+// drains vmcnt as well, which parks a wave until every row it has requested is back)
+__device__ __forceinline__ void dec_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ float dec_wave_sum(float v)               // sum over the 64 lanes, wave-uniform
 {
     v = dec_row_sum(v);

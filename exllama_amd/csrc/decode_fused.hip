@@ -436,8 +436,11 @@ __device__ unsigned long long g_attn_probe[512 * 8];                // [block][p
 // NW = waves per block (EXL_DEC_ATTN_WAVES): 4 -> 16 key rows per step, 10 rows per thread and chunk, 5 in flight;
 //                                            8 -> 32 key rows per step,  5 rows per thread and chunk, all 5 K rows in flight
 // (twice the waves per CU at the same bytes in flight per thread).
-template <bool SHORT, int NW>
-__global__ __launch_bounds__(NW * 64) void dec_attn_kernel(const f16* __restrict__ q, const f16* __restrict__ k_new,
+// The one-split bucket (context <= 160; the benchmark's "best case" runs here): round 2's kernel, unchanged.  The chunked form
+// below measured 0.3 us slower per launch here and 35 us per token slower inside the graph (same box, A/B of the two libraries:
+// 806 -> 773 tokens/s at context 4), where there is nothing to speculate on and one split to balance.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void dec_attn_short_kernel(const f16* __restrict__ q, const f16* __restrict__ k_new,
                                                        const f16* __restrict__ v_new, f16* __restrict__ kc,
                                                        f16* __restrict__ vc, const f16* __restrict__ sin,
                                                        const f16* __restrict__ cos, float* __restrict__ partial,
@@ -445,6 +448,7 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(const f16* __restrict
                                                        int max_seq, int nsplit, float scale, f16* __restrict__ direct_out,
                                                        const uint16_t* __restrict__ out_perm)
 {
+    constexpr bool SHORT = true;
     constexpr int HD = 128, LPK = 16, KPI = NW * 4, UN = DEC_ATT_CHUNK / 16, NT = NW * 64;   // 10 rows per thread and pass: 160 keys with 4 waves, 320 with 8
     __shared__ float sc[DEC_ATT_MAX_KEYS];
     __shared__ float red[KPI][HD + 1];
@@ -631,6 +635,240 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(const f16* __restrict
         float v = 0.f;
 #pragma unroll
         for (int s = 0; s < KPI; ++s) v += red[s][tid];
+        const f16 r = (f16) (nkeys > 0 ? v / lsum : 0.f);
+        if (direct_out) direct_out[out_perm ? (int) out_perm[h * HD + tid] : h * HD + tid] = r;   // a single split: this IS the attention output
+                                                                        // (stored where an act-order o_proj reads it linearly)
+        else po[tid] = r;
+    }
+    if (tid == 0 && !direct_out) {
+        pml[0] = nkeys > 0 ? mx : -INFINITY;
+        pml[1] = nkeys > 0 ? lsum : 0.f;
+    }
+    AP_CLK(6);                                                       // partials written
+#ifdef EXL_ATTN_PROBE
+    if (tid == 0 && blockIdx.x < 512) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) g_attn_probe[blockIdx.x * 8 + i] = ap_t[i] - ap_t0;
+        g_attn_probe[blockIdx.x * 8 + 7] = 1;
+    }
+#endif
+}
+
+template <bool SHORT, int NW>
+__global__ __launch_bounds__(NW * 64) void dec_attn_kernel(const f16* __restrict__ q, const f16* __restrict__ k_new,
+                                                       const f16* __restrict__ v_new, f16* __restrict__ kc,
+                                                       f16* __restrict__ vc, const f16* __restrict__ sin,
+                                                       const f16* __restrict__ cos, float* __restrict__ partial,
+                                                       const int32_t* __restrict__ pos_dev, int heads, int kv_heads,
+                                                       int max_seq, int nsplit, float scale, f16* __restrict__ direct_out,
+                                                       const uint16_t* __restrict__ out_perm)
+{
+    constexpr int HD = 128, LPK = 16, KPI = NW * 4, UN = DEC_ATT_CHUNK / 16, NT = NW * 64;   // 10 rows per thread and pass: 160 keys with 4 waves, 320 with 8
+    __shared__ float sc[DEC_ATT_MAX_KEYS];
+    __shared__ float red[NW][HD];
+    __shared__ float stat[2 * NW];
+
+    // 1-D grid; block id -> (head, split) such that every split of head h runs on XCD h % 8 (block b runs on XCD b % 8,
+    // observed, speed only): the merge block of head h (XCD h % 8 as well) then finds the partials in its own L2.
+    int h, split;
+    if ((heads & 7) == 0) {
+        const int r = blockIdx.x & 7, j = blockIdx.x >> 3;
+        h = r + 8 * (j / nsplit);
+        split = j % nsplit;
+    } else {
+        h = blockIdx.x / nsplit;
+        split = blockIdx.x % nsplit;
+    }
+    const int tid = threadIdx.x;
+    const int d8 = tid & 15, ks = tid >> 4;
+#ifdef EXL_ATTN_PROBE
+    unsigned long long ap_t[7];
+    const unsigned long long ap_t0 = __builtin_readcyclecounter();
+#endif
+    // Keys are dealt to the splits in CHUNKS of KPI (16 / 32) consecutive rows, round robin: chunk c belongs to split c % nsplit.
+    // The addresses of a block's first rows therefore do not depend on the position -- only how many of its chunks are visible
+    // does -- and the first DEC_ATT_AHEAD K rows are requested before the position has arrived (round 3 phase stamps of the
+    // contiguous form: first K request 4,300 cycles into a 17,800-cycle block, behind the kernel arguments and then the position,
+    // two dependent round trips).  Rows beyond the context are in-bounds reads of the cache (clamped to max_seq - 1) and masked.
+    // Every split still gets the same number of chunks (+- 1) at every position.
+    const int past_raw = *pos_dev;
+    const int kvh = h / (heads / kv_heads);
+    f16* kbase = kc + (size_t) kvh * max_seq * HD + d8 * 8;
+    f16* vbase = vc + (size_t) kvh * max_seq * HD + d8 * 8;
+    auto key_of = [&](int u) { return (u * nsplit + split) * KPI + ks; };       // global key index of this thread's row u
+
+    AP_CLK(0);
+    const f16x8 qraw = *(const f16x8*) (q + (size_t) h * HD + d8 * 8);
+    const f16x8 kraw = *(const f16x8*) (k_new + (size_t) kvh * HD + d8 * 8);
+    const f16x8 vn = *(const f16x8*) (v_new + (size_t) kvh * HD + d8 * 8);
+    f16x8 kv0[UN], vv0[UN];
+    if constexpr (!SHORT) {
+#pragma unroll
+        for (int u = 0; u < DEC_ATT_AHEAD; ++u)                        // speculative: before the position is known
+            kv0[u] = *(const f16x8*) (kbase + (size_t) min(key_of(u), max_seq - 1) * HD);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int past = past_raw;
+    const int vis = past + 1;
+    const int nchunk = vis > split * KPI ? (vis - split * KPI + nsplit * KPI - 1) / (nsplit * KPI) : 0;   // chunks of this split with a visible key
+    const int nkeys = nchunk * KPI;                                    // local key slots in use (the last chunk may be partly masked)
+    const f16x8 sn = *(const f16x8*) (sin + (size_t) past * HD + d8 * 8);
+    const f16x8 cs = *(const f16x8*) (cos + (size_t) past * HD + d8 * 8);
+    auto load_k0 = [&](int u) {
+        kv0[u] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (key_of(u) < vis) kv0[u] = *(const f16x8*) (kbase + (size_t) key_of(u) * HD);
+    };
+    auto load_v0 = [&](int u) {
+        vv0[u] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (key_of(u) < vis) vv0[u] = *(const f16x8*) (vbase + (size_t) key_of(u) * HD);
+    };
+    if constexpr (SHORT) {                                           // one split of <= 160 keys: only the rows that exist (a context of 4 has one)
+#pragma unroll
+        for (int u = 0; u < DEC_ATT_AHEAD; ++u) load_k0(u);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    AP_CLK(1);                                                       // first K rows requested, position known
+    // RoPE on q and on the new key: element d pairs with d +- 64, i.e. lane d8 with lane d8 ^ 8
+    const bool left = d8 < 8;
+    auto rope8 = [&](f16x8 own) {
+        const uint4 oi = __builtin_bit_cast(uint4, own);
+        uint4 pi;
+        pi.x = __shfl_xor((int) oi.x, 8, 64); pi.y = __shfl_xor((int) oi.y, 8, 64);
+        pi.z = __shfl_xor((int) oi.z, 8, 64); pi.w = __shfl_xor((int) oi.w, 8, 64);
+        const f16x8 oth = __builtin_bit_cast(f16x8, pi);
+        f16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f16 s = left ? (f16) (-sn[j]) : sn[j];
+            const f16 t = oth[j] * s;
+            r[j] = __builtin_fmaf16(own[j], cs[j], t);
+        }
+        return r;
+    };
+    const f16x8 qr = rope8(qraw);
+    const f16x8 kr = rope8(kraw);
+    if (split == 0 && (h % (heads / kv_heads)) == 0 && ks == 0) {
+        *(f16x8*) (kbase + (size_t) past * HD) = kr;
+        *(f16x8*) (vbase + (size_t) past * HD) = vn;
+    }
+    float qf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qf[j] = (float) qr[j] * scale;
+
+    AP_CLK(2);                                                       // q / k / sin / cos landed, RoPE done
+    // ---- scores ---------------------------------------------------------------------------------------------------
+    float mx = -INFINITY;
+    auto score_one = [&](int uabs, const f16x8& kv) {                  // uabs: row index of this thread counted over all passes
+        const int g = key_of(uabs);
+        const f16x8 kk = (g == past) ? kr : kv;                        // the new key never comes from memory
+        float dot = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dot = fmaf(qf[e], (float) kk[e], dot);
+#ifdef EXL_ATTN_VAR_SHFL
+#pragma unroll
+        for (int off = 1; off < LPK; off <<= 1) dot += __shfl_xor(dot, off, 64);
+#else
+        dot = dec_row_sum(dot);                                        // 16 lanes of a key row: DPP, no LDS-pipe round trips
+#endif
+        if (g < vis) {
+            if (d8 == 0) sc[uabs * KPI + ks] = dot;
+            mx = fmaxf(mx, dot);
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {                                     // first pass: row u + AHEAD of the K-then-V list is requested, row u scored
+        const int t = u + DEC_ATT_AHEAD;
+        if (t < UN) load_k0(t);
+        else if (t - UN < UN) load_v0(t - UN);
+        if (!SHORT || u < nchunk) score_one(u, kv0[u]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int u = DEC_ATT_AHEAD; u < UN; ++u) load_v0(u);               // the rest of V streams in during the softmax
+    __builtin_amdgcn_sched_barrier(0);
+    for (int u0 = UN; u0 < nchunk; u0 += UN) {                         // splits longer than one pass (UN chunks)
+        f16x8 kv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) kv[u] = *(const f16x8*) (kbase + (size_t) min(key_of(u0 + u), max_seq - 1) * HD);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) score_one(u0 + u, kv[u]);
+    }
+    AP_CLK(3);                                                       // K rows landed, scores done
+    mx = dec_row_max(mx);
+    mx = fmaxf(fmaxf(dec_lane(mx, 0), dec_lane(mx, 16)), fmaxf(dec_lane(mx, 32), dec_lane(mx, 48)));
+    if ((tid & 63) == 0) stat[tid >> 6] = mx;
+#ifdef EXL_ATTN_VAR_SYNC
+    __syncthreads();
+#else
+    dec_lds_barrier();                                               // (the V rows stay in flight across these barriers)
+#endif
+    mx = stat[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, stat[w]);
+    float lsum = 0.f;
+    for (int j = tid; j < nkeys; j += NT) {                            // local slot j = chunk (j / KPI) of this split, row j % KPI
+        const bool live = ((j / KPI) * nsplit + split) * KPI + (j % KPI) < vis;
+        const float p = live ? __expf(sc[j] - mx) : 0.f;
+        sc[j] = p;
+        lsum += p;
+    }
+    lsum = dec_wave_sum(lsum);
+    if ((tid & 63) == 0) stat[NW + (tid >> 6)] = lsum;
+#ifdef EXL_ATTN_VAR_SYNC
+    __syncthreads();
+#else
+    dec_lds_barrier();
+#endif
+    lsum = stat[NW];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) lsum += stat[NW + w];
+
+    AP_CLK(4);                                                       // softmax done
+    // ---- P V ------------------------------------------------------------------------------------------------------
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    auto pv_one = [&](int uabs, const f16x8& vv) {
+        const int g = key_of(uabs);
+        const float p = g < vis ? sc[uabs * KPI + ks] : 0.f;
+        const f16x8 v8 = (g == past) ? vn : vv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = fmaf(p, (float) v8[e], o[e]);
+    };
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        if (SHORT && u >= nchunk) continue;
+        pv_one(u, vv0[u]);
+    }
+    for (int u0 = UN; u0 < nchunk; u0 += UN) {
+        f16x8 vv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) vv[u] = *(const f16x8*) (vbase + (size_t) min(key_of(u0 + u), max_seq - 1) * HD);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) pv_one(u0 + u, vv[u]);
+    }
+    AP_CLK(5);                                                       // V rows landed, P V done
+    // the 4 key rows of a wave first (two cross-row exchanges per value), then one row per wave through LDS
+#ifdef EXL_ATTN_VAR_SHFL
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { o[e] += __shfl_xor(o[e], 16, 64); o[e] += __shfl_xor(o[e], 32, 64); }
+#else
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = dec_rows_sum(o[e]);
+#endif
+    if ((tid & 63) < 16) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid >> 6][d8 * 8 + e] = o[e];
+    }
+    __syncthreads();
+    // Several splits: each writes its OWN attention output (normalised by its own sum: a convex combination of V rows,
+    // safe in fp16) plus (max, sum); the o_proj kernel combines them while it builds its activation image.
+    f16* po = (f16*) partial + ((size_t) h * nsplit + split) * HD;
+    float* pml = partial + (size_t) heads * nsplit * (HD / 2) + ((size_t) h * nsplit + split) * 2;
+    if (tid < HD) {
+        float v = 0.f;
+#pragma unroll
+        for (int s = 0; s < NW; ++s) v += red[s][tid];
         const f16 r = (f16) (nkeys > 0 ? v / lsum : 0.f);
         if (direct_out) direct_out[out_perm ? (int) out_perm[h * HD + tid] : h * HD + tid] = r;   // a single split: this IS the attention output
                                                                         // (stored where an act-order o_proj reads it linearly)
@@ -900,8 +1138,8 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     if (const char* env = getenv("EXL_DEC_NSPLIT")) ns = atoi(env);  // measurement aid
     if (ns < 1) ns = 1;
     if (ns > DEC_MAX_NSPLIT) ns = DEC_MAX_NSPLIT;
-    while ((max_seq_len + ns - 1) / ns + 16 > DEC_ATT_MAX_KEYS) ++ns;
-    if (ns > DEC_MAX_NSPLIT) { delete d; EXL_FAIL(EXL_E_UNSUPPORTED, "decoder: max_seq_len %d too long (max %d)", max_seq_len, DEC_MAX_NSPLIT * (DEC_ATT_MAX_KEYS - 16)); }
+    while ((max_seq_len + ns - 1) / ns + 32 > DEC_ATT_MAX_KEYS) ++ns;   // chunks of up to 32 keys, round robin: a split holds <= keys / ns + 32 slots
+    if (ns > DEC_MAX_NSPLIT) { delete d; EXL_FAIL(EXL_E_UNSUPPORTED, "decoder: max_seq_len %d too long (max %d)", max_seq_len, DEC_MAX_NSPLIT * (DEC_ATT_MAX_KEYS - 32)); }
     d->nsplit = ns;
     d->nsplit_max = ns;
     const int kvd = kv_heads * head_dim;
@@ -1014,8 +1252,8 @@ extern "C" int exl_decoder_set_kv_splits(void* dec, int nsplit, int* max_context
     if (nsplit <= 0) nsplit = d->nsplit_max;
     EXL_REQUIRE(nsplit <= d->nsplit_max, EXL_E_INVALID, "decoder_set_kv_splits: %d splits requested, at most %d", nsplit, d->nsplit_max);
     d->nsplit = nsplit;
-    if (max_context) {                                               // keys visible = context + 1 must fit nsplit * (MAX_KEYS - 16)
-        const long cap = (long) nsplit * (DEC_ATT_MAX_KEYS - 16) - 1;
+    if (max_context) {                                               // keys visible = context + 1 must fit nsplit * (MAX_KEYS - 32)
+        const long cap = (long) nsplit * (DEC_ATT_MAX_KEYS - 32) - 1;
         *max_context = (int) (cap < d->max_seq - 1 ? cap : d->max_seq - 1);
     }
     return 0;
@@ -1266,13 +1504,16 @@ static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int3
                              : (d->qd() <= DEC_THREADS * 8 && d->nsplit > 1 && d->nsplit == d->nsplit_max && (d->max_seq + d->nsplit - 1) / d->nsplit > DEC_ATT_CHUNK) ? 8 : 4;
 #define DEC_ATTN_LAUNCH(SH, NWV, GRID, NS, OUT) hipLaunchKernelGGL((dec_attn_kernel<SH, NWV>), dim3(GRID), dim3(NWV * 64), 0, s, d->qbuf, d->kbuf, \
             d->vbuf, l.kc, l.vc, d->sin, d->cos, d->partial, pos_dev, d->heads, d->kv_heads, d->max_seq, NS, scale, OUT, l.inv_o)
+#define DEC_ATTN_SHORT(NWV, GRID, OUT) hipLaunchKernelGGL((dec_attn_short_kernel<NWV>), dim3(GRID), dim3(NWV * 64), 0, s, d->qbuf, d->kbuf, \
+            d->vbuf, l.kc, l.vc, d->sin, d->cos, d->partial, pos_dev, d->heads, d->kv_heads, d->max_seq, 1, scale, OUT, l.inv_o)
         if (d->nsplit == 1) {
-            if (attn_waves == 8) DEC_ATTN_LAUNCH(true, 8, d->heads, 1, d->attn_out); else DEC_ATTN_LAUNCH(true, 4, d->heads, 1, d->attn_out);
+            if (attn_waves == 8) DEC_ATTN_SHORT(8, d->heads, d->attn_out); else DEC_ATTN_SHORT(4, d->heads, d->attn_out);
         } else {
             if (attn_waves == 8) DEC_ATTN_LAUNCH(false, 8, d->nsplit * d->heads, d->nsplit, (f16*) nullptr);
             else DEC_ATTN_LAUNCH(false, 4, d->nsplit * d->heads, d->nsplit, (f16*) nullptr);
         }
 #undef DEC_ATTN_LAUNCH
+#undef DEC_ATTN_SHORT
         EXL_LAUNCH_CHECK();
         return 0;
     }
