@@ -103,6 +103,14 @@ struct RingUnit {                  // wave-uniform description of one unit of th
 
 // Phase attribution (probe builds only, -DEXL_RING_PROBE; scripts/probe_ring.sh): shader cycles since block start at 7 points,
 // per kernel class [0 q/k/v, 1 o_proj + merge, 2 gate/up, 3 plain vector (o_proj behind the merge kernel, down_proj)].
+// This file is compiled twice (the critical path of a parallel build is one translation unit): as itself -- the launcher and the
+// kernels for group size % 128 == 0 -- and through decode_ring_gm.hip with EXL_RING_PART = 1 -- the group-size 32 / 64 kernels.
+#ifndef EXL_RING_PART
+#define EXL_RING_PART 0
+#endif
+#if defined(EXL_RING_PROBE) && EXL_RING_PART == 1
+#undef EXL_RING_PROBE                                               /* the stamps live in part 0 */
+#endif
 #ifdef EXL_RING_PROBE
 __device__ unsigned long long g_ring_probe[4 * 512 * 8];
 #define RP_CLK(i) rp_t[i] = __builtin_readcyclecounter()
@@ -626,6 +634,23 @@ static int ring_cfg(int depth, int rbw, int grid, const DecGemvArgs& a, hipStrea
     return 1;
 }
 
+#define RING_GM(P, E, N) return ring_cfg<P, E, N, 8, 1>(depth, rbw, grid, a, s, plan)
+#if EXL_RING_PART == 1
+// group sizes 32 / 64 (decode_ring_gm.hip)
+int launch_dec_ring_gm(int pnorm, int emode, int nv, int depth, int rbw, int grid, const DecGemvArgs& a, hipStream_t s, int* plan)
+{
+#ifndef EXL_DEC_FAST_BUILD
+    if (pnorm == 1 && emode == 0) { if (nv <= 1) RING_GM(1, 0, 1); if (nv <= 2) RING_GM(1, 0, 2); }
+    if (pnorm == 1 && emode == 2) { if (nv <= 1) RING_GM(1, 2, 1); if (nv <= 2) RING_GM(1, 2, 2); }
+    if (pnorm == 2 && emode == 0) { if (nv <= 1) RING_GM(2, 0, 1); if (nv <= 2) RING_GM(2, 0, 2); }
+    if (pnorm == 2 && emode == 2) { if (nv <= 1) RING_GM(2, 2, 1); if (nv <= 2) RING_GM(2, 2, 2); }
+    if (pnorm == 0 && emode == 1) { if (nv <= 1) RING_GM(0, 1, 1); if (nv <= 2) RING_GM(0, 1, 2); if (nv <= 3) RING_GM(0, 1, 3); if (nv <= 6) RING_GM(0, 1, 6); }
+#endif
+    return 1;
+}
+#else
+int launch_dec_ring_gm(int pnorm, int emode, int nv, int depth, int rbw, int grid, const DecGemvArgs& a, hipStream_t s, int* plan);
+
 int launch_dec_ring(int pnorm, int emode, bool g16, int K, int grid, int depth, bool wide_blocks, const DecGemvArgs& a, hipStream_t s, int* plan)
 {
     const bool gm = !g16;                                            // group sizes 32 / 64: per-piece scale / zero pairs
@@ -650,19 +675,7 @@ int launch_dec_ring(int pnorm, int emode, bool g16, int K, int grid, int depth, 
     const int rbw = (RB + wpt - 1) / wpt;
     const int nv = (K / 8 + nw * 64 - 1) / (nw * 64);
 #define RING_GO(P, E, N, W) return ring_cfg<P, E, N, W, 0>(depth, rbw, grid, a, s, plan)
-#define RING_GM(P, E, N) return ring_cfg<P, E, N, 8, 1>(depth, rbw, grid, a, s, plan)
-#ifndef EXL_DEC_FAST_BUILD
-    if (gm) {
-        if (pnorm == 1 && emode == 0) { if (nv <= 1) RING_GM(1, 0, 1); if (nv <= 2) RING_GM(1, 0, 2); }
-        if (pnorm == 1 && emode == 2) { if (nv <= 1) RING_GM(1, 2, 1); if (nv <= 2) RING_GM(1, 2, 2); }
-        if (pnorm == 2 && emode == 0) { if (nv <= 1) RING_GM(2, 0, 1); if (nv <= 2) RING_GM(2, 0, 2); }
-        if (pnorm == 2 && emode == 2) { if (nv <= 1) RING_GM(2, 2, 1); if (nv <= 2) RING_GM(2, 2, 2); }
-        if (pnorm == 0 && emode == 1) { if (nv <= 1) RING_GM(0, 1, 1); if (nv <= 2) RING_GM(0, 1, 2); if (nv <= 3) RING_GM(0, 1, 3); if (nv <= 6) RING_GM(0, 1, 6); }
-        return 1;
-    }
-#else
-    if (gm) return 1;
-#endif
+    if (gm) return launch_dec_ring_gm(pnorm, emode, nv, depth, rbw, grid, a, s, plan);
 #ifdef EXL_DEC_FAST_BUILD
     if (pnorm == 1 && emode == 0 && nv == 1) RING_GO(1, 0, 1, 8);
     if (pnorm == 1 && emode == 2 && nv == 1) RING_GO(1, 2, 1, 8);
@@ -690,6 +703,7 @@ int launch_dec_ring(int pnorm, int emode, bool g16, int K, int grid, int depth, 
     }
 #endif
 #undef RING_GO
-#undef RING_GM
     return 1;
 }
+#endif
+#undef RING_GM
