@@ -294,7 +294,7 @@ def per_rank_report(local_values, dist, device, names):
         rows = [o.tolist() for o in out]
         info = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}
     info["per_rank"] = [{"rank": r, **{n: round(v, 3) for n, v in zip(names, row)}} for r, row in enumerate(rows)]
-    info["device"] = torch.cuda.get_device_name(device)
+    info["device"] = torch.cuda.get_device_name(device) if torch.cuda.is_available() else str(device)
     return info
 
 

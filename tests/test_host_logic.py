@@ -404,3 +404,13 @@ def test_perplexity_harness_equals_the_references_own_perplexity(tmp_path):
             assert [[int(c.shape[1]), int(c[0, 0]), int(c[0, -1])] for c in p.dataset_chunks] == rec["chunks"], rec["args"]
             got = p.test(ppl_token=mode, quiet=True)
             assert round(got, 4) == pytest.approx(rec[key], abs=1.5e-4), (rec["args"], mode, got, rec[key])   # the reference prints 4 decimals
+
+
+def test_bench_per_rank_report_single_process():
+    """bench.py's multi-GPU modes print the communicator size and every rank's own timings next to the MAX over ranks; without a
+    process group the report has one row and rccl_ranks = 0."""
+    import bench
+    info = bench.per_rank_report([1.5, 2.25], None, "cpu", ("a_ms", "b_ms"))
+    assert info["rccl_ranks"] == 0 and info["backend"] is None
+    assert info["per_rank"] == [{"rank": 0, "a_ms": 1.5, "b_ms": 2.25}]
+    assert bench.reduce_over_ranks([3.0, 4.0], None, "cpu") == [3.0, 4.0]

@@ -23,9 +23,10 @@ def _worker(rank, world, port, out):
     # rank r pretends its phases took (10 + r, 20 + 2r, 30 + 3r, 40 + 4r) ms
     local = [10.0 + rank, 20.0 + 2 * rank, 30.0 + 3 * rank, 40.0 + 4 * rank]
     red = bench.reduce_over_ranks(local, dist, "cpu")
+    rep = bench.per_rank_report(local[:2], dist, "cpu", ("prefill_ms", "decode_ms"))      # what --tensor-parallel / --layer-split print
     dist.barrier()
     if rank == 0:
-        out.put(red)
+        out.put((red, rep))
     dist.destroy_process_group()
 
 
@@ -36,11 +37,13 @@ def test_rank_reduction_is_max_and_rates_are_whole_job():
     procs = [ctx.Process(target=_worker, args=(r, world, PORT, out)) for r in range(world)]
     for p in procs:
         p.start()
-    red = out.get(timeout=120)
+    red, rep = out.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert red == [11.0, 22.0, 33.0, 44.0]                      # MAX over ranks of every phase
+    assert rep["rccl_ranks"] == 2 and rep["backend"] == "gloo"  # (the communicator the run used; "nccl" = RCCL on the GPU box)
+    assert rep["per_rank"] == [{"rank": 0, "prefill_ms": 10.0, "decode_ms": 20.0}, {"rank": 1, "prefill_ms": 11.0, "decode_ms": 22.0}]
     import bench
     rates = bench.whole_job_rates(world, 2048, 128, red[1], red[2], red[3])
     assert abs(rates["prefill"] - world * 2048 / 0.022) < 1e-6
