@@ -30,6 +30,7 @@ def _build(name, gs, act, seed=11, max_seq_len=64, num_layers=None, zeros="rand"
 ORACLE_TOL = 4e-3        # HIP path vs CPU oracle: max |diff| <= 4e-3 x the largest reference logit (measured: 6e-4 .. 1.2e-3 typical,
                          # gpurun_out tol_stats of round 3); decode steps add the oracle's OWN conditioning, see _oracle_steps
 ILL_CONDITIONED = 2e-3   # a decode step whose ORACLE moves by more than this x scale under one-ulp noise (see _model_close)
+LORA_TOL = 6e-3          # with an adapter on every projection: two more fp16-rounded GEMMs per matmul on both sides (measured 3.97e-3 on tiny_gqa)
 PATHS_TOL = 8e-3         # two HIP paths with different fp16 rounding points (MFMA prefill vs GEMV decode, fused vs op by op)
 
 
@@ -413,12 +414,12 @@ def test_lora_adapter_end_to_end(name, gs, act):
     orc.set_lora({k: v.cpu() for k, v in lora.tensors.items()})
     ref = torch.from_numpy(np.asarray(orc.forward(ids.numpy(), last_id_only=False), dtype=np.float32))
     scale = ref.abs().max().item()
-    _model_close(got, ref, ORACLE_TOL, f"LoRA prefill {name}")
+    _model_close(got, ref, LORA_TOL, f"LoRA prefill {name}")
     assert (got - base).abs().max().item() > 5e-2 * scale                    # the adapter is not a no-op
     tok = torch.tensor([[int(ref[0, -1].argmax())]])
     step = model.forward(tok.to("cuda:0"), cache2, lora=lora).float().cpu()   # rows == 1: fused decode ops with LoRA operands
     ref_step = torch.from_numpy(np.asarray(orc.forward(tok.numpy()), dtype=np.float32))
-    _model_close(step, ref_step, ORACLE_TOL, f"LoRA step {name}")
+    _model_close(step, ref_step, LORA_TOL, f"LoRA step {name}")
     model.free_unmanaged()
 
 
