@@ -1498,10 +1498,13 @@ static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int3
     case EXL_DEC_ATTN: {
         const float scale = 1.0f / sqrtf((float) d->hd);
         if (g_plan) { g_plan[0] = 1; g_plan[1] = d->nsplit; g_plan[7] = d->nsplit * d->heads; return 0; }
-        // 8 waves (320 keys per pass) where a split of the deepest bucket can exceed the 160 keys a 4-wave pass holds
+        // 8 waves in the deepest bucket: where a split can exceed the 160 keys a 4-wave pass holds (<= 4096-wide models, 8 splits per
+        // head), and for the wider models (12-16 splits per head of ~128-170 keys: twice the waves per block request twice the rows at a
+        // time; round 3, same box: 13B attention 12.96 -> 10.61 us, 407 -> 419 tokens/s; 65B 15.5 -> 14.5 us)
         static const int attn_waves_env = getenv("EXL_DEC_ATTN_WAVES") ? atoi(getenv("EXL_DEC_ATTN_WAVES")) : 0;
+        const bool deepest = d->nsplit > 1 && d->nsplit == d->nsplit_max;
         const int attn_waves = attn_waves_env ? attn_waves_env
-                             : (d->qd() <= DEC_THREADS * 8 && d->nsplit > 1 && d->nsplit == d->nsplit_max && (d->max_seq + d->nsplit - 1) / d->nsplit > DEC_ATT_CHUNK) ? 8 : 4;
+                             : (deepest && (d->qd() > DEC_THREADS * 8 || (d->max_seq + d->nsplit - 1) / d->nsplit > DEC_ATT_CHUNK)) ? 8 : 4;
 #define DEC_ATTN_LAUNCH(SH, NWV, GRID, NS, OUT) hipLaunchKernelGGL((dec_attn_kernel<SH, NWV>), dim3(GRID), dim3(NWV * 64), 0, s, d->qbuf, d->kbuf, \
             d->vbuf, l.kc, l.vc, d->sin, d->cos, d->partial, pos_dev, d->heads, d->kv_heads, d->max_seq, NS, scale, OUT, l.inv_o)
 #define DEC_ATTN_SHORT(NWV, GRID, OUT) hipLaunchKernelGGL((dec_attn_short_kernel<NWV>), dim3(GRID), dim3(NWV * 64), 0, s, d->qbuf, d->kbuf, \
