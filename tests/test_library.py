@@ -220,3 +220,24 @@ def test_reference_modules_import_against_the_shim():
     env = dict(os.environ, PYTHONPATH=root + os.pathsep + REFERENCE)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stderr[-2000:]
+
+
+def test_fused_ops_name_the_offending_tensor_without_a_gpu():
+    """The shim checks device / contiguity of the nine tensors of q4_attn in one sweep and, when the sweep fails, once more one by one to
+    NAME the offender (exllama_amd/cuda_ext.py) -- the reference's TORCH_CHECK messages name theirs (exllama_ext.cpp:53-75).  No kernel
+    runs: the check fails first."""
+    import torch
+    from exllama_amd import cuda_ext
+    ext = cuda_ext.exllama_ext
+    h = torch.zeros((1, 1, 64), dtype=torch.float16)
+    w = torch.zeros((64,), dtype=torch.float16)
+    none = cuda_ext.none_tensor
+    assert cuda_ext._is_none(none) and cuda_ext._is_none(None) and not cuda_ext._is_none(h) and cuda_ext._ptr(none) is None
+    with pytest.raises(RuntimeError, match="x must be on a HIP device"):
+        ext.q4_attn(h, w, 1e-6, h, h, h, 0, 0, 0, w, w, 1, 0, 1, 1, 64, h, h, 16, none, none, none, none, none, none, none)
+    with pytest.raises(RuntimeError, match="x must be on a HIP device"):
+        ext.q4_attn_2(h, h, 0, none, none, none)
+    with pytest.raises(RuntimeError, match="x must be on a HIP device"):
+        ext.q4_mlp(h.view(1, 64), w, 1e-6, 0, 0, 0, none, none, none, none, none, none, none)
+    with pytest.raises(RuntimeError, match="incorrect datatype"):
+        ext.q4_attn(h, w, 1e-6, h.float(), h, h, 0, 0, 0, w, w, 1, 0, 1, 1, 64, h, h, 16, none, none, none, none, none, none, none)
