@@ -42,7 +42,7 @@ def _oracle_steps(ref, toks, past):
     differ (fp32 vs fp16 accumulation, rounding of the rotation, order of the split-KV sums).  A random-weight model has steps whose attention
     scores are large and nearly tied; there one ulp in q / k moves every logit by ~1e-2 x scale, for the oracle as for any
     kernel (measured in round 3 on the 13B act-order layer: seven steps in eight 6e-4, one 4.8e-3 in all three HIP paths, which
-    agree with each other to one logit ulp; scripts/debug/ulp_sensitivity.py reproduces the oracle's share on the CPU).  The
+    agree with each other to one logit ulp; tests/debug/ulp_sensitivity.py reproduces the oracle's share on the CPU).  The
     parity bound of such a step is ORACLE_TOL plus that movement; a well-conditioned step adds one logit ulp."""
     from oracle import exl_oracle as O
     from oracle import model_oracle as MO
