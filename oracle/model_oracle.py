@@ -197,3 +197,97 @@ class OracleLlama:
         hn = O.rms_norm(hidden.reshape(-1, h), self.norm_w, self.eps)
         logits = (hn.astype(f32) @ self.lm_head.astype(f32).T).astype(f16).astype(f32)
         return logits.reshape(bsz, q, -1)
+
+
+class TruthLlama(OracleLlama):
+    """The same forward pass with NO fp16 rounding anywhere: every op of `layer_forward` / `forward` in float64, in the same order,
+    on the same model constants (the fp16 embedding / norm / head weights, the fp16 RoPE tables of model.py:864-877 and the
+    dequantised weights h(h(q - z) * s) of q4_matrix.cu:170-210 -- all of them exact in float64).  It states what the fp16 pipeline
+    approximates, so a test can require  |HIP - truth| <= c * |fp16 oracle - truth|  instead of widening a bound where the fp16
+    oracle itself is ill-conditioned (tests/test_model_gpu.py: _truth_close).  K / V rows are cached unrounded (float64 cache);
+    rows copied in from an fp16 cache are taken as given.  LoRA operands are not supported here."""
+
+    @classmethod
+    def from_oracle(cls, ref, past=None):
+        """A truth model on the SAME weight objects as the fp16 oracle `ref` (nothing is dequantised twice), continuing from the
+        first `past` (default: ref.past) cached positions of `ref` -- taken as given, widened to float64."""
+        t = cls.__new__(cls)
+        t.__dict__.update({k: v for k, v in ref.__dict__.items() if k not in ("kc", "vc", "past")})
+        t.reset(ref.kc[0].shape[0])
+        t.past = ref.past if past is None else past
+        for i in range(t.L):
+            t.kc[i][:, :, :t.past] = ref.kc[i][:, :, :t.past]
+            t.vc[i][:, :, :t.past] = ref.vc[i][:, :, :t.past]
+        return t
+
+    def reset(self, bsz=1):
+        self.past = 0
+        shape = (bsz, self.kv_heads, self.max_seq_len, self.hd)
+        self.kc = [np.zeros(shape, dtype=np.float64) for _ in range(self.L)]
+        self.vc = [np.zeros(shape, dtype=np.float64) for _ in range(self.L)]
+
+    @staticmethod
+    def _norm(x, w, eps):
+        return x / np.sqrt((x * x).mean(axis=-1, keepdims=True) + eps) * np.asarray(w).astype(np.float64)
+
+    def _rope(self, x, heads):
+        """x [bsz, rows * hd] float64, rotate-half with the fp16 tables (rope.cu:27-87 without its three roundings)."""
+        bsz = x.shape[0]
+        xr = x.reshape(bsz, -1, self.hd)
+        hd2 = self.hd // 2
+        pos = self.past + np.arange(xr.shape[1]) // heads
+        s = np.asarray(self.sin).reshape(-1, self.hd)[pos].astype(np.float64)[None]
+        c = np.asarray(self.cos).reshape(-1, self.hd)[pos].astype(np.float64)[None]
+        l, r = xr[:, :, :hd2], xr[:, :, hd2:]
+        out = np.concatenate([l * c[:, :, :hd2] - r * s[:, :, :hd2], r * c[:, :, hd2:] + l * s[:, :, hd2:]], axis=-1)
+        return out.reshape(x.shape)
+
+    def _mm(self, i, which, x):
+        lin = self.layers[i][which]
+        if lin.w32 is None:
+            lin.prepare()
+        K = lin.w32.shape[0]
+        acc = np.zeros((x.shape[0], lin.w32.shape[1]), dtype=np.float64)
+        for k0 in range(0, K, 2048):                        # the fp16-exact weights are held as fp32: widen a slab at a time
+            acc += x[:, k0:k0 + 2048] @ lin.w32[k0:k0 + 2048].astype(np.float64)
+        return acc
+
+    def layer_forward(self, i, hidden):
+        assert not self.lora, "TruthLlama: no LoRA operands"
+        l = self.layers[i]
+        bsz, q_len, h = hidden.shape
+        x2 = hidden.reshape(-1, h)
+        xn = self._norm(x2, l["in_norm"], self.eps)
+        q = self._rope(self._mm(i, "q", xn).reshape(bsz, -1), self.heads).reshape(bsz, q_len, self.heads, self.hd)
+        k = self._rope(self._mm(i, "k", xn).reshape(bsz, -1), self.kv_heads).reshape(bsz, q_len, -1)
+        v = self._mm(i, "v", xn).reshape(bsz, q_len, -1)
+        O.update_cache(k, v, self.kc[i], self.vc[i], self.past)
+        kv_len = self.past + q_len
+        qh = q.transpose(0, 2, 1, 3)
+        kk, vv = self.kc[i][:bsz, :, :kv_len], self.vc[i][:bsz, :, :kv_len]
+        rep = self.heads // self.kv_heads
+        if rep > 1:
+            kk, vv = np.repeat(kk, rep, axis=1), np.repeat(vv, rep, axis=1)
+        s = np.einsum("bhqd,bhkd->bhqk", qh, kk) / np.sqrt(self.hd)
+        qi, kj = np.arange(q_len)[:, None], np.arange(kv_len)[None, :]
+        s = np.where(kj > self.past + qi, -np.inf, s)
+        p = np.exp(s - s.max(axis=-1, keepdims=True))
+        a = np.einsum("bhqk,bhkd->bhqd", p / p.sum(axis=-1, keepdims=True), vv)
+        a = a.transpose(0, 2, 1, 3).reshape(-1, h)
+        x2 = x2 + self._mm(i, "o", a)
+        xn = self._norm(x2, l["post_norm"], self.eps)
+        g, u = self._mm(i, "gate", xn), self._mm(i, "up", xn)
+        x2 = x2 + self._mm(i, "down", g / (1.0 + np.exp(-g)) * u)
+        return x2.reshape(bsz, q_len, h)
+
+    def forward(self, input_ids, last_id_only=True):
+        ids = np.asarray(input_ids)
+        hidden = self.embed[ids].astype(np.float64)
+        for i in range(self.L):
+            hidden = self.layer_forward(i, hidden)
+        self.past += ids.shape[1]
+        if last_id_only:
+            hidden = hidden[:, -1:, :]
+        bsz, q, h = hidden.shape
+        hn = self._norm(hidden.reshape(-1, h), self.norm_w, self.eps)
+        return (hn @ self.lm_head.astype(np.float64).T).reshape(bsz, q, -1)

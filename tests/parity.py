@@ -1,0 +1,110 @@
+"""Model-level comparison helpers shared by the GPU parity tests (tests/test_model_gpu.py, tests/test_tp_gpu.py) and the CPU test
+that exercises them (tests/test_oracle.py): whole-array criteria (_model_close) and the float64-truth criterion of decode steps
+(_oracle_steps, _truth_close)."""
+import json
+import math
+import os
+
+import numpy as np
+
+ORACLE_TOL = 4e-3        # HIP path vs CPU oracle: max |diff| <= 4e-3 x the largest reference logit (measured: 6e-4 .. 1.2e-3 typical,
+                         # profiles/r03_model_tolerance_stats.jsonl); decode steps are held to the float64 truth model instead, see _truth_close
+TRUTH_FACTOR = 1.5       # decode step: |HIP - truth| <= 1.5 x |fp16 oracle - truth| + one logit ulp
+LORA_TOL = 6e-3          # with an adapter on every projection: two more fp16-rounded GEMMs per matmul on both sides (measured 3.97e-3 on tiny_gqa)
+PATHS_TOL = 8e-3         # two HIP paths with different fp16 rounding points (MFMA prefill vs GEMV decode, fused vs op by op)
+
+
+def _oracle_steps(ref, toks, past):
+    """Teacher-forced decode steps from cache position `past`, three ways: the fp16 oracle (`clean`), the float64 truth model
+    (oracle.model_oracle.TruthLlama: same ops, same order, same constants, no fp16 rounding; it continues from the same cached
+    rows) and three more realisations of the fp16 oracle in which every fp16 tensor a decode step produces -- the projections,
+    the RoPE'd q and k, the attention output, the residual stream -- is moved by one ulp on half of its elements: the places
+    where two correct fp16 implementations differ (fp32 vs fp16 accumulation, rounding of the rotation, order of the split-KV
+    sums).  A random-weight model has steps whose attention scores are large and nearly tied; there one ulp in q / k moves every
+    logit by ~1e-2 x scale, for the oracle as for any kernel, and the response is heavy-tailed (which element flips matters:
+    7.7e-4 / 5.1e-3 / 6.6e-3 for one step over three seeds, tests/debug/ulp_sensitivity.py) -- so "how far a correct fp16
+    pipeline sits from the truth at this step" is taken as the worst of the four realisations, and the result under test is held
+    to TRUTH_FACTOR x that (_truth_close).  Returns (clean, runs, truth): clean / truth are lists over steps, runs = [clean] + noise."""
+    from oracle import exl_oracle as O
+    from oracle import model_oracle as MO
+    truth = MO.TruthLlama.from_oracle(ref, past)
+    want = [truth.forward(np.array([[t]]))[0, 0] for t in toks]
+    rope0, attn0, lin0 = O.rope, O.attention, MO.OracleLinear.__call__
+    runs = []
+    for seed in (11, 12, 13):
+        nrs = np.random.RandomState(seed)
+
+        def ulp_noise(y):                                            # half of the elements one fp16 ulp up or down
+            bump = nrs.rand(*y.shape) < 0.5
+            toward = np.where(nrs.rand(*y.shape) < 0.5, np.float16(np.inf), np.float16(-np.inf)).astype(np.float16)
+            return np.where(bump, np.nextafter(y, toward), y)
+
+        O.rope = lambda *a, **kw: ulp_noise(rope0(*a, **kw))
+        O.attention = lambda *a, **kw: ulp_noise(attn0(*a, **kw))
+        MO.OracleLinear.__call__ = lambda self, x, residual=None: ulp_noise(lin0(self, x, residual=residual))
+        try:
+            ref.past = past
+            runs.append([ref.forward(np.array([[t]]))[0, 0] for t in toks])
+        finally:
+            O.rope, O.attention, MO.OracleLinear.__call__ = rope0, attn0, lin0
+    ref.past = past                                                  # the clean pass runs last: its K / V rows are the ones left in ref
+    clean = [ref.forward(np.array([[t]]))[0, 0] for t in toks]
+    return clean, [clean] + runs, want
+
+
+def _err_stats(x, truth):
+    """(max |x - truth|, rms(x - truth), worst rms over the 16-element blocks)."""
+    d = np.asarray(x, dtype=np.float64).reshape(-1) - truth.reshape(-1)
+    nblk = d.size // 16
+    blk = float(np.sqrt(np.mean(d[:nblk * 16].reshape(nblk, 16) ** 2, axis=1)).max()) if nblk >= 4 else 0.0
+    return float(np.abs(d).max()), float(np.sqrt(np.mean(d ** 2))), blk
+
+
+def _truth_close(got, runs, truth, step, tag=""):
+    """One decode step against the float64 truth: the result under test may sit at most TRUTH_FACTOR x as far from the truth as the
+    fp16 oracle does (worst of its realisations, see _oracle_steps) plus one ulp of the largest logit -- in the maximum norm, in
+    the RMS over all logits and in the worst 16-element block (one wrong column group or one bad KV split shows up there).  No
+    branch on conditioning and no blanket bound: where the oracle is sharp (1-2 logit ulps, most steps) so is the test."""
+    got = np.asarray(got.detach().cpu() if hasattr(got, "detach") else got, dtype=np.float64)
+    want = np.asarray(truth[step], dtype=np.float64)
+    assert got.shape == want.shape and np.isfinite(got).all(), tag
+    scale = max(float(np.abs(want).max()), 1e-3)
+    ulp = 2.0 ** (math.floor(math.log2(scale)) - 10)                 # fp16 spacing at the largest logit
+    o_max, o_rms, o_blk = np.max([_err_stats(run[step], want) for run in runs], axis=0)
+    g_max, g_rms, g_blk = _err_stats(got, want)
+    stats = os.environ.get("EXL_TOL_STATS")
+    if stats:
+        with open(stats, "a") as f:
+            f.write(json.dumps({"tag": tag, "scale": scale, "hip_vs_truth": [g_max / scale, g_rms / scale, g_blk / scale],
+                                "oracle_vs_truth": [o_max / scale, o_rms / scale, o_blk / scale]}) + "\n")
+    assert g_max <= TRUTH_FACTOR * o_max + ulp, (tag, "max", g_max / scale, o_max / scale)
+    assert g_rms <= TRUTH_FACTOR * o_rms + ulp / 2, (tag, "rms", g_rms / scale, o_rms / scale)
+    assert g_blk <= TRUTH_FACTOR * o_blk + ulp, (tag, "16-element block", g_blk / scale, o_blk / scale)
+
+
+def _model_close(got, ref, tol, tag=""):
+    """Whole-model comparison of logits / cache rows: an absolute bound at the scale of the largest reference value, plus -- because
+    that bound alone would let a wrong low-magnitude column or one bad KV split through -- the relative RMS error over the whole
+    array and over every 16-element block of it (the criteria of tests/test_ops_gpu.py:_close at model depth)."""
+    got = np.asarray(got.detach().cpu() if hasattr(got, "detach") else got, dtype=np.float64)
+    ref = np.asarray(ref.detach().cpu() if hasattr(ref, "detach") else ref, dtype=np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert np.isfinite(got).all(), tag
+    scale = max(float(np.abs(ref).max()), 1e-3)
+    err = float(np.abs(got - ref).max())
+    rms_ref = float(np.sqrt(np.mean(ref ** 2)))
+    rel = float(np.sqrt(np.mean((got - ref) ** 2))) / max(rms_ref, 1e-12)
+    worst_block = 0.0
+    nblk = ref.size // 16
+    if nblk >= 4:
+        fg, fr = got.reshape(-1)[:nblk * 16].reshape(nblk, 16), ref.reshape(-1)[:nblk * 16].reshape(nblk, 16)
+        eb = np.sqrt(np.mean((fg - fr) ** 2, axis=1))
+        rb = np.sqrt(np.mean(fr ** 2, axis=1))
+        worst_block = float((eb / np.maximum(rb, rms_ref / 8.0)).max())
+    stats = os.environ.get("EXL_TOL_STATS")
+    if stats:
+        with open(stats, "a") as f:
+            f.write(json.dumps({"tag": tag, "tol": tol, "err_over_scale": err / scale, "rms_rel": rel, "worst_block": worst_block}) + "\n")
+    assert err <= tol * scale, (tag, err, scale)
+    assert rel <= tol / 2, (tag, "rms(diff) / rms(ref)", rel)
+    assert worst_block <= 4 * tol, (tag, "16-element block", worst_block)

@@ -170,3 +170,43 @@ def test_oracle_model_lora_path():
     t = (x.astype(np.float32) @ a.numpy().astype(np.float32)).astype(np.float16)
     d = (t.astype(np.float32) @ b.numpy().astype(np.float32)).astype(np.float16)
     assert np.array_equal(lin.with_lora(x, a.numpy(), b.numpy()), lin(x, residual=d))
+
+
+def test_truth_model_and_the_decode_step_criterion():
+    """oracle.model_oracle.TruthLlama (float64, no fp16 rounding) is what the fp16 oracle approximates, and tests/parity.py's
+    decode-step criterion |x - truth| <= 1.5 |oracle - truth| + 1 ulp accepts a second correct fp16 implementation (the oracle
+    on prepared weights: fp32 BLAS instead of the per-group reconstruction order) and refuses small defects: one 16-column
+    block of the logits off by 4e-3 x scale, or a K row of the cache rotated with the wrong position."""
+    from oracle.model_oracle import TruthLlama
+    from parity import _oracle_steps, _truth_close
+    dims = synth.PRESETS["tiny_gqa"]
+    tensors = synth.make_checkpoint(dims, groupsize=128, act_order=True, seed=5, device="cpu", zeros="rand")
+    cfg = synth.config_dict(dims)
+    ref = OracleLlama(cfg, tensors, max_seq_len=64)
+    ids = np.random.RandomState(0).randint(1, dims.vocab_size, size=(1, 20))
+    full = ref.forward(ids, last_id_only=False)
+    truth_full = TruthLlama(cfg, tensors, max_seq_len=64).forward(ids, last_id_only=False)
+    scale = float(np.abs(truth_full).max())
+    assert np.abs(full - truth_full).max() <= 3e-3 * scale            # the fp16 pipeline sits a few logit ulps from the truth
+    toks = [5, 9, 200]
+    other = OracleLlama(cfg, tensors, max_seq_len=64)                 # the "implementation under test": same cache, fp32 BLAS matmuls
+    other.prepare()
+    other.kc, other.vc = [a.copy() for a in ref.kc], [a.copy() for a in ref.vc]
+    clean, runs, truth = _oracle_steps(ref, toks, 20)
+    assert len(runs) == 4 and runs[0] is clean
+    other.past = 20
+    got = [other.forward(np.array([[t]]))[0, 0] for t in toks]
+    for i in range(len(toks)):
+        _truth_close(got[i], runs, truth, i, f"second implementation, step {i}")
+        bad = got[i].copy()
+        bad[32:48] += np.float32(4e-3 * scale)
+        with pytest.raises(AssertionError):
+            _truth_close(bad, runs, truth, i)
+    # a defect inside the model: the key of the first generated token cached one position off in RoPE
+    broken = OracleLlama(cfg, tensors, max_seq_len=64)
+    broken.kc, broken.vc = [a.copy() for a in other.kc], [a.copy() for a in other.vc]
+    for l in range(broken.L):
+        broken.kc[l][0, :, 20] = broken.kc[l][0, :, 19]
+    broken.past = 21
+    with pytest.raises(AssertionError):
+        _truth_close(broken.forward(np.array([[toks[1]]]))[0, 0], runs, truth, 1)
