@@ -40,6 +40,9 @@ def parse_args():
     p.add_argument("--model", default="7b", choices=["7b", "13b", "33b", "65b", "70b", "tiny", "tiny_gqa"])
     p.add_argument("--groupsize", type=int, default=128)
     p.add_argument("--act-order", action="store_true")
+    p.add_argument("--act-order-maps", default="gptq", choices=["gptq", "independent"],
+                   help="with --act-order: 'gptq' = q/k/v and gate/up share their row permutation, as GPTQ (desc_act) writes them "
+                        "(quantised against the same input); 'independent' = one random permutation per matrix (the general case)")
     p.add_argument("--prompt", type=int, default=2048)
     p.add_argument("--gen", type=int, default=128)
     p.add_argument("--layers", type=int, default=None, help="debug: truncate the model (INVALID as a benchmark)")
@@ -55,7 +58,10 @@ def parse_args():
     p.add_argument("--tensor-parallel", action="store_true",
                    help="ONE model split by heads / intermediate columns across the ranks (exllama_amd/tp.py): every rank streams 1/N of "
                         "the weights per token, two all-reduces of the residual stream per layer over RCCL")
-    return p.parse_args()
+    args = p.parse_args()
+    if args.act_order:                                    # what synth.make_checkpoint takes: False, True (independent maps) or "gptq"
+        args.act_order = "gptq" if args.act_order_maps == "gptq" else True
+    return args
 
 
 def algorithmic_bytes_per_matmul(K, N, g, M=1):
@@ -426,7 +432,7 @@ def main():
         "dtype": "int4 weights (GPTQ) x fp16 activations, fp32 accumulate",
         "data": "synthetic (seeded random GPTQ weights of the named architecture, random token ids)",
         "config": {
-            "workload": f"Llama-{args.model.upper()} 4-bit GPTQ g{args.groupsize}{' act-order' if args.act_order else ''}, "
+            "workload": f"Llama-{args.model.upper()} 4-bit GPTQ g{args.groupsize}{(' act-order (shared q/k/v and gate/up maps)' if args.act_order == 'gptq' else ' act-order (one map per matrix)') if args.act_order else ''}, "
                         f"{S}-token prefill + {G}-token greedy decode at context {S}..{S + G} (BASELINE configs[1]); "
                         f"plus {G} tokens from context 4",
             "layers": L, "prompt_tokens": S, "gen_tokens": G, "parallelism": f"replicas x{world}" if world > 1 else "single GPU",

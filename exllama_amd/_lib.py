@@ -50,6 +50,9 @@ SIGNATURES = {
     "exl_q4_matmul_dual": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, C.POINTER(c_int)]),
     "exl_q4_qkv_rope_cache": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_int, c_int, c_int, c_int, c_int, c_void_p, C.POINTER(c_int)]),
+    "exl_q4_attn_prompt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                           c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, C.POINTER(c_int)]),
+    "exl_q4_mlp_prompt": (c_int, [c_void_p, c_void_p, C.c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, C.POINTER(c_int)]),
     "exl_q4_matmul_lora": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "exl_q4_reconstruct": (c_int, [c_void_p, c_void_p, c_void_p]),
     "exl_column_remap": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

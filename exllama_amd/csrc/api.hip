@@ -71,6 +71,27 @@ int exl_workspace(int device, size_t floats, float** out)
     return 0;
 }
 
+int exl_gemm_workspace(int device, size_t floats, float** out)
+{
+    EXL_REQUIRE(device >= 0 && device < EXL_MAX_DEVICES, EXL_E_INVALID, "invalid device index %d", device);
+    DeviceBuffers* b = &g_buffers[device];
+    if (b->gemm_ws_floats < floats) {
+        if (floats > ((size_t) 512 << 20) / sizeof(float)) return EXL_E_TOO_SMALL;
+        int prev = 0;
+        EXL_HIP(hipGetDevice(&prev));
+        EXL_HIP(hipSetDevice(device));
+        if (b->gemm_ws) (void) hipFree(b->gemm_ws);         // (hipFree waits for the kernels still reading the old buffer)
+        b->gemm_ws = nullptr; b->gemm_ws_floats = 0;
+        const size_t want = floats + floats / 4;             // head room: the next shape rarely needs a new allocation
+        const hipError_t e = hipMalloc((void**) &b->gemm_ws, want * sizeof(float));
+        (void) hipSetDevice(prev);
+        if (e != hipSuccess) { (void) hipGetLastError(); return EXL_E_TOO_SMALL; }
+        b->gemm_ws_floats = want;
+    }
+    *out = b->gemm_ws;
+    return 0;
+}
+
 extern "C" int exl_prepare_buffers(int device, void* temp_state, size_t temp_state_numel, void* temp_mlp,
                                    size_t temp_mlp_numel, void* temp_zeros_float, size_t max_zeros_float,
                                    void* temp_dq, size_t temp_dq_numel)
@@ -135,11 +156,12 @@ extern "C" int exl_cleanup(void)
     for (int d = 0; d < EXL_MAX_DEVICES; ++d) {
 
         DeviceBuffers* b = &g_buffers[d];
-        if (b->workspace) {
+        if (b->workspace || b->gemm_ws) {
             int prev = 0;
             if (hipGetDevice(&prev) == hipSuccess) {
                 (void) hipSetDevice(d);
-                (void) hipFree(b->workspace);
+                if (b->workspace) (void) hipFree(b->workspace);
+                if (b->gemm_ws) (void) hipFree(b->gemm_ws);
                 (void) hipSetDevice(prev);
             }
         }
@@ -173,6 +195,7 @@ extern "C" int exl_make_q4(int device, int height, int width, int groups, uint32
     m->qzeros = qzeros;
     m->scales = (f16*) scales;
     m->x_map = nullptr;
+    m->xmap_hash = 0;
     m->layout = EXL_LAYOUT_GPTQ;
     m->fp_valid = false;
     // make_q4 re-tiles (and, with act-order, repacks -- as the reference does, q4_matrix.cu:159) `qweight` IN PLACE: a second
@@ -217,6 +240,9 @@ extern "C" int exl_make_q4(int device, int height, int width, int groups, uint32
         }
         for (int gidx = 0; gidx < groups; ++gidx) start[gidx + 1] += start[gidx];
         for (int row = 0; row < height; ++row) x_map[start[g_idx_host[row]]++] = (uint32_t) row;
+        uint64_t hsh = 1469598103934665603ull;                        // FNV-1a over the map: equal maps <=> (with overwhelming odds) equal hashes
+        for (int row = 0; row < height; ++row) { hsh ^= x_map[row]; hsh *= 1099511628211ull; }
+        m->xmap_hash = hsh ? hsh : 1;
         int prev = 0;
         hipError_t e = hipGetDevice(&prev);
         if (e == hipSuccess) e = hipSetDevice(device);
@@ -357,15 +383,17 @@ extern "C" int exl_q4_matmul_dual(void* w1, void* w2, const void* x, int x_heigh
     EXL_REQUIRE(x && out1 && (silu || out2), EXL_E_INVALID, "q4_matmul_dual: null tensor pointer");
     DeviceGuard guard(m1->device);
     EXL_REQUIRE(guard.ok, EXL_E_INVALID, "q4_matmul_dual: cannot select device %d", m1->device);
-    const int r = launch_q4_gemm_dual(m1, m2, (const f16*) x, x_height, (f16*) out1, (f16*) out2, silu, (hipStream_t) stream);
+    DeviceBuffers* bufs = exl_buffers(m1->device);
+    const PromptPrologue pro = {nullptr, 0.f, bufs->temp_state, bufs->temp_state_numel};     // act-order pairs that share a map: one gather
+    const int r = launch_q4_gemm_dual(m1, m2, (const f16*) x, x_height, (f16*) out1, (f16*) out2, silu, pro, (hipStream_t) stream);
     if (r == 1) return 0;                                    // not eligible: the caller runs the two products itself
     if (r == 0) *launched = 1;
     return r;
 }
 
-extern "C" int exl_q4_qkv_rope_cache(void* wq, void* wk, void* wv, const void* x, int bsz, int q_len, void* q_out, const void* sin,
-                                     const void* cos, void* key_cache, void* value_cache, int heads, int kv_heads, int head_dim,
-                                     int past_len, int max_seq_len, void* stream, int* launched)
+extern "C" int exl_q4_attn_prompt(void* wq, void* wk, void* wv, const void* x, const void* norm_w, float eps, int bsz, int q_len,
+                                 void* q_out, const void* sin, const void* cos, void* key_cache, void* value_cache, int heads, int kv_heads,
+                                 int head_dim, int past_len, int max_seq_len, void* stream, int* launched)
 {
     EXL_REQUIRE(launched, EXL_E_INVALID, "q4_qkv_rope_cache: launched is null");
     *launched = 0;
@@ -380,12 +408,54 @@ extern "C" int exl_q4_qkv_rope_cache(void* wq, void* wk, void* wv, const void* x
                 past_len, q_len, max_seq_len);
     DeviceGuard guard(mq->device);
     EXL_REQUIRE(guard.ok, EXL_E_INVALID, "q4_qkv_rope_cache: cannot select device %d", mq->device);
+    DeviceBuffers* bufs = exl_buffers(mq->device);
+    const PromptPrologue pro = {(const f16*) norm_w, eps, bufs->temp_state, bufs->temp_state_numel};
     const int r = launch_q4_qkv_rope_cache(mq, mk, mv, (const f16*) x, bsz * q_len, (f16*) q_out, (const f16*) sin, (const f16*) cos,
                                            (f16*) key_cache, (f16*) value_cache, q_len, heads, kv_heads, head_dim, past_len, max_seq_len,
-                                           (hipStream_t) stream);
+                                           pro, (hipStream_t) stream);
     if (r == 1) return 0;                                    // not eligible: the caller runs the separate ops
     if (r == 0) *launched = 1;
     return r;
+}
+
+extern "C" int exl_q4_qkv_rope_cache(void* wq, void* wk, void* wv, const void* x, int bsz, int q_len, void* q_out, const void* sin,
+                                     const void* cos, void* key_cache, void* value_cache, int heads, int kv_heads, int head_dim,
+                                     int past_len, int max_seq_len, void* stream, int* launched)
+{
+    return exl_q4_attn_prompt(wq, wk, wv, x, nullptr, 0.f, bsz, q_len, q_out, sin, cos, key_cache, value_cache, heads, kv_heads, head_dim,
+                              past_len, max_seq_len, stream, launched);
+}
+
+// The MLP half of a decoder layer for a PROMPT (more than 512 rows): x += down( silu(gate(norm(x))) * up(norm(x)) ) -- what the
+// reference runs as rms_norm, two q4_matmul, silu_mul and a third q4_matmul with the residual (model.py:266-273, :546-552), here:
+// RMSNorm (writing the row order of gate / up when they are act-order matrices sharing a map) -> ONE kernel for both products and
+// SiLU * mul -> down_proj GEMM accumulating into x.  `act`: caller's scratch of rows * intermediate halves.
+extern "C" int exl_q4_mlp_prompt(void* x, const void* norm_w, float eps, void* gate, void* up, void* down, int rows, void* act,
+                                 void* stream, int* launched)
+{
+    EXL_REQUIRE(launched, EXL_E_INVALID, "q4_mlp_prompt: launched is null");
+    *launched = 0;
+    Q4Matrix* gm = q4_from_handle(gate);
+    Q4Matrix* um = q4_from_handle(up);
+    Q4Matrix* dm = q4_from_handle(down);
+    EXL_REQUIRE(gm && um && dm, EXL_E_INVALID, "q4_mlp_prompt: invalid q4 handle");
+    EXL_REQUIRE(rows >= 0, EXL_E_INVALID, "q4_mlp_prompt: negative row count");
+    if (rows == 0) { *launched = 1; return 0; }
+    EXL_REQUIRE(x && norm_w && act, EXL_E_INVALID, "q4_mlp_prompt: null tensor pointer");
+    EXL_REQUIRE(gm->height == dm->width && um->height == dm->width && dm->height == um->width && gm->width == um->width &&
+                gm->device == dm->device && um->device == dm->device, EXL_E_INVALID, "q4_mlp_prompt: incompatible shapes");
+    DeviceGuard guard(gm->device);
+    EXL_REQUIRE(guard.ok, EXL_E_INVALID, "q4_mlp_prompt: cannot select device %d", gm->device);
+    DeviceBuffers* bufs = exl_buffers(gm->device);
+    EXL_REQUIRE(bufs->prepared, EXL_E_NO_BUFFERS, "q4_mlp_prompt: prepare_buffers was not called for device %d", gm->device);
+    hipStream_t s = (hipStream_t) stream;
+    const PromptPrologue pro = {(const f16*) norm_w, eps, bufs->temp_state, bufs->temp_state_numel};
+    const int r = launch_q4_gemm_dual(gm, um, (const f16*) x, rows, (f16*) act, nullptr, 1, pro, s);
+    if (r == 1) return 0;                                    // not eligible: the caller runs the separate ops
+    if (r != 0) return r;
+    *launched = 1;
+    // (temp_state is free again: the dual kernel read it in stream order before down_proj's gather overwrites it)
+    return q4_gemm(dm, act, rows, x, 1, bufs->temp_state, bufs->temp_state_numel, s);
 }
 
 extern "C" int exl_q4_matmul_lora(void* w, const void* x, int x_height, void* out, const void* lora_a,

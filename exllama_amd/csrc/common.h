@@ -64,6 +64,8 @@ struct Q4Matrix {
     uint32_t* qzeros;  // borrowed [G, N/8]
     f16* scales;       // borrowed [G, N]
     uint32_t* x_map;   // owned   [K] or NULL (act-order)
+    uint64_t xmap_hash;// FNV-1a of the map's K entries (0 without a map): matrices quantised against the same input (q / k / v, gate / up)
+                       // carry the SAME map in GPTQ checkpoints; equal (height, hash) lets the fused prompt kernels gather once
     int layout;        // EXL_LAYOUT_GPTQ or EXL_LAYOUT_T16
     uint32_t fp[8];    // first and last 16 bytes of qweight AFTER the in-place rewrite (make_q4's double-call guard); fp_valid: rewritten
     bool fp_valid;
@@ -82,10 +84,13 @@ struct DeviceBuffers {
     f16* temp_mlp;    size_t temp_mlp_numel;
     float* temp_zeros_float; size_t max_zeros_float;
     f16* temp_dq;     size_t temp_dq_numel;
-    float* workspace; size_t workspace_floats;   // owned: split-K slabs / attention partials
+    float* workspace; size_t workspace_floats;   // owned: decode split-K slabs / attention partials
+    float* gemm_ws;   size_t gemm_ws_floats;     // owned, grown on demand: fp32 slices of the prompt GEMMs' K splits (its own buffer: a caller
+                                                 // running attention on another stream must not see them land in `workspace`)
 };
 DeviceBuffers* exl_buffers(int device);           // never NULL for 0 <= device < EXL_MAX_DEVICES
 int exl_workspace(int device, size_t floats, float** out);   // fails if too small / not prepared
+int exl_gemm_workspace(int device, size_t floats, float** out);   // grows (device-synchronising, NOT capturable) up to 512 MiB; non-zero: no room
 extern ExlTuning g_tuning;
 
 // ---- launchers implemented in the .hip files -----------------------------------------------------------
@@ -106,11 +111,16 @@ int launch_q4_gemv(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
 bool q4_gemv_covers(const Q4Matrix* w);          // false: in_features beyond what the decode GEMV stages -> use launch_q4_gemm
 int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_zero, f16* remap_tmp,
                    size_t remap_tmp_numel, hipStream_t s);
+// Optional prologue of the two fused prompt-pass launches below: `norm_w` != NULL -> x is the residual stream and the kernel input is
+// RMSNorm(x) (written to `tmp`); act-order matrices that share one map get their input gathered ONCE into `tmp` (by the norm
+// kernel when there is one, else by column_remap).  `tmp` must hold rows * K halves whenever either applies.
+struct PromptPrologue { const f16* norm_w; float eps; f16* tmp; size_t tmp_numel; };
+bool q4_same_map(const Q4Matrix* a, const Q4Matrix* b);      // both without a map, or maps with equal (height, hash)
 int launch_q4_qkv_rope_cache(const Q4Matrix* wq, const Q4Matrix* wk, const Q4Matrix* wv, const f16* x, int rows, f16* q_out,
                              const f16* sin, const f16* cos, f16* kc, f16* vc, int q_len, int heads, int kv_heads, int head_dim,
-                             int past_len, int max_seq, hipStream_t s);
+                             int past_len, int max_seq, const PromptPrologue& pro, hipStream_t s);
 int launch_q4_gemm_dual(const Q4Matrix* w1, const Q4Matrix* w2, const f16* x, int rows, f16* out1, f16* out2, int silu,
-                        hipStream_t s);                     // 1 = not eligible (run the products separately)
+                        const PromptPrologue& pro, hipStream_t s);   // 1 = not eligible (run the products separately)
 int launch_half_gemm(const f16* x, const f16* w, f16* out, int M, int K, int N, int no_zero, hipStream_t s);
 
 int launch_dec_sample(float* logits, float* probs, int64_t* history, int64_t* token_io, const int32_t* pos_dev, const float* uniforms,
@@ -118,6 +128,7 @@ int launch_dec_sample(float* logits, float* probs, int64_t* history, int64_t* to
 int launch_embedding(const int64_t* ids, const f16* table, f16* out, int n_ids, int hidden, int vocab, hipStream_t s);
 int launch_head_rows(const f16* x, const f16* w, float* out, int rows, int hidden, int vocab, hipStream_t s);   // 1 = not covered
 int launch_rms_norm(const f16* x, const f16* w, f16* out, float eps, int rows, int dim, hipStream_t s);
+int launch_rms_norm_gather(const f16* x, const f16* w, f16* out, const uint32_t* x_map, float eps, int rows, int dim, hipStream_t s);   // x_map NULL: plain norm
 // decode_fused.hip: one fused executor launch for the op-level entry points (0 done, 1 not covered, > 1 error)
 int dec_op_gemv(int device, int cls, int pnorm, int emode, const f16* vec, const f16* norm_w, float eps, int nmat,
                 Q4Matrix* const* mats, f16* const* outs, f16* hid_io, hipStream_t s);

@@ -78,6 +78,83 @@ int launch_rms_norm(const f16* x, const f16* w, f16* out, float eps, int rows, i
     return 0;
 }
 
+// RMSNorm whose output row is written in an act-order matrix' row order: out[row][c] = norm(x)[row][x_map[c]] -- the
+// reference's rms_norm followed by column_remap (rms_norm.cu + column_remap.cu:7-36) as ONE pass over x: the normalised row goes
+// through LDS (dim * 2 bytes), the gather reads LDS, the stores stay 16-byte coalesced.  Same bits as the two kernels.
+template <int MAXV>
+__global__ __launch_bounds__(256) void rms_norm_gather_kernel(const f16* __restrict__ x, const f16* __restrict__ w,
+                                                              f16* __restrict__ out, const uint32_t* __restrict__ x_map,
+                                                              float eps, int dim)
+{
+    extern __shared__ __attribute__((aligned(16))) f16 nrow[];
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const f16* xr = x + (size_t) row * dim;
+    f16* orow = out + (size_t) row * dim;
+    const int nvec = dim >> 3;
+
+    f16x8 v[MAXV];
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = tid + i * 256;
+        if (idx < nvec) {
+            v[i] = *(const f16x8*) (xr + idx * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = (float) v[i][j]; acc = fmaf(f, f, acc); }
+        }
+    }
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    const float total = red[0] + red[1] + red[2] + red[3];
+    const float rmf = 1.0f / sqrtf(total * (1.0f / (float) dim) + eps);
+    const f16 rm = (f16) rmf;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = tid + i * 256;
+        if (idx < nvec) {
+            const f16x8 wv = *(const f16x8*) (w + idx * 8);
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f16 m = v[i][j] * rm;
+                o[j] = m * wv[j];
+            }
+            *(f16x8*) (nrow + idx * 8) = o;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = tid + i * 256;
+        if (idx < nvec) {
+            const uint4 m0 = *(const uint4*) (x_map + idx * 8);
+            const uint4 m1 = *(const uint4*) (x_map + idx * 8 + 4);
+            f16x8 o;
+            o[0] = nrow[m0.x]; o[1] = nrow[m0.y]; o[2] = nrow[m0.z]; o[3] = nrow[m0.w];
+            o[4] = nrow[m1.x]; o[5] = nrow[m1.y]; o[6] = nrow[m1.z]; o[7] = nrow[m1.w];
+            *(f16x8*) (orow + idx * 8) = o;
+        }
+    }
+}
+
+int launch_rms_norm_gather(const f16* x, const f16* w, f16* out, const uint32_t* x_map, float eps, int rows, int dim, hipStream_t s)
+{
+    if (!x_map) return launch_rms_norm(x, w, out, eps, rows, dim, s);
+    if (rows <= 0) return 0;
+    EXL_REQUIRE(dim % 8 == 0 && dim <= 256 * 8 * 16, EXL_E_UNSUPPORTED, "rms_norm_gather: dim (%d) must be a multiple of 8, <= 32768", dim);
+    const int per = (dim / 8 + 255) / 256;
+    const size_t lds = (size_t) dim * 2;                                 // <= 64 KiB
+    if (per <= 2)      hipLaunchKernelGGL(rms_norm_gather_kernel<2>,  dim3(rows), dim3(256), lds, s, x, w, out, x_map, eps, dim);
+    else if (per <= 4) hipLaunchKernelGGL(rms_norm_gather_kernel<4>,  dim3(rows), dim3(256), lds, s, x, w, out, x_map, eps, dim);
+    else if (per <= 8) hipLaunchKernelGGL(rms_norm_gather_kernel<8>,  dim3(rows), dim3(256), lds, s, x, w, out, x_map, eps, dim);
+    else               hipLaunchKernelGGL(rms_norm_gather_kernel<16>, dim3(rows), dim3(256), lds, s, x, w, out, x_map, eps, dim);
+    EXL_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // RoPE (rotate-half), in place.  One thread = 8 columns of the left half + the matching 8 of the right half.
 //   l' = h(fma(l, cos_l, h(r * h(-sin_l))))      r' = h(fma(r, cos_r, h(l * sin_r)))

@@ -15,8 +15,10 @@
 //                            (> 512 rows);
 //   (q4_gemm_skinny.hip)     <= 256 rows: the decode-shaped short-prompt kernel;
 //   half_gemm_kernel         plain fp16 GEMM of the LoRA path (correctness first).
-// Act-order weights: x is gathered through x_map by column_remap into the borrowed temp_state buffer first
-// (same as the reference, q4_matmul.cu:320-325); folding the gather into the A-tile load is future work.
+// Act-order weights: x is gathered through x_map into the borrowed temp_state buffer first (the reference's column_remap,
+// q4_matmul.cu:320-325) -- ONCE for the matrices that share a map (q / k / v and gate / up of a GPTQ checkpoint: quantised against
+// the same input, hence the same permutation), and by the RMSNorm kernel that produces the activations where there is one
+// (prompt_prologue).  A 2-byte gather cannot ride in the 16-byte LDS-DMA pieces of the A tile.
 #include "gemv_t16.h"
 #include <stdlib.h>
 
@@ -568,6 +570,7 @@ __global__ __launch_bounds__(256) void q4_gemm_splitk_reduce_kernel(const float*
 // head of q, k or v (three matrices sharing x and K, tiles numbered across them); the epilogue applies RoPE to q and k
 // (the partner column d +- 64 sits in the other column wave: exchanged through LDS) and writes q to its buffer, k and v
 // straight into the KV cache -- the reference runs 3 matmuls, 2 RoPE kernels and a cache scatter (model.py:431-445).
+struct GemmTail { int b_split, parts; float* ws; };      // see plan_gemm_tail
 struct GwQkv {
     const uint4* qw[3]; const uint32_t* qz[3]; const f16* sc[3];
     int n[3];                      // out_features of q, k, v
@@ -582,7 +585,7 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
                                                                const uint32_t* __restrict__ qzeros,
                                                                const f16* __restrict__ scales, f16* __restrict__ out, int M,
                                                                int K, int N, int gshift, int no_zero, int mtiles, int ntiles,
-                                                               const GwQkv e)
+                                                               const GwQkv e, const GemmTail tail)
 {
     constexpr int TM = 4, TN = 4, WAVES_N = 2;
     constexpr int TBM = 256;
@@ -591,7 +594,15 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [3][A] then [2][B]
     unsigned char* const ldsB = lds + 3 * A_BYTES;
 
-    const int b = blockIdx.x;
+    int b = blockIdx.x;
+    int kz = 0, nparts = 1, tseq = 0;                                  // tail blocks: part kz of `parts` of the K range of logical block b_split + tseq
+    if (EPI == 0 && b >= tail.b_split) {
+        const int j = b - tail.b_split;
+        tseq = j / tail.parts;
+        kz = j - tseq * tail.parts;
+        b = tail.b_split + tseq;
+        nparts = tail.parts;
+    }
     const int xcd = b & 7;
     const int idx = b >> 3;
     const int nl = idx / mtiles;
@@ -610,7 +621,8 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nk = K / GT_BK;                                         // even (K % 128 == 0), >= 2
+    const int nk = K / GT_BK / nparts;                                // K steps of this block: even (K % (128 parts) == 0), >= 2
+    const int it0 = kz * nk;                                          // its first K tile
     auto ring = [](int s, int d) { const int v = s + d; return v >= 3 ? v - 3 : v; };
 
     if (wave >= GW_CONS) {
@@ -699,8 +711,8 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
             __builtin_amdgcn_s_barrier();
         };
         BRegs rX, rY;
-        issue_b(0, rX);  stage_a(0, 0);
-        issue_b(1, rY);  stage_a(1, GT_BK);
+        issue_b(it0, rX);      stage_a(0, it0 * GT_BK);
+        issue_b(it0 + 1, rY);  stage_a(1, (it0 + 1) * GT_BK);
         GW_WAIT("11", rX);                                               // batch 0 landed
         store_b(0, rX);
         publish();
@@ -728,7 +740,7 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
             GP_ACC(p_iss, q0, q1); GP_ACC(p_wait, q1, q2); GP_ACC(p_store, q2, q3); GP_ACC(p_bar, q3, q4);
         };
         for (int t = 0; t < nk; t += 2) {                                // straight line: every wait is unconditional
-            const int t2 = min(t + 2, nk - 1), t3 = min(t + 3, nk - 1);   // the last two steps re-fetch the last tile (never read)
+            const int t2 = it0 + min(t + 2, nk - 1), t3 = it0 + min(t + 3, nk - 1);   // the last two steps re-fetch the last tile (never read)
             // B(t+2) first, then the wait for B(t+1)'s registers, then the 8 DMA
             // pieces of A(t+2) BETWEEN the dequantised words: the CU's vector-memory pipe takes ~16 cycles per 1 KiB piece
             // whoever issues it, so DMA issue and the VALU work overlap instead of adding up
@@ -871,6 +883,15 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
         return;
     }
 
+    if (nparts > 1) {                                                    // fp32 slice of this part of K: q4_gemm_tail_reduce_kernel adds them up
+        float* wt = tail.ws + (size_t) (tseq * nparts + kz) * (256 * 128);
+#pragma unroll
+        for (int im = 0; im < TM; ++im)
+#pragma unroll
+            for (int in = 0; in < TN; ++in)
+                *(f32x4*) (wt + ((wm * TM + im) * 16 + fr) * 128 + (wn * TN + in) * 16 + fk * 4) = acc[in][im];
+        return;
+    }
 #pragma unroll
     for (int im = 0; im < TM; ++im) {
         const int row = m0 + (wm * TM + im) * 16 + fr;
@@ -893,19 +914,150 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
     }
 }
 
+// Epilogue of the tail blocks (GemmTail): logical block b_split + blockIdx.x sums its `parts` fp32 slices in a fixed order and
+// finishes the tile -- DUAL 0: out (+)= sum; DUAL 1: a slice holds the gate tile then the up tile, out = silu(gate) * up in the
+// fp16 order of q4_gemm_t16d2_kernel's own epilogue; DUAL 2: the two products go to out and out2.
+template <int DUAL>
+__global__ __launch_bounds__(256) void q4_gemm_tail_reduce_kernel(f16* __restrict__ out, f16* __restrict__ out2, int M, int N, int no_zero,
+                                                                  int mtiles, int ntiles, const GemmTail tail)
+{
+    const int b = tail.b_split + blockIdx.x;
+    const int xcd = b & 7, idx = b >> 3;
+    const int nl = idx / mtiles, mt = idx - nl * mtiles;
+    const int nt = nl * 8 + xcd;
+    if (nt >= ntiles) return;
+    const int m0 = mt * 256, n0 = nt * GT_BN;
+    constexpr int SLICE = (DUAL ? 2 : 1) * 256 * 128;
+    const float* w0 = tail.ws + (size_t) blockIdx.x * tail.parts * SLICE;
+    for (int c = threadIdx.x; c < 256 * 32; c += 256) {                  // 4-column chunks of the 256 x 128 tile
+        const int r = c >> 5, c4 = (c & 31) * 4;
+        const int row = m0 + r, n = n0 + c4;
+        if (row >= M || n >= N) continue;
+        f32x4 v = *(const f32x4*) (w0 + r * 128 + c4), u = {0.f, 0.f, 0.f, 0.f};
+        if (DUAL) u = *(const f32x4*) (w0 + 256 * 128 + r * 128 + c4);
+        for (int z = 1; z < tail.parts; ++z) {
+            const f32x4 a = *(const f32x4*) (w0 + (size_t) z * SLICE + r * 128 + c4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += a[j];
+            if (DUAL) {
+                const f32x4 a2 = *(const f32x4*) (w0 + (size_t) z * SLICE + 256 * 128 + r * 128 + c4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) u[j] += a2[j];
+            }
+        }
+        f16* op = out + (size_t) row * N + n;
+        f16x4 o;
+        if (DUAL == 2) {
+            o = (f16x4){(f16) v[0], (f16) v[1], (f16) v[2], (f16) v[3]};
+            *(f16x4*) (out2 + (size_t) row * N + n) = (f16x4){(f16) u[0], (f16) u[1], (f16) u[2], (f16) u[3]};
+        } else if (DUAL) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                                // exactly elementwise.hip: silu_mul_h on the fp16 values
+                const f16 g = (f16) v[j], up = (f16) u[j];
+                const f16 e = (f16) __expf((float) (f16) (-g));
+                const f16 sm = (f16) 1.0f + e;
+                const f16 rc = (f16) (1.0f / (float) sm);
+                const f16 t = g * rc;
+                o[j] = t * up;
+            }
+        } else {
+            if (no_zero) {
+                const f16x4 prev = *(const f16x4*) op;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += (float) prev[j];
+            }
+            o = (f16x4){(f16) v[0], (f16) v[1], (f16) v[2], (f16) v[3]};
+        }
+        *(f16x4*) op = o;
+    }
+}
+
+// Tail of a launch whose tile count is not a multiple of the CU count (7B gate / up: 688 tiles = 2.69 rounds of 256 CUs; 13B
+// o / down: 320 = 1.25): the tiles of the last, partly filled round are cut along K into `parts` blocks each, so the round's work
+// is spread over the whole chip; their fp32 slices are summed by q4_gemm_tail_reduce_kernel.  Only when at least one FULL round
+// precedes the tail (small problems keep their one-block-per-tile form and their bit patterns).  Deterministic: the split depends
+// on (tiles, K) only, the slices are added in a fixed order -- but the K split makes the fp32 sums of the tail tiles differ from
+// the unsplit kernel's by rounding.  Returns the grid size; t->parts == 1: no split.
+static int plan_gemm_tail(int device, int mtiles, int ntiles, int K, int slices_per_tile, GemmTail* t, int* n_tail)
+{
+    static const bool off = getenv("EXL_GEMM_NO_TAIL_SPLIT") != nullptr;      // A/B switch
+    const int padded = 8 * ((ntiles + 7) / 8) * mtiles;
+    t->b_split = padded; t->parts = 1; t->ws = nullptr;
+    *n_tail = 0;
+    int ncu = 256;
+    {
+        static int cus[EXL_MAX_DEVICES] = {};
+        if (device >= 0 && device < EXL_MAX_DEVICES) {
+            if (!cus[device]) { hipDeviceProp_t p; if (hipGetDeviceProperties(&p, device) == hipSuccess) cus[device] = p.multiProcessorCount; }
+            if (cus[device] > 0) ncu = cus[device];
+        }
+    }
+    const int tiles = mtiles * ntiles;
+    const int full = tiles / ncu * ncu, rem = tiles - full;
+    if (off || full == 0 || rem == 0) return padded;
+    // choose the split: parts in {2, 4, 8} with whole 128-row blocks of K per part; cost of the tail in rounds of one full tile
+    const int RB = K >> 7;
+    int best = 1; double best_cost = 1.0;
+    for (int p = 2; p <= 8; p *= 2) {
+        if (RB % p != 0 || RB / p < 2) continue;
+        const double rounds = (double) ((rem * p + ncu - 1) / ncu);
+        const double cost = rounds / p * (1.0 + 3.0 * p / (2.0 * RB));        // ~3 K steps of fill / drain / slice store per part
+        if (cost < best_cost - 0.05) { best = p; best_cost = cost; }
+    }
+    if (best == 1) return padded;
+    // the logical block after which `full` valid tiles have been dispatched
+    int valid = 0, bs = 0;
+    for (; bs < padded && valid < full; ++bs) {
+        const int nt = (bs >> 3) / mtiles * 8 + (bs & 7);
+        if (nt < ntiles) ++valid;
+    }
+    const int nl_tail = padded - bs;
+    float* ws = nullptr;
+    if (exl_gemm_workspace(device, (size_t) nl_tail * best * slices_per_tile * 256 * 128, &ws) != 0) return padded;   // no room: unsplit
+    t->b_split = bs; t->parts = best; t->ws = ws;
+    *n_tail = nl_tail;
+    return bs + nl_tail * best;
+}
+
+bool q4_same_map(const Q4Matrix* a, const Q4Matrix* b)
+{
+    if (!a->x_map || !b->x_map) return !a->x_map && !b->x_map;
+    return a->height == b->height && a->xmap_hash == b->xmap_hash;
+}
+
+// Runs the prologue of a fused prompt-pass launch (common.h: PromptPrologue) and points *x at the kernel's input.
+static int prompt_prologue(const PromptPrologue& pro, const Q4Matrix* w, const f16** x, int rows, hipStream_t s)
+{
+    if (!pro.norm_w && !w->x_map) return 0;
+    EXL_REQUIRE(pro.tmp && pro.tmp_numel >= (size_t) rows * w->height, EXL_E_TOO_SMALL,
+                "q4 gemm: temp_state buffer is too small for the normalised / gathered activations (%zu < %zu halves)",
+                pro.tmp_numel, (size_t) rows * w->height);
+    EXL_REQUIRE(*x != pro.tmp, EXL_E_INVALID, "q4 gemm: the activations may not live in the temp_state buffer");
+    if (pro.norm_w) EXL_TRY(launch_rms_norm_gather(*x, pro.norm_w, pro.tmp, w->x_map, pro.eps, rows, w->height, s));
+    else            EXL_TRY(launch_column_remap(*x, pro.tmp, rows, w->height, w->x_map, s));
+    *x = pro.tmp;
+    return 0;
+}
+
 static int launch_gemm_t16w(const Q4Matrix* w, const f16* xin, int rows, f16* out, int no_zero, int gshift, hipStream_t s)
 {
     const int K = w->height, N = w->width;
     const int mtiles = (rows + 255) / 256;
     const int ntiles = (N + GT_BN - 1) / GT_BN;
-    const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
+    GemmTail tail;
+    int n_tail = 0;
+    const int grid = plan_gemm_tail(w->device, mtiles, ntiles, K, 1, &tail, &n_tail);
     const size_t smem = 3 * (size_t) 256 * 128 + 2 * GT_BTILE_BYTES;
     static bool big[EXL_MAX_DEVICES] = {};
     EXL_TRY(exl_lds_opt_in((const void*) q4_gemm_t16w_kernel<0>, big));
     GwQkv none = {};
     hipLaunchKernelGGL(q4_gemm_t16w_kernel<0>, dim3(grid), dim3((GW_CONS + GW_PROD) * 64), smem, s, xin, (const uint4*) w->qweight, w->qzeros,
-                       w->scales, out, rows, K, N, gshift, no_zero, mtiles, ntiles, none);
+                       w->scales, out, rows, K, N, gshift, no_zero, mtiles, ntiles, none, tail);
     EXL_LAUNCH_CHECK();
+    if (n_tail) {
+        hipLaunchKernelGGL(q4_gemm_tail_reduce_kernel<0>, dim3(n_tail), dim3(256), 0, s, out, (f16*) nullptr, rows, N, no_zero, mtiles, ntiles, tail);
+        EXL_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -913,7 +1065,7 @@ static int launch_gemm_t16w(const Q4Matrix* w, const f16* xin, int rows, f16* ou
 // matrices / shapes are outside what the fused kernel covers; the caller then runs the separate ops.
 int launch_q4_qkv_rope_cache(const Q4Matrix* wq, const Q4Matrix* wk, const Q4Matrix* wv, const f16* x, int rows, f16* q_out,
                              const f16* sin, const f16* cos, f16* kc, f16* vc, int q_len, int heads, int kv_heads, int head_dim,
-                             int past_len, int max_seq, hipStream_t s)
+                             int past_len, int max_seq, const PromptPrologue& pro, hipStream_t s)
 {
     static const bool off = getenv("EXL_GEMM_NO_QKV_FUSION") != nullptr;      // A/B switch
     const Q4Matrix* m[3] = {wq, wk, wv};
@@ -923,11 +1075,12 @@ int launch_q4_qkv_rope_cache(const Q4Matrix* wq, const Q4Matrix* wk, const Q4Mat
     if ((uint64_t) rows * (uint64_t) K >= (1ull << 31)) return 1;
     int gshift = -1;
     for (int i = 0; i < 3; ++i) {
-        if (m[i]->layout != EXL_LAYOUT_T16 || m[i]->x_map || m[i]->height != K || m[i]->groupsize != wq->groupsize) return 1;
+        if (m[i]->layout != EXL_LAYOUT_T16 || m[i]->height != K || m[i]->groupsize != wq->groupsize || !q4_same_map(m[i], wq)) return 1;
         if ((uint64_t) K * (uint64_t) m[i]->width >= (1ull << 32)) return 1;
     }
     if ((wq->groupsize & (wq->groupsize - 1)) == 0) { gshift = 0; while ((1 << gshift) < wq->groupsize) ++gshift; }
     if (gshift < 5) return 1;
+    EXL_TRY(prompt_prologue(pro, wq, &x, rows, s));                           // RMSNorm and / or the (shared) act-order gather
     GwQkv e = {};
     int tiles = 0;
     for (int i = 0; i < 3; ++i) {
@@ -943,7 +1096,7 @@ int launch_q4_qkv_rope_cache(const Q4Matrix* wq, const Q4Matrix* wk, const Q4Mat
     static bool big[EXL_MAX_DEVICES] = {};
     EXL_TRY(exl_lds_opt_in((const void*) q4_gemm_t16w_kernel<1>, big));
     hipLaunchKernelGGL(q4_gemm_t16w_kernel<1>, dim3(grid), dim3((GW_CONS + GW_PROD) * 64), smem, s, x, (const uint4*) nullptr, (const uint32_t*) nullptr,
-                       (const f16*) nullptr, (f16*) nullptr, rows, K, 0, gshift, 0, mtiles, tiles, e);
+                       (const f16*) nullptr, (f16*) nullptr, rows, K, 0, gshift, 0, mtiles, tiles, e, GemmTail{1 << 30, 1, nullptr});
     EXL_LAUNCH_CHECK();
     return 0;
 }
@@ -970,14 +1123,22 @@ __global__ __launch_bounds__(512) void q4_gemm_t16d2_kernel(const f16* __restric
                                                             const uint4* __restrict__ qw2, const uint32_t* __restrict__ qz2,
                                                             const f16* __restrict__ sc2, f16* __restrict__ out1,
                                                             f16* __restrict__ out2, int M, int K, int N, int gshift,
-                                                            int groupsize, int mtiles, int ntiles)
+                                                            int groupsize, int mtiles, int ntiles, const GemmTail tail)
 {
     constexpr int TBM = 256;
     constexpr int A_BYTES = TBM * 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [3][A] then [2][B1 | B2]
     unsigned char* const ldsB = lds + 3 * A_BYTES;
 
-    const int b = blockIdx.x;
+    int b = blockIdx.x;
+    int kz = 0, nparts = 1, tseq = 0;                                  // tail blocks (plan_gemm_tail): part kz of the K range of logical block b_split + tseq
+    if (b >= tail.b_split) {
+        const int j = b - tail.b_split;
+        tseq = j / tail.parts;
+        kz = j - tseq * tail.parts;
+        b = tail.b_split + tseq;
+        nparts = tail.parts;
+    }
     const int xcd = b & 7;
     const int idx = b >> 3;
     const int nl = idx / mtiles;
@@ -992,7 +1153,8 @@ __global__ __launch_bounds__(512) void q4_gemm_t16d2_kernel(const f16* __restric
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int RB = K >> 7;
-    const int nk = K / GT_BK;                                         // even, >= 2
+    const int nk = K / GT_BK / nparts;                                // K steps of this block: even, >= 2
+    const int it0 = kz * nk;                                          // its first K tile
 
     // Every address is (uniform base, advanced per K step by scalar arithmetic) + (fixed 32-bit byte offset per lane): saddr-form
     // loads, no 64-bit address registers (the register file is full: 128 accumulators + 56 fragment registers).
@@ -1097,10 +1259,10 @@ __global__ __launch_bounds__(512) void q4_gemm_t16d2_kernel(const f16* __restric
 
     // ---- prologue: batches 0 and 1 in flight, B(0) dequantised --------------------------------------------------------
     BRegs rX, rY;
-    stage_a2(0, 0, 0); stage_a2(1, 0, 0);
-    issue_w(0, rX); issue_zs(0, rX);
-    stage_a2(0, 1, GT_BK); stage_a2(1, 1, GT_BK);                        // nk >= 2 always
-    issue_w(1, rY); issue_zs(1, rY);
+    stage_a2(0, 0, it0 * GT_BK); stage_a2(1, 0, it0 * GT_BK);
+    issue_w(it0, rX); issue_zs(it0, rX);
+    stage_a2(0, 1, (it0 + 1) * GT_BK); stage_a2(1, 1, (it0 + 1) * GT_BK);    // nk >= 2 always
+    issue_w(it0 + 1, rY); issue_zs(it0 + 1, rY);
     GD2_WAIT("7", rX);                                                    // batch 0 landed (batch 1 may still fly)
 #pragma unroll
     for (int j = 0; j < 4; ++j) store_word(0, rX, j);
@@ -1114,7 +1276,7 @@ __global__ __launch_bounds__(512) void q4_gemm_t16d2_kernel(const f16* __restric
 #endif
     // one K step; rI receives the packed weights of tile t + 2, rW holds tile t + 1 (landing), bcur = LDS slot of B(t)
     auto step = [&](int t, BRegs& rI, BRegs& rW, int bcur) {
-        const int tf = min(t + 2, nk - 1);                                // the last two steps re-fetch the last tile (never read)
+        const int tf = it0 + min(t + 2, nk - 1);                          // the last two steps re-fetch the last tile (never read)
         const int adma = ring(a_slot, 2);
         const unsigned char* at = lds + (size_t) a_slot * A_BYTES;
         const unsigned char* b1 = ldsB + (size_t) (bcur * 2) * GT_BTILE_BYTES;
@@ -1164,6 +1326,18 @@ __global__ __launch_bounds__(512) void q4_gemm_t16d2_kernel(const f16* __restric
 #undef GD2_SB
 
     // ---- epilogue ------------------------------------------------------------------------------------------------------
+    if (nparts > 1) {                                                    // fp32 slices (gate tile, then up tile) of this part of K: q4_gemm_tail_reduce_kernel<1>
+        float* wt = tail.ws + (size_t) (tseq * nparts + kz) * (2 * 256 * 128);
+#pragma unroll
+        for (int im = 0; im < 4; ++im)
+#pragma unroll
+            for (int in = 0; in < 4; ++in) {
+                float* p = wt + ((wm * 4 + im) * 16 + fr) * 128 + (wn * 4 + in) * 16 + fk * 4;
+                *(f32x4*) p = acc1[in][im];
+                *(f32x4*) (p + 256 * 128) = acc2[in][im];
+            }
+        return;
+    }
 #pragma unroll
     for (int im = 0; im < 4; ++im) {
         const int row = m0 + (wm * 4 + im) * 16 + fr;
@@ -1199,10 +1373,10 @@ __global__ __launch_bounds__(512) void q4_gemm_t16d2_kernel(const f16* __restric
 // out1 = silu(x @ W1) * (x @ W2) (silu != 0) or out1 = x @ W1, out2 = x @ W2.  Returns 1 when the pair is not eligible
 // for the dual kernel (the caller then runs the two products separately), 0 on success, otherwise an error.
 int launch_q4_gemm_dual(const Q4Matrix* w1, const Q4Matrix* w2, const f16* x, int rows, f16* out1, f16* out2, int silu,
-                        hipStream_t s)
+                        const PromptPrologue& pro, hipStream_t s)
 {
     static const bool off = getenv("EXL_GEMM_NO_DUAL") != nullptr;
-    if (off || rows <= 512 || w1->layout != EXL_LAYOUT_T16 || w2->layout != EXL_LAYOUT_T16 || w1->x_map || w2->x_map ||
+    if (off || rows <= 512 || w1->layout != EXL_LAYOUT_T16 || w2->layout != EXL_LAYOUT_T16 || !q4_same_map(w1, w2) ||
         w1->height != w2->height || w1->width != w2->width || w1->groupsize != w2->groupsize || w1->device != w2->device ||
         (size_t) rows * w1->height >= ((size_t) 1 << 32))
         return 1;
@@ -1211,13 +1385,16 @@ int launch_q4_gemm_dual(const Q4Matrix* w1, const Q4Matrix* w2, const f16* x, in
     if ((w1->groupsize & (w1->groupsize - 1)) == 0) { gshift = 0; while ((1 << gshift) < w1->groupsize) ++gshift; }
     const int mtiles = (rows + 255) / 256;
     const int ntiles = (N + GT_BN - 1) / GT_BN;
-    const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
+    GemmTail tail = {1 << 30, 1, nullptr};
+    int n_tail = 0;
+    const int grid = plan_gemm_tail(w1->device, mtiles, ntiles, K, 2, &tail, &n_tail);                 // the same split as either product alone: same bits
 #define GD_ARGS x, (const uint4*) w1->qweight, w1->qzeros, w1->scales, (const uint4*) w2->qweight, w2->qzeros, w2->scales, out1, out2, \
-                rows, K, N, gshift, w1->groupsize, mtiles, ntiles
+                rows, K, N, gshift, w1->groupsize, mtiles, ntiles, tail
     // power-of-two groups (one shift), 32-bit byte offsets into the weight / scale / activation arrays; anything else runs as the
     // separate products
     const bool pipelined_ok = gshift >= 5 && (uint64_t) K * (uint64_t) N < (1ull << 32) && (uint64_t) rows * (uint64_t) K < (1ull << 31);
     if (!pipelined_ok) return 1;
+    EXL_TRY(prompt_prologue(pro, w1, &x, rows, s));                           // RMSNorm and / or the (shared) act-order gather
     {
         const size_t smem = 3 * (size_t) 256 * 128 + 4 * GT_BTILE_BYTES;              // 160 KiB: the whole LDS of a CU
         static bool big_silu[EXL_MAX_DEVICES] = {}, big_pair[EXL_MAX_DEVICES] = {};
@@ -1228,6 +1405,11 @@ int launch_q4_gemm_dual(const Q4Matrix* w1, const Q4Matrix* w2, const f16* x, in
     }
 #undef GD_ARGS
     EXL_LAUNCH_CHECK();
+    if (n_tail) {
+        if (silu) hipLaunchKernelGGL(q4_gemm_tail_reduce_kernel<1>, dim3(n_tail), dim3(256), 0, s, out1, (f16*) nullptr, rows, N, 0, mtiles, ntiles, tail);
+        else      hipLaunchKernelGGL(q4_gemm_tail_reduce_kernel<2>, dim3(n_tail), dim3(256), 0, s, out1, out2, rows, N, 0, mtiles, ntiles, tail);
+        EXL_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -1244,7 +1426,7 @@ static int launch_gemm_t16m(const Q4Matrix* w, const f16* xin, int rows, f16* ou
     static bool big[EXL_MAX_DEVICES] = {};
     if (smem > 64 * 1024) EXL_TRY(exl_lds_opt_in((const void*) kfn, big));
     float* ws = nullptr;
-    if constexpr (KS > 1) EXL_TRY(exl_workspace(w->device, (size_t) KS * rows * N, &ws));
+    if constexpr (KS > 1) EXL_TRY(exl_gemm_workspace(w->device, (size_t) KS * rows * N, &ws));
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(WAVES_M * WAVES_N * 64), smem, s, xin, (const uint4*) w->qweight, w->qzeros,
                        w->scales, out, rows, K, N, gshift, w->groupsize, no_zero, mtiles, ntiles, ws);
     EXL_LAUNCH_CHECK();
@@ -1303,7 +1485,7 @@ int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
         // 0.397 / 0.405 / 0.423 ms without, 0.318 / 0.327 / 0.355 ms with (profiles/r03_tile128_validation.txt); validated by the
         // GEMM op tests and the cold-launch case t16m128k.  EXL_GEMM_NO_SPLITK=1 is the A/B switch.
         static const bool splitk = getenv("EXL_GEMM_NO_SPLITK") == nullptr;
-        if (splitk && rows > 256 && K % 256 == 0 && N % 4 == 0 && (size_t) 2 * rows * N <= exl_buffers(w->device)->workspace_floats)
+        if (splitk && rows > 256 && K % 256 == 0 && N % 4 == 0)
             return launch_gemm_t16m<2, 2, 4, 4, 2>(w, xin, rows, out, no_zero, gshift, s);
         return launch_gemm_t16m<2, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s);                // 128 x 128, 4 waves
     }

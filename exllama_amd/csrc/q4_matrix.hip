@@ -193,9 +193,36 @@ __global__ __launch_bounds__(256) void column_remap_kernel(const f16* __restrict
     }
 }
 
+// The same gather with the source row staged in LDS: one block per row copies it in with coalesced 16-byte loads and gathers from
+// LDS (2-byte reads that cost no cache-line transaction each), so HBM / L2 see one read and one write of the row.  width % 8 == 0,
+// width * 2 bytes <= 64 KiB (every Llama shape: 28672 columns = 56 KiB).
+__global__ __launch_bounds__(512) void column_remap_lds_kernel(const f16* __restrict__ x, f16* __restrict__ x_new,
+                                                               const uint32_t* __restrict__ x_map, int width)
+{
+    extern __shared__ __attribute__((aligned(16))) f16 srow[];
+    const int row = blockIdx.x;
+    const int nvec = width >> 3;
+    const f16* xr = x + (size_t) row * width;
+    for (int i = threadIdx.x; i < nvec; i += 512) *(f16x8*) (srow + i * 8) = *(const f16x8*) (xr + i * 8);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nvec; i += 512) {
+        const uint4 m0 = *(const uint4*) (x_map + i * 8);
+        const uint4 m1 = *(const uint4*) (x_map + i * 8 + 4);
+        f16x8 o;
+        o[0] = srow[m0.x]; o[1] = srow[m0.y]; o[2] = srow[m0.z]; o[3] = srow[m0.w];
+        o[4] = srow[m1.x]; o[5] = srow[m1.y]; o[6] = srow[m1.z]; o[7] = srow[m1.w];
+        *(f16x8*) (x_new + (size_t) row * width + i * 8) = o;
+    }
+}
+
 int launch_column_remap(const f16* x, f16* x_new, int height, int width, const uint32_t* x_map, hipStream_t s)
 {
     if (height <= 0) return 0;
+    if (width % 8 == 0 && (size_t) width * 2 <= 64 * 1024 && width >= 1024) {
+        hipLaunchKernelGGL(column_remap_lds_kernel, dim3(height), dim3(512), (size_t) width * 2, s, x, x_new, x_map, width);
+        EXL_LAUNCH_CHECK();
+        return 0;
+    }
     dim3 grid(((width + 7) / 8 + 255) / 256, height);
     hipLaunchKernelGGL(column_remap_kernel, grid, dim3(256), 0, s, x, x_new, x_map, width);
     EXL_LAUNCH_CHECK();

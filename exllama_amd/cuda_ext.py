@@ -197,9 +197,10 @@ class _ExllamaExt:
         return bool(done.value)
 
     def q4_qkv_rope_cache(self, x, wq, wk, wv, q_out, sin, cos, key_cache, value_cache, q_len, past_len, num_heads, num_kv_heads,
-                          head_dim, max_seq_len):
+                          head_dim, max_seq_len, norm_weight=None, eps=0.0):
         """q_out = rope(x @ Wq), key_cache <- rope(x @ Wk), value_cache <- x @ Wv at past_len in one kernel (include/exl_amd.h:
-        exl_q4_qkv_rope_cache).  x: [bsz * q_len, hidden].  Returns False when the shapes are not eligible: nothing was launched."""
+        exl_q4_qkv_rope_cache; with `norm_weight` exl_q4_attn_prompt: x is the residual stream and RMSNorm runs as the launch's
+        prologue).  x: [bsz * q_len, hidden].  Returns False when the shapes are not eligible: nothing was launched."""
         if x.dtype != torch.float16 or q_out.dtype != torch.float16 or not x.is_contiguous() or not q_out.is_contiguous():
             raise RuntimeError("q4_qkv_rope_cache: x and q_out must be contiguous fp16")
         rows = x.size(0)
@@ -207,9 +208,22 @@ class _ExllamaExt:
             raise RuntimeError("q4_qkv_rope_cache: x, q_out and q_len have incompatible shapes")
         done = C.c_int()
         with _Guard(x.device):
-            check(self._lib.exl_q4_qkv_rope_cache(wq, wk, wv, x.data_ptr(), rows // q_len, q_len, q_out.data_ptr(), sin.data_ptr(), cos.data_ptr(),
-                                                  key_cache.data_ptr(), value_cache.data_ptr(), num_heads, num_kv_heads, head_dim, past_len,
-                                                  max_seq_len, _stream(x), C.byref(done)), "q4_qkv_rope_cache")
+            check(self._lib.exl_q4_attn_prompt(wq, wk, wv, x.data_ptr(), _ptr(norm_weight), float(eps), rows // q_len, q_len, q_out.data_ptr(),
+                                               sin.data_ptr(), cos.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), num_heads,
+                                               num_kv_heads, head_dim, past_len, max_seq_len, _stream(x), C.byref(done)), "q4_qkv_rope_cache")
+        return bool(done.value)
+
+    def q4_mlp_prompt(self, x, norm_weight, eps, gate, up, down, act):
+        """x += down(silu(gate(n)) * up(n)), n = rms_norm(x), for a prompt of more than 512 rows (include/exl_amd.h: exl_q4_mlp_prompt).
+        x: [rows, hidden] in place; act: scratch [rows, intermediate].  Returns False when not eligible: nothing was launched."""
+        for t, n in ((x, "x"), (norm_weight, "rms_norm_weight"), (act, "act")):
+            _req_dtype(t, torch.float16, n)
+            _req_cuda(t, n)
+        _req(x.is_contiguous() and act.is_contiguous() and act.size(0) == x.size(0), "x and act have incompatible shapes")
+        done = C.c_int()
+        with _Guard(x.device):
+            check(self._lib.exl_q4_mlp_prompt(x.data_ptr(), norm_weight.data_ptr(), float(eps), gate, up, down, x.size(0), act.data_ptr(),
+                                              _stream(x), C.byref(done)), "q4_mlp_prompt")
         return bool(done.value)
 
     def q4_reconstruct(self, w, out):

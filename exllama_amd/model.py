@@ -230,9 +230,19 @@ class ExLlamaMLP:
         ext.silu_mul(g, u)
         return g
 
-    def forward_residual(self, normed, hidden, lora):
-        """hidden += down(silu(gate(normed)) * up(normed)); residual fused in the down_proj epilogue."""
+    def forward_residual(self, normed, hidden, lora, norm=None):
+        """hidden += down(silu(gate(normed)) * up(normed)); residual fused in the down_proj epilogue.  `normed` None + `norm`: the
+        post-attention RMSNorm has not run yet -- a long prompt without adapters goes through exl_q4_mlp_prompt (norm -> fused
+        gate / up / SiLU kernel -> down_proj), otherwise the norm runs here."""
         tp = self.config.tp
+        if normed is None:
+            if tp is None and not any(p.lora_applies(lora) or p.bias is not None for p in (self.gate_proj, self.up_proj, self.down_proj)):
+                h2 = hidden.view(-1, hidden.shape[-1])
+                if h2.shape[0] > 512:
+                    act = torch.empty((h2.shape[0], self.gate_proj.out_features), dtype=torch.float16, device=hidden.device)
+                    if ext.q4_mlp_prompt(h2, norm.weight, norm.variance_epsilon, self.gate_proj.q4, self.up_proj.q4, self.down_proj.q4, act):
+                        return
+            normed = norm.forward(hidden)
         if tp is None:
             self.down_proj.forward(self._activation(normed, lora), lora, out=hidden, accumulate=True)
         elif self.down_gather:
@@ -285,20 +295,27 @@ class ExLlamaAttention:
         ext.attention(q, kc, vc, attn, past_len, cfg.num_attention_heads)
         ext.q4_attn_2(hidden_states, attn, self.o_proj.q4, oa, ob, lora_temp)
 
-    def forward_residual(self, normed, hidden, cache, buffer, lora):
-        """General path: hidden += o_proj(attention(rope(q), cache <- rope(k), v)) (reference: model.py:421-502)."""
+    def forward_residual(self, normed, hidden, cache, buffer, lora, norm=None):
+        """General path: hidden += o_proj(attention(rope(q), cache <- rope(k), v)) (reference: model.py:421-502).
+        `normed` None + `norm`: the input RMSNorm has not run yet -- the fused prompt launch takes it as its prologue
+        (exl_q4_attn_prompt), otherwise it runs here."""
         cfg = self.config
-        bsz, q_len, _ = normed.shape
+        bsz, q_len, _ = hidden.shape
         past_len = cache.current_seq_len
         kc, vc = cache.key_states[self.index], cache.value_states[self.index]
         q = None
         if not any(p.lora_applies(lora) or p.bias is not None for p in (self.q_proj, self.k_proj, self.v_proj)):
             # long prompts: the three projections, both RoPEs and the cache write as one kernel (exl_q4_qkv_rope_cache)
-            q = torch.empty((bsz, q_len, cfg.num_attention_heads * cfg.head_dim), dtype=torch.float16, device=normed.device)
-            if not ext.q4_qkv_rope_cache(normed.view(-1, normed.shape[-1]), self.q_proj.q4, self.k_proj.q4, self.v_proj.q4,
+            q = torch.empty((bsz, q_len, cfg.num_attention_heads * cfg.head_dim), dtype=torch.float16, device=hidden.device)
+            src = hidden if normed is None else normed
+            if not ext.q4_qkv_rope_cache(src.view(-1, src.shape[-1]), self.q_proj.q4, self.k_proj.q4, self.v_proj.q4,
                                          q.view(-1, q.shape[-1]), self.sin, self.cos, kc, vc, q_len, past_len,
-                                         cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cache.max_seq_len):
+                                         cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cache.max_seq_len,
+                                         norm_weight=norm.weight if normed is None else None,
+                                         eps=norm.variance_epsilon if normed is None else 0.0):
                 q = None
+        if q is None and normed is None:
+            normed = norm.forward(hidden, buffer)
         if q is None:
             q = self.q_proj.forward(normed, lora)
             k = self.k_proj.forward(normed, lora)
@@ -345,14 +362,12 @@ class ExLlamaDecoderLayer:
             return hidden_states
         if cfg.fused_attn and rows == 1:
             self.self_attn.fused(hidden_states, cache, buffer, self.input_layernorm, lora)
-        else:
-            normed = self.input_layernorm.forward(hidden_states, buffer)
-            self.self_attn.forward_residual(normed, hidden_states, cache, buffer, lora)
+        else:                                                        # (the norms run inside: a long prompt takes them as launch prologues)
+            self.self_attn.forward_residual(None, hidden_states, cache, buffer, lora, norm=self.input_layernorm)
         if cfg.fused_mlp_thd > 0 and rows <= cfg.fused_mlp_thd:
             self.mlp.fused(hidden_states, buffer, self.post_attention_layernorm, lora)
         else:
-            normed = self.post_attention_layernorm.forward(hidden_states, buffer)
-            self.mlp.forward_residual(normed, hidden_states, lora)
+            self.mlp.forward_residual(None, hidden_states, lora, norm=self.post_attention_layernorm)
         return hidden_states
 
 

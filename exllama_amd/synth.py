@@ -61,8 +61,8 @@ PRESETS = {"7b": LLAMA_7B, "13b": LLAMA_13B, "33b": LLAMA_33B, "65b": LLAMA_65B,
            "tiny_hd128_gqa": LLAMA_TINY_HD128_GQA}
 
 
-def make_q4_linear(K, N, groupsize, act_order, gen, device, zeros="sym", std=None):
-    """One GPTQ linear. Returns dict(qweight, qzeros, scales[, g_idx])."""
+def make_q4_linear(K, N, groupsize, act_order, gen, device, zeros="sym", std=None, g_idx=None):
+    """One GPTQ linear. Returns dict(qweight, qzeros, scales[, g_idx]).  `g_idx`: reuse this group index instead of drawing one."""
     G = K // groupsize
     qweight = torch.randint(-2**31, 2**31 - 1, (K // 8, N), dtype=torch.int64, generator=gen, device=device).to(torch.int32)
     if zeros == "sym":
@@ -73,7 +73,9 @@ def make_q4_linear(K, N, groupsize, act_order, gen, device, zeros="sym", std=Non
         std = 0.02 * math.sqrt(4096.0 / K)
     scales = ((torch.rand((G, N), generator=gen, device=device) + 0.5) * (std / 4.61)).to(torch.float16)
     out = {"qweight": qweight, "qzeros": qzeros, "scales": scales}
-    if act_order:
+    if act_order and g_idx is not None:
+        out["g_idx"] = g_idx.clone()
+    elif act_order:
         perm = torch.randperm(K, generator=gen, device=device)
         g_idx = torch.empty(K, dtype=torch.int32, device=device)
         g_idx[perm] = (torch.arange(K, device=device) // groupsize).to(torch.int32)
@@ -82,7 +84,12 @@ def make_q4_linear(K, N, groupsize, act_order, gen, device, zeros="sym", std=Non
 
 
 def make_checkpoint(dims, groupsize=128, act_order=False, seed=0, device="cpu", zeros="sym", num_layers=None):
-    """Full tensor dict for a Llama of shape `dims` (optionally truncated to `num_layers`)."""
+    """Full tensor dict for a Llama of shape `dims` (optionally truncated to `num_layers`).
+
+    act_order: False; True = every matrix draws its own row permutation (the general case the reference's per-matrix x_map allows);
+    "gptq" = what GPTQ with desc_act actually writes: the permutation is argsort(diag(H)) of the layer INPUT's Hessian, and the
+    matrices quantised against the same input -- q / k / v, and gate / up -- see the same H (GPTQ-for-LLaMa / AutoGPTQ quantise
+    them as one group of the sequential pass), so their g_idx tensors are identical; o_proj and down_proj have their own."""
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     L = dims.num_hidden_layers if num_layers is None else num_layers
@@ -99,7 +106,10 @@ def make_checkpoint(dims, groupsize=128, act_order=False, seed=0, device="cpu", 
         for name, (K, N) in (("self_attn.q_proj", (h, h)), ("self_attn.k_proj", (h, kvd)),
                              ("self_attn.v_proj", (h, kvd)), ("self_attn.o_proj", (h, h)),
                              ("mlp.gate_proj", (h, I)), ("mlp.up_proj", (h, I)), ("mlp.down_proj", (I, h))):
-            lin = make_q4_linear(K, N, groupsize, act_order, gen, device, zeros=zeros)
+            share = None
+            if act_order == "gptq" and name in ("self_attn.k_proj", "self_attn.v_proj", "mlp.up_proj"):
+                share = t[f"{p}.{'self_attn.q_proj' if name.startswith('self_attn') else 'mlp.gate_proj'}.g_idx"]
+            lin = make_q4_linear(K, N, groupsize, bool(act_order), gen, device, zeros=zeros, g_idx=share)
             for k, v in lin.items():
                 t[f"{p}.{name}.{k}"] = v
     return t

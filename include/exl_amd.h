@@ -106,7 +106,7 @@ int exl_q4_matmul_gemm(void* w, const void* x, int x_height, void* out, int no_z
 /* Prompt-pass fusion with no counterpart in the reference (it runs gate_proj, up_proj and the SiLU kernel one after the
  * other, model.py:266-273): out1 = silu(x @ W1) * (x @ W2) when silu != 0, else out1 = x @ W1 and out2 = x @ W2, in ONE
  * kernel that shares the activation tile between the two products.  Only for two T16 matrices of identical shape and
- * group size without act-order and more than 512 rows: otherwise nothing is launched and *launched = 0 -- the caller then
+ * group size (act-order only when both carry the same row permutation: gathered once) and more than 512 rows: otherwise nothing is launched and *launched = 0 -- the caller then
  * issues the separate calls (exl_q4_matmul twice + exl_silu_mul). */
 int exl_q4_matmul_dual(void* w1, void* w2, const void* x, int x_height, void* out1, void* out2, int silu, void* stream,
                        int* launched);
@@ -118,6 +118,20 @@ int exl_q4_matmul_dual(void* w1, void* w2, const void* x, int x_height, void* ou
 int exl_q4_qkv_rope_cache(void* wq, void* wk, void* wv, const void* x, int bsz, int q_len, void* q_out, const void* sin,
                           const void* cos, void* key_cache, void* value_cache, int heads, int kv_heads, int head_dim,
                           int past_len, int max_seq_len, void* stream, int* launched);
+/* The same launch with the layer's input RMSNorm as its prologue (x is the residual stream, norm_w != NULL; reference:
+ * model.py:524-530 -- rms_norm, then the ops above).  Act-order q / k / v matrices are accepted when they share one row
+ * permutation (GPTQ quantises them against the same input, so their g_idx tensors are identical): the norm kernel then writes
+ * its rows through that map -- the reference's three column_remap passes (q4_matmul.cu:320-325) cost nothing.  norm_w == NULL:
+ * exactly exl_q4_qkv_rope_cache (x already normalised; a shared map is gathered once).  Borrows temp_state. */
+int exl_q4_attn_prompt(void* wq, void* wk, void* wv, const void* x, const void* norm_w, float eps, int bsz, int q_len, void* q_out,
+                       const void* sin, const void* cos, void* key_cache, void* value_cache, int heads, int kv_heads, int head_dim,
+                       int past_len, int max_seq_len, void* stream, int* launched);
+/* The MLP half of a layer for a prompt of more than 512 rows, in place on the residual stream x [rows, hidden]:
+ * x += down( silu(gate(n)) * up(n) ), n = RMSNorm(x) (reference: model.py:266-273 + :546-552: rms_norm, q4_matmul x 2, silu_mul,
+ * q4_matmul with the residual) as norm(+ act-order gather) -> exl_q4_matmul_dual's kernel -> down_proj GEMM.  `act`: scratch of
+ * rows * intermediate halves.  Same `launched` protocol; gate / up must be dual-eligible (act-order: one shared map). */
+int exl_q4_mlp_prompt(void* x, const void* norm_w, float eps, void* gate, void* up, void* down, int rows, void* act, void* stream,
+                      int* launched);
 /* out = x @ W + (x @ lora_A) @ lora_B   (reference: exllama_ext.cpp:245-324 q4_matmul_lora) */
 int exl_q4_matmul_lora(void* w, const void* x, int x_height, void* out, const void* lora_a, const void* lora_b,
                        int rank, void* lora_temp, void* stream);

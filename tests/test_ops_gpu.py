@@ -77,6 +77,21 @@ def _close(got, ref, ulps=2.0):
             assert not bad.any(), f"{int(bad.sum())} of {nblk} 16-element blocks off (first: block {int(np.argmax(bad))})"
 
 
+def _same_up_to_fp32_order(a, b):
+    """Two launches of the same product whose K loops are cut differently (a tile of a partly filled last round is split along K,
+    q4_gemm.hip: plan_gemm_tail) add the same fp32 terms in another order: the fp16 results are equal except where the fp32 sums
+    straddle a rounding boundary -- at most one fp16 step at the sum's magnitude (rotated / cancelled values: at the output scale),
+    and only for a small share of the elements."""
+    if torch.equal(a, b):
+        return
+    af, bf = a.float(), b.float()
+    assert torch.isfinite(af).all() and torch.isfinite(bf).all()
+    scale = float(torch.maximum(af.abs(), bf.abs()).max())
+    d = (af - bf).abs()
+    assert float(d.max()) <= scale * 2.0 ** -10, (float(d.max()), scale)
+    assert float((d > 0).float().mean()) <= 0.05, float((d > 0).float().mean())
+
+
 # ---------------------------------------------------------------------------------------------------------
 # make_q4 / act-order / reconstruct / column_remap: integer + bit-exact fp16
 # ---------------------------------------------------------------------------------------------------------
@@ -216,7 +231,10 @@ GEMM_SHAPES = [(256, 128, 64, True, 16), (512, 96, 128, False, 33), (704, 256, 6
                # 257 .. 512 rows: the 128-row tile kernel (q4_gemm_t16m_kernel<2, 2, 4, 4>)
                (4096, 4096, 128, False, 300), (11008, 4096, 128, True, 512), (4096, 11008, 32, True, 400), (2048, 512, 64, False, 257),
                # > 512 rows: the 256-row pipelined tile, ragged last m-tile
-               (4096, 4096, 128, False, 600), (1408, 512, 64, True, 530), (512, 11008, 32, False, 777)]
+               (4096, 4096, 128, False, 600), (1408, 512, 64, True, 530), (512, 11008, 32, False, 777),
+               # more tiles than CUs with a partly filled last round: its tiles are cut along K (plan_gemm_tail): 13B o_proj (320 tiles,
+               # act-order: the LDS-staged gather), 7B gate_proj with a ragged last m-tile (430 tiles)
+               (5120, 5120, 128, True, 2048), (4096, 11008, 128, False, 1100)]
 
 
 @pytest.mark.parametrize("K,N,gs,act,rows", GEMM_SHAPES)
@@ -310,7 +328,7 @@ def test_q4_matmul_dual_equals_separate_products(ce, K, N, gs, rows):
     assert ce.exllama_ext.q4_matmul_dual(x, h1, h2, act, None, silu=True)
     ce.exllama_ext.silu_mul(g, u)
     assert torch.equal(act, g)
-    if K * N <= 1 << 21:
+    if K * N <= 1 << 21 or rows == 2048:                                        # (2048 rows: the 7B shape, whose last round is cut along K)
         ref = O.silu_mul(O.q4_matmul_recons(x.cpu().numpy(), **_oracle_w(lin1)), O.q4_matmul_recons(x.cpu().numpy(), **_oracle_w(lin2)))
         _close(act.cpu().numpy(), ref, ulps=4.0)
 
@@ -370,6 +388,77 @@ def test_q4_qkv_rope_cache_equals_separate_ops(ce, hidden, heads, kvh, gs, bsz, 
     assert float(kc2[:, :, past + q_len:].float().min()) == 7.0 and float(vc2[:, :, past + q_len:].float().max()) == -3.0     # beyond the prompt: untouched
     # declines short prompts and act-order
     assert not ext.q4_qkv_rope_cache(x[:256].contiguous(), hq, hk, hv, q2.view(-1, heads * hd)[:256], sin, cos, kc2, vc2, 256 // bsz, 0, heads, kvh, hd, max_seq)
+
+
+@pytest.mark.parametrize("hidden,heads,kvh,inter,gs,rows", [(1024, 8, 2, 2816, 64, 600), (5120, 40, 40, 13824, 128, 2048)])
+def test_prompt_fusions_take_act_order_matrices_that_share_a_map(ce, hidden, heads, kvh, inter, gs, rows):
+    """GPTQ with act-order quantises q / k / v (and gate / up) against the same input, so their g_idx tensors are identical
+    (synth.make_checkpoint(act_order="gptq")).  The fused prompt launches then gather ONCE -- inside the RMSNorm kernel when the
+    norm is their prologue (exl_q4_attn_prompt, exl_q4_mlp_prompt) -- and must reproduce, bit for bit, what the reference issues:
+    rms_norm, column_remap + matmul per matrix, rope_ x 2, the cache scatter; rms_norm, two matmuls, silu_mul, matmul + residual
+    (model.py:431-445, :266-273; q4_matmul.cu:320-325).  Matrices with DIFFERENT maps are declined (separate ops)."""
+    hd, max_seq = 128, rows + 5
+    ext = ce.exllama_ext
+    keep = _prep_buffers(ce, rows, hidden, inter)
+    gen = torch.Generator().manual_seed(hidden + rows)
+    std = 0.02 * (4096 / hidden) ** 0.5
+    lq, _ = _lin(hidden, heads * hd, gs, True, seed=1 + hidden, std=std)
+    share = lambda n, seed, K, g: synth.make_q4_linear(K, n, gs, True, torch.Generator().manual_seed(seed), "cpu", zeros="rand", std=std, g_idx=g)
+    lk, lv = share(kvh * hd, 2 + hidden, hidden, lq["g_idx"]), share(kvh * hd, 3 + hidden, hidden, lq["g_idx"])
+    lg, _ = _lin(hidden, inter, gs, True, seed=4 + hidden, std=std)
+    lu = share(inter, 5 + hidden, hidden, lg["g_idx"])
+    ld, _ = _lin(inter, hidden, gs, True, seed=6 + hidden, std=0.02 * (4096 / inter) ** 0.5)
+    lk_own, _ = _lin(hidden, kvh * hd, gs, True, seed=7 + hidden, std=std)            # its own permutation
+    (hq, _0), (hk, _1), (hv, _2), (hg, _3), (hu, _4), (hdn, _5), (hko, _6) = (_handle(ce, l) for l in (lq, lk, lv, lg, lu, ld, lk_own))
+    x = torch.randn(rows, hidden, generator=gen).half().to(DEV)
+    w = (1 + 0.1 * torch.randn(hidden, generator=gen)).half().to(DEV)
+    pos = torch.arange(max_seq, dtype=torch.float32)[:, None] * (10000.0 ** (-torch.arange(0, hd, 2, dtype=torch.float32) / hd))[None, :]
+    emb = torch.cat([pos, pos], dim=-1)
+    sin, cos = emb.sin().half().to(DEV), emb.cos().half().to(DEV)
+    # ---- attention front half: the reference's sequence
+    normed = ce.ext_rms_norm(x, w, 1e-6)
+    q = torch.empty((1, rows, heads * hd), dtype=torch.float16, device=DEV)
+    k = torch.empty((1, rows, kvh * hd), dtype=torch.float16, device=DEV)
+    v = torch.empty_like(k)
+    for h_, o_ in ((hq, q), (hk, k), (hv, v)):
+        ext.q4_matmul_gemm(normed, h_, o_.view(rows, -1))                       # column_remap inside, per matrix
+    ext.rope_(q, sin, cos, 0, heads, hd)
+    ext.rope_(k, sin, cos, 0, kvh, hd)
+    kc = torch.full((1, kvh, max_seq, hd), 7.0, dtype=torch.float16, device=DEV)
+    vc = torch.full_like(kc, -3.0)
+    ext.update_cache(k, v, kc, vc, 0)
+    for norm_w, src in ((w, x), (None, normed)):                                # norm as the prologue / input already normalised
+        q2, kc2, vc2 = torch.full_like(q, float("nan")), torch.full_like(kc, 7.0), torch.full_like(vc, -3.0)
+        assert ext.q4_qkv_rope_cache(src, hq, hk, hv, q2.view(rows, -1), sin, cos, kc2, vc2, rows, 0, heads, kvh, hd, max_seq,
+                                     norm_weight=norm_w, eps=1e-6)
+        # (the separate q / k / v launches of the 13B shape split their last round along K, the fused launch does not)
+        _same_up_to_fp32_order(q2, q); _same_up_to_fp32_order(kc2, kc); _same_up_to_fp32_order(vc2, vc)
+    assert not ext.q4_qkv_rope_cache(x, hq, hko, hv, q2.view(rows, -1), sin, cos, kc2, vc2, rows, 0, heads, kvh, hd, max_seq, norm_weight=w, eps=1e-6)
+    # ---- MLP half
+    g = torch.empty((rows, inter), dtype=torch.float16, device=DEV)
+    u = torch.empty_like(g)
+    ext.q4_matmul_gemm(normed, hg, g)
+    ext.q4_matmul_gemm(normed, hu, u)
+    ext.silu_mul(g, u)
+    want = x.clone()
+    ext.q4_matmul_gemm(g, hdn, want, no_zero=True)                              # residual added in the epilogue
+    got = x.clone()
+    act = torch.full_like(g, float("nan"))
+    assert ext.q4_mlp_prompt(got, w, 1e-6, hg, hu, hdn, act)
+    assert torch.equal(act, g) and torch.equal(got, want)
+    # different maps for gate and up: declined, nothing written
+    lu_own, _ = _lin(hidden, inter, gs, True, seed=8 + hidden, std=std)
+    huo, _7 = _handle(ce, lu_own)
+    untouched = x.clone()
+    assert not ext.q4_mlp_prompt(untouched, w, 1e-6, hg, huo, hdn, act)
+    assert torch.equal(untouched, x)
+    if hidden <= 1024:                                                          # and the oracle, at the size it finishes in seconds
+        xn = O.rms_norm(x.cpu().numpy(), w.cpu().numpy(), 1e-6)
+        with np.errstate(over="ignore"):
+            a_ref = O.silu_mul(O.q4_matmul_recons(xn, **_oracle_w(lg)), O.q4_matmul_recons(xn, **_oracle_w(lu)))
+            ref = O.q4_matmul_recons(a_ref, **_oracle_w(ld), out=x.cpu().numpy())
+        _close(got.cpu().numpy(), ref, ulps=4.0)
+        _close(q.cpu().numpy().reshape(rows, -1), O.rope(O.q4_matmul_recons(xn, **_oracle_w(lq)).reshape(1, -1), sin.cpu().numpy(), cos.cpu().numpy(), 0, heads, hd).reshape(rows, -1), ulps=2.0)
 
 
 @pytest.mark.parametrize("hidden,vocab,rows", [(512, 640, 1), (4096, 32000, 1), (4096, 32000, 5), (1024, 777, 8)])
