@@ -241,3 +241,52 @@ def test_fused_ops_name_the_offending_tensor_without_a_gpu():
         ext.q4_mlp(h.view(1, 64), w, 1e-6, 0, 0, 0, none, none, none, none, none, none, none)
     with pytest.raises(RuntimeError, match="incorrect datatype"):
         ext.q4_attn(h, w, 1e-6, h.float(), h, h, 0, 0, 0, w, w, 1, 0, 1, 1, 64, h, h, 16, none, none, none, none, none, none, none)
+
+
+def test_compiled_binding_mirrors_the_ctypes_methods():
+    """exllama_amd/_exl_fast.so (csrc/binding/exl_fast.cpp) replaces the per-token methods of cuda_ext.exllama_ext: it must load, be
+    what the module dispatches to, and expose the same parameter lists (names, order, defaults) as the ctypes methods it replaces --
+    they stay in the class as the A/B reference."""
+    import inspect
+    from exllama_amd import cuda_ext
+    fast = cuda_ext.FAST_BINDING
+    assert fast is not None, "the compiled binding is not active (EXL_NO_FAST_BINDING set?)"
+    for name in ("q4_matmul", "rms_norm", "rope_", "q4_attn", "q4_attn_2", "q4_mlp", "attention"):
+        f = getattr(fast, name)
+        assert getattr(cuda_ext.exllama_ext, name) is f
+        py = inspect.signature(getattr(type(cuda_ext.exllama_ext), name))
+        want = [(p.name, p.default) for p in list(py.parameters.values())[1:]]          # without self
+        got = [(p.name, p.default) for p in inspect.signature(f).parameters.values()]
+        assert got == want, (name, got, want)
+    assert cuda_ext.rms_norm is fast.rms_norm and cuda_ext.q4_matmul is fast.q4_matmul and cuda_ext.rope_ is fast.rope_
+
+
+def test_compiled_binding_raises_what_the_ctypes_path_raises():
+    """Same RuntimeError / TypeError behaviour on bad arguments, checked without a GPU (every check precedes the native call)."""
+    import torch
+    from exllama_amd import cuda_ext
+    fast, ext_cls = cuda_ext.FAST_BINDING, type(cuda_ext.exllama_ext)
+    slow = cuda_ext.exllama_ext
+    h = torch.zeros((2, 64), dtype=torch.float16)
+    none = cuda_ext.none_tensor
+    cases = [
+        ("rms_norm", (h, h[0], h, 1e-6)),                      # CPU tensors
+        ("rms_norm", (h.float(), h[0], h, 1e-6)),              # wrong dtype
+        ("rope_", (h, h, h, 0, 1, 64)),
+        ("q4_matmul", (h, 0, h)),
+        ("q4_attn_2", (h, h, 0, none, none, none)),
+        ("q4_mlp", (h, h[0], 1e-6, 0, 0, 0, none, none, none, none, none, none, none)),
+        ("attention", (h.view(1, 2, 64), h.view(1, 1, 2, 64), h.view(1, 1, 2, 64), h.view(1, 2, 64), 0, 1)),
+    ]
+    for name, args in cases:
+        errs = []
+        for fn in (getattr(fast, name), lambda *a, _n=name: getattr(ext_cls, _n)(slow, *a)):
+            with pytest.raises(RuntimeError) as e:
+                fn(*args)
+            errs.append(str(e.value))
+        key = "incorrect datatype" if "incorrect datatype" in errs[1] else "HIP device" if "HIP device" in errs[1] else "handle"
+        assert key in errs[0] and key in errs[1], (name, errs)
+    with pytest.raises(TypeError):
+        fast.rms_norm(h, h)
+    with pytest.raises(TypeError):
+        fast.attention(h, h, h, h, 0, 1, bogus=1)

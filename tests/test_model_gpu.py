@@ -244,22 +244,23 @@ def test_perplexity_module_chunk_and_token_modes_and_oracle():
 
 def test_perplexity_agrees_to_the_second_decimal_of_the_readme_range():
     """north_star: "perplexity equal to 2 dp".  The reference prints perplexity with 4 decimals (perplexity.py:121-138) and its
-    README quotes 5.68 .. 3.53 for 7B .. 65B; half a unit of the second decimal there is a RELATIVE 8.8e-4 (0.005 / 5.68).  No real
-    checkpoint exists here, so the claim is tested in relative form on BASELINE configs[1] layer shapes (two layers, vocabulary
-    32000, head x 3 -> perplexity ~73) over 1535 tokens SAMPLED from the model's own next-token distribution (decode path):
-      * whole-chunk HIP path (MFMA GEMMs, flash attention) vs CPU oracle, neither of which chose the text: < 4.4e-4 relative
-        (measured 1.3e-4: 72.948 vs 72.939 -- at the README's 5.68 that is 0.0007);
-      * token-by-token HIP path vs oracle: < 1.76e-3 (measured 7.8e-4: 72.882).  This path SAMPLED the text, and a path that
-        samples the text scores it with its own entropy while every other path pays the KL divergence to it on top (~s^2 / 2 for
-        logit noise of standard deviation s nats): its perplexity is the lowest of the three by construction, here by 8e-4.
-    Absolute |delta| < 0.005 on a synthetic model would need perplexity x KL < 0.005; sharpening the head lowers the perplexity and
-    raises s in proportion (first attempt, 512-wide tiny preset, head x 10, 144 tokens: 6.704 / 6.560 / 6.692), so the relative form
-    is what a random-weight model can pin."""
+    README quotes 5.68 .. 3.53 for 7B .. 65B.  No real checkpoint exists here, so the claim is tested on BASELINE configs[1] layer
+    shapes (two layers, vocabulary 32000) with the head sharpened until the model's own text scores IN that range (head x 4.6:
+    next-token entropy 1.7 - 1.8 nats, perplexity ~6; calibrated on the CPU oracle), over 1535 tokens SAMPLED from the model's
+    next-token distribution (decode path):
+      * whole-chunk HIP path (MFMA GEMMs, flash attention) vs CPU oracle, neither of which chose the text: ABSOLUTE
+        |delta| < 0.005, i.e. equal to the second decimal (first-order logit noise averages out over the tokens: relative 1.3e-4
+        measured at head x 3 in round 3);
+      * token-by-token HIP path vs oracle: this path SAMPLED the text, and a path that samples the text scores it with its own
+        entropy while every other path pays the KL divergence to it on top (log E_p[exp(d)] - E_p[d] ~ s^2 / 2 for logit noise of
+        standard deviation s nats, whatever the text): its perplexity is the lowest of the three by construction.  The term is
+        second order in the fp16 noise of the logits (s ~ 0.04 - 0.06 nats at logits of +-30, fp16 spacing 0.016 - 0.03 there), so it is
+        bounded, not equal: |delta| < 0.02 absolute, measured value recorded through EXL_TOL_STATS (profiles/)."""
     from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
     from exllama_amd.perplexity import Perplexity
     dims, L, S = synth.PRESETS["7b"], 2, 1536
     tensors = synth.make_checkpoint(dims, groupsize=128, act_order=False, seed=23, device="cpu", zeros="rand", num_layers=L)
-    tensors["lm_head.weight"] = (tensors["lm_head.weight"].float() * 3.0).half()
+    tensors["lm_head.weight"] = (tensors["lm_head.weight"].float() * 4.6).half()
     cfg = ExLlamaConfig(synth.config_dict(dims, L))
     cfg.max_seq_len = S + 64
     cfg.max_input_len = 2048
@@ -292,9 +293,9 @@ def test_perplexity_agrees_to_the_second_decimal_of_the_readme_range():
     if stats:
         with open(stats, "a") as f:
             f.write(json.dumps({"tag": "perplexity whole / token / oracle", "values": [whole, token, ref], "tokens": n}) + "\n")
-    assert 2.0 < ref < 200.0, ref
-    assert abs(whole - ref) / ref < 4.4e-4, (whole, token, ref)
-    assert abs(token - ref) / ref < 1.76e-3 and token < whole, (whole, token, ref)
+    assert 3.0 < ref < 12.0, ref                                     # the README's range (5.68 .. 3.53) or just above it
+    assert abs(whole - ref) < 0.005, (whole, token, ref)             # equal to the second decimal
+    assert abs(token - ref) < 0.02 and token < whole + 0.005, (whole, token, ref)
     model.free_unmanaged()
 
 
