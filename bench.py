@@ -485,6 +485,33 @@ def main():
                                           "note": "BASELINE configs[0] prompt length (<= 256 rows: the short-prompt GEMM, csrc/q4_gemm_skinny.hip; op-by-op eager launches)"}
         result["other_lengths"] = extra
 
+        # ---- the reference's own generation loop on THIS repository's model.py (test_benchmark_inference.py:182-197: forward, then
+        # torch.argmax on the logits, per token -- no generate_greedy): (a) forward() replaying the executor's hipGraph, the token
+        # picked by a torch kernel between replays; (b) the executor off: forward() through the op-by-op fused ops (q4_attn ->
+        # attention -> q4_attn_2 -> q4_mlp per layer, compiled binding), what the reference's model.py runs on the shim too, minus
+        # its ATen attention.  With `value` (argmax inside the graph) and dropin_reference_model_py these are the tiers of the path.
+        def host_loop(n, ctx):
+            cache.current_seq_len = 0
+            lg = model.forward(ids[:, :ctx], cache)
+            for _ in range(8):                                    # warm
+                lg = model.forward(lg[0, -1].argmax().view(1, 1), cache)
+            cache.current_seq_len = ctx
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                lg = model.forward(lg[0, -1].argmax().view(1, 1), cache)
+            torch.cuda.synchronize()
+            return n / (time.perf_counter() - t)
+        tiers = {}
+        if use_graph:
+            tiers["forward_graph_replay_plus_torch_argmax"] = {"worst": round(host_loop(G, S), 2), "best": round(host_loop(G, 4), 2)}
+            model.disable_decode_graph()
+        tiers["forward_op_by_op_plus_torch_argmax"] = {"worst": round(host_loop(G, S), 2), "best": round(host_loop(G, 4), 2)}
+        if use_graph:
+            model.enable_decode_graph(cache)
+        tiers["unit"] = "tokens/s; wall clock around %d tokens incl. host time, context %d.. (worst) / 4.. (best)" % (G, S)
+        result["host_argmax_loop"] = tiers
+
     # ---- whole-path roofline fractions (algorithmic bytes / flops) ------------------------------
     full = synth.LlamaDims(dims.hidden_size, dims.intermediate_size, L, dims.num_attention_heads, dims.num_key_value_heads,
                            dims.vocab_size)

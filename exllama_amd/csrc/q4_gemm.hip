@@ -995,14 +995,21 @@ static int plan_gemm_tail(int device, int mtiles, int ntiles, int K, int slices_
     const int tiles = mtiles * ntiles;
     const int full = tiles / ncu * ncu, rem = tiles - full;
     if (off || full == 0 || rem == 0) return padded;
-    // choose the split: parts in {2, 4, 8} with whole 128-row blocks of K per part; cost of the tail in rounds of one full tile
+    // choose the split: parts in {2, 4, 8} with whole 128-row blocks of K per part.  Cost of the tail in units of one whole tile's
+    // time (2 * 256 * 128 * K flops at the ~4.7 TFLOP/s a CU sustains in these kernels): rounds / parts, ~3 K steps of fill / drain
+    // per part, and the fp32 slices' round trip through HBM at ~6 TB/s -- the term that decides: measured in round 4
+    // (gpurun_out/r04a), 7B gate / up with 176 tail tiles cut in 4 wrote + read 360 MB and ran 360 us instead of 305; 13B o / down (64
+    // tail tiles, 67 MB) gained.  slices_per_tile scales the tile's time and its traffic alike, so a pair of matrices and either
+    // of them alone get the same split (same bits).
     const int RB = K >> 7;
+    const double tile_us = 2.0 * 256 * 128 * K / 4.7e6;
     int best = 1; double best_cost = 1.0;
     for (int p = 2; p <= 8; p *= 2) {
         if (RB % p != 0 || RB / p < 2) continue;
         const double rounds = (double) ((rem * p + ncu - 1) / ncu);
-        const double cost = rounds / p * (1.0 + 3.0 * p / (2.0 * RB));        // ~3 K steps of fill / drain / slice store per part
-        if (cost < best_cost - 0.05) { best = p; best_cost = cost; }
+        const double traffic_us = (double) rem * p * (256 * 128 * 4) * 2.0 / 6.0e6;
+        const double cost = rounds / p * (1.0 + 3.0 * p / (2.0 * RB)) + traffic_us / tile_us;
+        if (cost < best_cost - 0.1) { best = p; best_cost = cost; }
     }
     if (best == 1) return padded;
     // the logical block after which `full` valid tiles have been dispatched

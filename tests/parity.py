@@ -10,6 +10,12 @@ import numpy as np
 ORACLE_TOL = 4e-3        # HIP path vs CPU oracle: max |diff| <= 4e-3 x the largest reference logit (measured: 6e-4 .. 1.2e-3 typical,
                          # profiles/r03_model_tolerance_stats.jsonl); decode steps are held to the float64 truth model instead, see _truth_close
 TRUTH_FACTOR = 1.5       # decode step: |HIP - truth| <= 1.5 x |fp16 oracle - truth| + one logit ulp
+TRUTH_CAP = 1.2e-2       # ... and never more than this x scale, however ill-conditioned the oracle says the step is (measured over the 159
+                         # decode-step comparisons of the suite, gpurun_out/r04a: HIP <= 7.7e-3 from the truth where the oracle's realisations
+                         # sit 1.9e-2 .. 1.1e-1 away; median HIP 6.1e-4, median oracle 9.2e-4)
+TP_TOL = 5e-3            # tensor-parallel ranks vs oracle: each rank's partial sum of a half layer is rounded to fp16 before the all-reduce,
+                         # one rounding more per rank and half layer than the unsharded pipeline (measured 4.33e-3 / rms 2.13e-3 at the
+                         # common ORACLE_TOL = 4e-3 / 2e-3 line, two cases of tests/test_tp_gpu.py)
 LORA_TOL = 6e-3          # with an adapter on every projection: two more fp16-rounded GEMMs per matmul on both sides (measured 3.97e-3 on tiny_gqa)
 PATHS_TOL = 8e-3         # two HIP paths with different fp16 rounding points (MFMA prefill vs GEMV decode, fused vs op by op)
 
@@ -77,7 +83,7 @@ def _truth_close(got, runs, truth, step, tag=""):
         with open(stats, "a") as f:
             f.write(json.dumps({"tag": tag, "scale": scale, "hip_vs_truth": [g_max / scale, g_rms / scale, g_blk / scale],
                                 "oracle_vs_truth": [o_max / scale, o_rms / scale, o_blk / scale]}) + "\n")
-    assert g_max <= TRUTH_FACTOR * o_max + ulp, (tag, "max", g_max / scale, o_max / scale)
+    assert g_max <= min(TRUTH_FACTOR * o_max + ulp, TRUTH_CAP * scale), (tag, "max", g_max / scale, o_max / scale)
     assert g_rms <= TRUTH_FACTOR * o_rms + ulp / 2, (tag, "rms", g_rms / scale, o_rms / scale)
     assert g_blk <= TRUTH_FACTOR * o_blk + ulp, (tag, "16-element block", g_blk / scale, o_blk / scale)
 

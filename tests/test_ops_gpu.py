@@ -747,3 +747,66 @@ def test_q4_attn_2_and_mlp_fused(ce, dim, inter, gs, act):
         with np.errstate(over="ignore"):
             refm = O.q4_mlp(x.numpy().reshape(-1, dim), w.numpy(), 1e-6, _oracle_w(lg), _oracle_w(lu), _oracle_w(ld))
         _close(xm.cpu().numpy(), refm, ulps=4.0)
+
+
+def test_compiled_binding_and_ctypes_path_launch_the_same_work(ce):
+    """exllama_amd/_exl_fast.so (the compiled binding of the per-token entry points, csrc/binding/exl_fast.cpp) against the ctypes
+    methods it replaces (kept in the class as the A/B reference): the same C-ABI calls with the same arguments, so every output is
+    bit-identical -- q4_matmul, rms_norm, rope_ (host and device-side position), q4_attn, attention, q4_attn_2, q4_mlp with LoRA
+    operands present and absent."""
+    fast, slow_cls, ext = ce.FAST_BINDING, type(ce.exllama_ext), ce.exllama_ext
+    assert fast is not None and ext.q4_attn is fast.q4_attn
+    slow = lambda name: (lambda *a, **kw: getattr(slow_cls, name)(ext, *a, **kw))
+    dim, heads, kvh, hd, inter, gs, r = 512, 4, 2, 128, 1408, 128, 16
+    keep = _prep_buffers(ce, 2, dim, inter)
+    gen = torch.Generator().manual_seed(77)
+    lins = [_lin(K, N, gs, act, seed=90 + i, std=0.03)[0] for i, (K, N, act) in
+            enumerate([(dim, heads * hd, True), (dim, kvh * hd, True), (dim, kvh * hd, False), (dim, dim, True), (dim, inter, False), (dim, inter, True), (inter, dim, True)])]
+    (hq, _0), (hk, _1), (hv, _2), (ho, _3), (hg, _4), (hu, _5), (hdn, _6) = (_handle(ce, l) for l in lins)
+    max_seq, past = 64, 11
+    sin, cos = (torch.from_numpy(t).to(DEV)[None, None] for t in O.rope_tables(max_seq, hd))
+    x = torch.randn(1, 1, dim, generator=gen).half().to(DEV)
+    w = (1 + 0.1 * torch.randn(dim, generator=gen)).half().to(DEV)
+    nt = ce.none_tensor
+    lora = lambda n_out, n_in=dim: ((torch.randn(n_in, r, generator=gen) * 0.05).half().to(DEV), (torch.randn(r, n_out, generator=gen) * 0.05).half().to(DEV))
+    pos = torch.tensor([past], dtype=torch.int32, device=DEV)
+    adapters = {}
+    for with_lora in (False, True):
+        la = {k: (lora(n) if with_lora else (nt, nt)) for k, n in (("q", heads * hd), ("k", kvh * hd), ("v", kvh * hd), ("o", dim), ("g", inter), ("u", inter))}
+        adapters[with_lora] = (la, lora(dim, inter) if with_lora else (nt, nt), torch.zeros((1, r), dtype=torch.float16, device=DEV) if with_lora else nt)
+    results = {}
+    for tag, pick in (("fast", lambda n: getattr(fast, n)), ("ctypes", slow)):
+        out = {}
+        # q4_matmul / rms_norm / rope_
+        xn = torch.empty((3, dim), dtype=torch.float16, device=DEV)
+        x3 = torch.randn(3, dim, generator=torch.Generator().manual_seed(5)).half().to(DEV)
+        pick("rms_norm")(x3, w, xn, 1e-6)
+        y = torch.empty((3, heads * hd), dtype=torch.float16, device=DEV)
+        pick("q4_matmul")(xn, hq, y)
+        y2 = y.clone().view(1, 3, heads * hd)
+        pick("rope_")(y2, sin, cos, 3, heads, hd)
+        y3 = y.clone().view(1, 3, heads * hd)
+        pick("rope_")(y3, sin, cos, 0, heads, hd, past_len_dev=pos)
+        out.update(xn=xn, y=y, y2=y2, y3=y3)
+        for with_lora in (False, True):
+            la, ld, lt = adapters[with_lora]
+            q = torch.empty((1, 1, heads * hd), dtype=torch.float16, device=DEV)
+            k = torch.empty((1, 1, kvh * hd), dtype=torch.float16, device=DEV)
+            v = torch.empty_like(k)
+            kc = torch.randn(1, kvh, max_seq, hd, generator=torch.Generator().manual_seed(6)).half().to(DEV)
+            vc = torch.randn(1, kvh, max_seq, hd, generator=torch.Generator().manual_seed(7)).half().to(DEV)
+            h = x.clone()
+            pick("q4_attn")(h, w, 1e-6, q, k, v, hq, hk, hv, sin, cos, 1, past, heads, kvh, hd, kc, vc, max_seq,
+                            la["q"][0], la["q"][1], la["k"][0], la["k"][1], la["v"][0], la["v"][1], lt)
+            attn = torch.empty_like(q)
+            pick("attention")(q, kc, vc, attn, past, heads)
+            pick("q4_attn_2")(h, attn, ho, la["o"][0], la["o"][1], lt)
+            m = h.clone().view(1, dim)
+            pick("q4_mlp")(m, w, 1e-6, hg, hu, hdn, la["g"][0], la["g"][1], la["u"][0], la["u"][1], ld[0], ld[1], lt)
+            out.update({f"q{with_lora}": q, f"kc{with_lora}": kc, f"attn{with_lora}": attn, f"h{with_lora}": h, f"m{with_lora}": m})
+        torch.cuda.synchronize()
+        results[tag] = out
+    for key, a in results["fast"].items():
+        assert torch.isfinite(a.float()).all(), key
+        assert torch.equal(a, results["ctypes"][key]), key
+    assert not torch.equal(results["fast"]["mFalse"], results["fast"]["mTrue"])      # the adapters did something
