@@ -71,6 +71,25 @@ int exl_workspace(int device, size_t floats, float** out)
     return 0;
 }
 
+int exl_sampler_workspace(int device, size_t bytes, void** out)
+{
+    EXL_REQUIRE(device >= 0 && device < EXL_MAX_DEVICES, EXL_E_INVALID, "invalid device index %d", device);
+    DeviceBuffers* b = &g_buffers[device];
+    if (b->sampler_ws_bytes < bytes) {
+        int prev = 0;
+        EXL_HIP(hipGetDevice(&prev));
+        EXL_HIP(hipSetDevice(device));
+        if (b->sampler_ws) (void) hipFree(b->sampler_ws);
+        b->sampler_ws = nullptr; b->sampler_ws_bytes = 0;
+        const hipError_t e = hipMalloc(&b->sampler_ws, bytes);
+        (void) hipSetDevice(prev);
+        if (e != hipSuccess) { (void) hipGetLastError(); EXL_FAIL((int) e, "device sampler: cannot allocate its %zu-byte workspace: %s", bytes, hipGetErrorString(e)); }
+        b->sampler_ws_bytes = bytes;
+    }
+    *out = b->sampler_ws;
+    return 0;
+}
+
 int exl_gemm_workspace(int device, size_t floats, float** out)
 {
     EXL_REQUIRE(device >= 0 && device < EXL_MAX_DEVICES, EXL_E_INVALID, "invalid device index %d", device);
@@ -156,12 +175,13 @@ extern "C" int exl_cleanup(void)
     for (int d = 0; d < EXL_MAX_DEVICES; ++d) {
 
         DeviceBuffers* b = &g_buffers[d];
-        if (b->workspace || b->gemm_ws) {
+        if (b->workspace || b->gemm_ws || b->sampler_ws) {
             int prev = 0;
             if (hipGetDevice(&prev) == hipSuccess) {
                 (void) hipSetDevice(d);
                 if (b->workspace) (void) hipFree(b->workspace);
                 if (b->gemm_ws) (void) hipFree(b->gemm_ws);
+                if (b->sampler_ws) (void) hipFree(b->sampler_ws);
                 (void) hipSetDevice(prev);
             }
         }

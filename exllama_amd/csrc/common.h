@@ -85,11 +85,15 @@ struct DeviceBuffers {
     float* temp_zeros_float; size_t max_zeros_float;
     f16* temp_dq;     size_t temp_dq_numel;
     float* workspace; size_t workspace_floats;   // owned: decode split-K slabs / attention partials
+    void* sampler_ws; size_t sampler_ws_bytes;   // owned: whole-vocabulary sort of the device sampler (top_k = 0 / > 1024), allocated on first request
     float* gemm_ws;   size_t gemm_ws_floats;     // owned, grown on demand: fp32 slices of the prompt GEMMs' K splits (its own buffer: a caller
                                                  // running attention on another stream must not see them land in `workspace`)
 };
 DeviceBuffers* exl_buffers(int device);           // never NULL for 0 <= device < EXL_MAX_DEVICES
 int exl_workspace(int device, size_t floats, float** out);   // fails if too small / not prepared
+#define SMP_BIG_MAX 65536                             // entries the sampler's whole-vocabulary sort holds (a power of two)
+#define SMP_BIG_BYTES ((size_t) SMP_BIG_MAX * (8 + 4 + 4 + 4 + 4))
+int exl_sampler_workspace(int device, size_t bytes, void** out);  // allocated once per device (NOT capturable)
 int exl_gemm_workspace(int device, size_t floats, float** out);   // grows (device-synchronising, NOT capturable) up to 512 MiB; non-zero: no room
 extern ExlTuning g_tuning;
 

@@ -1163,6 +1163,11 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     if (e == hipSuccess) e = hipMemset((unsigned char*) d->block + o_zero, 0, (size_t) hidden * 2);
     (void) hipSetDevice(prev);
     if (e != hipSuccess) { delete d; EXL_FAIL((int) e, "decoder_create: %s", hipGetErrorString(e)); }
+    if (lm_head) {                                                   // the sampler's whole-vocabulary workspace (top_k = 0 / > 1024): a captured
+        void* sw = nullptr;                                          // exl_decoder_step_sample cannot allocate it
+        const int rs = exl_sampler_workspace(device, SMP_BIG_BYTES, &sw);
+        if (rs) { (void) hipFree(d->block); delete d; return rs; }
+    }
     unsigned char* b = (unsigned char*) d->block;
     d->hid = (f16*) (b + o_hid); d->qbuf = (f16*) (b + o_q);
     d->kbuf = (f16*) (b + o_k); d->vbuf = (f16*) (b + o_v); d->attn_out = (f16*) (b + o_ao); d->act = (f16*) (b + o_act);

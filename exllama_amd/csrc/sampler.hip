@@ -15,8 +15,11 @@
 //      the caller (uniforms[position]) or Philox4x32-10(seed, position).  (torch.multinomial's exponential-race draw
 //      cannot be reproduced from a uniform stream; oracle/sampler_oracle.py states the same rule, so tokens are comparable
 //      one to one.)
-// One block of 1024 threads; selection by a 4-pass radix select on the probability bits, candidates (<= 1024) sorted by a
-// bitonic network in LDS.  top_k = 0 (sort the whole vocabulary) is not offered on the device: 1 <= top_k <= 1024.
+// One block of 1024 threads.  1 <= top_k <= 1024 (dec_sample_kernel): selection by a 4-pass radix select on the probability
+// bits, the candidates sorted by a bitonic network in LDS.  top_k = 0 -- the reference then sorts the WHOLE vocabulary and does
+// not renormalise (generator.py:110-111) -- and top_k > 1024 (dec_sample_big_kernel): the whole vocabulary (<= 65536 entries) is
+// sorted in a per-device workspace by the same network run in LDS-sized chunks, and the reference's sequential loops (top-p /
+// min-p, typical, the draw) walk the sorted list chunk by chunk, so any number of survivors is handled.
 #include "common.h"
 
 #define SMP_THREADS 1024
@@ -90,22 +93,11 @@ __device__ __forceinline__ void smp_bitonic_desc(unsigned long long* key)
     __syncthreads();
 }
 
-__global__ __launch_bounds__(SMP_THREADS) void dec_sample_kernel(const SamplerArgs a)
+// Steps 1 and 2 of both kernels: repetition penalty, ban, temperature, softmax -> a.probs (logits modified in place).
+__device__ __forceinline__ void smp_prepare(const SamplerArgs& a, int n, float* redf, double* redd)
 {
-    __shared__ unsigned long long key[SMP_MAXK];
-    __shared__ float cp[SMP_MAXK];
-    __shared__ int ci[SMP_MAXK];
-    __shared__ unsigned int hist[256];
-    __shared__ double redd[SMP_THREADS / 64];
-    __shared__ float redf[SMP_THREADS / 64];
-    __shared__ int scan[SMP_THREADS];
-    __shared__ unsigned int sh_prefix, sh_need;
-    __shared__ int sh_count, sh_n;
     const int tid = threadIdx.x, V = a.vocab;
-    const int pos_new = *a.pos_dev;                                  // position the sampled token will take
-    const int n = pos_new;                                           // sequence so far = history[0 .. n - 1]
     float* lg = a.logits;
-
     // ---- 1. repetition penalty (rep_penalty.cpp:36-74) -----------------------------------------------------------------
     if (a.s.rep_penalty_max != 1.0f && n > 0) {
         const int sustain = a.s.rep_sustain < 0 ? n : a.s.rep_sustain;
@@ -146,6 +138,26 @@ __global__ __launch_bounds__(SMP_THREADS) void dec_sample_kernel(const SamplerAr
     const float inv = (float) (1.0 / smp_block_sum(ssum, redd));
     for (int i = tid; i < V; i += SMP_THREADS) a.probs[i] *= inv;
     __syncthreads();
+
+}
+
+__global__ __launch_bounds__(SMP_THREADS) void dec_sample_kernel(const SamplerArgs a)
+{
+    __shared__ unsigned long long key[SMP_MAXK];
+    __shared__ float cp[SMP_MAXK];
+    __shared__ int ci[SMP_MAXK];
+    __shared__ unsigned int hist[256];
+    __shared__ double redd[SMP_THREADS / 64];
+    __shared__ float redf[SMP_THREADS / 64];
+    __shared__ int scan[SMP_THREADS];
+    __shared__ unsigned int sh_prefix, sh_need;
+    __shared__ int sh_count, sh_n;
+    const int tid = threadIdx.x, V = a.vocab;
+    const int pos_new = *a.pos_dev;                                  // position the sampled token will take
+    const int n = pos_new;                                           // sequence so far = history[0 .. n - 1]
+    float* lg = a.logits;
+
+    smp_prepare(a, n, redf, redd);
 
     // ---- 3. top-k: radix select of the k-th largest probability (non-negative floats order like their bits) ----------
     int k = a.s.top_k < 1 ? 1 : a.s.top_k > SMP_MAXK ? SMP_MAXK : a.s.top_k;
@@ -292,17 +304,213 @@ __global__ __launch_bounds__(SMP_THREADS) void dec_sample_kernel(const SamplerAr
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// top_k = 0 / top_k > 1024: the whole vocabulary sorted in global memory (per-device workspace, exl_sampler_workspace).
+// ---------------------------------------------------------------------------------------------------------------
+#define SMP_CH 4096                                   // keys per LDS chunk of the big sort (32 KiB)
+struct SamplerBig { unsigned long long* key; float* cp; int* ci; float* cp2; int* ci2; };
+
+// Descending bitonic sort of np (a power of two) 64-bit keys in global memory by one block: the network of smp_bitonic_desc on the
+// global index; every run of stages whose partners lie inside one SMP_CH-aligned chunk is done in LDS.
+__device__ void smp_big_sort(unsigned long long* g, int np, unsigned long long* lds)
+{
+    const int t = threadIdx.x;
+    const int ch = np < SMP_CH ? np : SMP_CH;
+    auto chunk_stages = [&](int c, int size, int first_stride) {        // strides first_stride .. 1 of network size `size` inside chunk c
+        for (int j = t; j < ch; j += SMP_THREADS) lds[j] = g[c * ch + j];
+        for (int stride = first_stride; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int p = t; p < ch / 2; p += SMP_THREADS) {
+                const int i = ((p / stride) * 2 * stride) + (p % stride), q = i + stride;
+                const bool desc = (((c * ch + i) & size) == 0);
+                const unsigned long long x = lds[i], y = lds[q];
+                if (desc ? x < y : x > y) { lds[i] = y; lds[q] = x; }
+            }
+        }
+        __syncthreads();
+        for (int j = t; j < ch; j += SMP_THREADS) g[c * ch + j] = lds[j];
+        __syncthreads();
+    };
+    for (int c = 0; c < np / ch; ++c)                                    // sizes 2 .. ch: whole sub-networks per chunk
+        for (int size = 2; size <= ch; size <<= 1) {
+            // (one load / store per size keeps the code small; this path is the rare one)
+            chunk_stages(c, size, size >> 1);
+        }
+    for (int size = 2 * ch; size <= np; size <<= 1) {
+        for (int stride = size >> 1; stride >= ch; stride >>= 1) {        // partners in different chunks: global memory
+            __syncthreads();
+            for (int p = t; p < np / 2; p += SMP_THREADS) {
+                const int i = ((p / stride) * 2 * stride) + (p % stride), q = i + stride;
+                const bool desc = ((i & size) == 0);
+                const unsigned long long x = g[i], y = g[q];
+                if (desc ? x < y : x > y) { g[i] = y; g[q] = x; }
+            }
+        }
+        __syncthreads();
+        for (int c = 0; c < np / ch; ++c) chunk_stages(c, size, ch >> 1);
+    }
+}
+
+// Thread 0 walks g[0 .. n) IN ORDER through an LDS staging buffer (a single thread reading global memory element by element
+// would pay a memory latency per element); f(i, value) returns false to stop.  All threads must call it.
+template <class F>
+__device__ __forceinline__ void smp_walk(const float* g, int n, float* stage, int* stop, F&& f)
+{
+    if (threadIdx.x == 0) *stop = 0;
+    for (int base = 0; base < n; base += SMP_THREADS) {
+        __syncthreads();
+        if (*stop) break;
+        if (base + (int) threadIdx.x < n) stage[threadIdx.x] = g[base + threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int m = min(SMP_THREADS, n - base);
+            for (int j = 0; j < m; ++j)
+                if (!f(base + j, stage[j])) { *stop = 1; break; }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(SMP_THREADS) void dec_sample_big_kernel(const SamplerArgs a, const SamplerBig w)
+{
+    __shared__ unsigned long long chunk[SMP_CH];
+    __shared__ float stage[SMP_THREADS];
+    __shared__ double redd[SMP_THREADS / 64];
+    __shared__ float redf[SMP_THREADS / 64];
+    __shared__ int sh_stop, sh_n;
+    __shared__ float sh_f;
+    __shared__ double sh_d;
+    const int tid = threadIdx.x, V = a.vocab;
+    const int pos_new = *a.pos_dev;
+    const int n = pos_new;
+    smp_prepare(a, n, redf, redd);
+
+    // ---- 3. the whole vocabulary, probability descending, ties: lower id first ------------------------------------------
+    int np = 1;
+    while (np < V) np <<= 1;
+    for (int i = tid; i < np; i += SMP_THREADS)
+        w.key[i] = i < V ? ((unsigned long long) __float_as_uint(a.probs[i]) << 32) | (unsigned long long) (0xFFFFFFFFu - (unsigned) i) : 0ull;
+    __syncthreads();
+    smp_big_sort(w.key, np, chunk);
+    int m = a.s.top_k == 0 ? V : (a.s.top_k < V ? a.s.top_k : V);
+    float* cp = w.cp; int* ci = w.ci; float* cp2 = w.cp2; int* ci2 = w.ci2;
+    for (int i = tid; i < m; i += SMP_THREADS) {
+        cp[i] = __uint_as_float((unsigned) (w.key[i] >> 32));
+        ci[i] = (int) (0xFFFFFFFFu - (unsigned) (w.key[i] & 0xFFFFFFFFu));
+    }
+    __syncthreads();
+    // F.normalize(p = 1) = x / max(sum, 1e-12), the sum in list order in fp32 (the order the oracle and the small kernel use)
+    auto normalize = [&](int cnt) {
+        if (tid == 0) sh_f = 0.f;
+        smp_walk(cp, cnt, stage, &sh_stop, [&](int, float v) { sh_f += v; return true; });
+        const float s1 = fmaxf(sh_f, 1e-12f);
+        for (int i = tid; i < cnt; i += SMP_THREADS) cp[i] /= s1;
+        __syncthreads();
+    };
+    if (a.s.top_k != 0) normalize(m);                                  // generator.py:113-114; top_k = 0: torch.sort only (:110-111)
+
+    // ---- 4. top-p with the min-p cut (generator.py:118-134) ------------------------------------------------------------
+    if (a.s.top_p > 0.0f) {
+        if (tid == 0) { sh_n = 0; sh_d = 0.0; }
+        const int list = m;
+        smp_walk(cp, list, stage, &sh_stop, [&](int i, float v) {
+            if (i == 0) { sh_d = (double) v; sh_n = 1; return list > 1; }      // cum = top_probs[0]; num = 1; (num == length -> break)
+            if (v < a.s.min_p) return false;
+            sh_d += (double) v;
+            if (sh_d > (double) a.s.top_p) return false;
+            sh_n = i + 1;
+            return i + 1 < list;
+        });
+        m = sh_n;
+        __syncthreads();
+        normalize(m);
+    }
+
+    // ---- 5. locally typical sampling (generator.py:138-161) ------------------------------------------------------------
+    if (a.s.typical > 0.0f) {
+        double part = 0.0;
+        for (int i = tid; i < m; i += SMP_THREADS) { const float lp = logf(cp[i] + 1e-10f); part += (double) (cp[i] * lp); }
+        const float neg_entropy = (float) smp_block_sum(part, redd);
+        int np2 = 1;
+        while (np2 < m) np2 <<= 1;
+        for (int i = tid; i < np2; i += SMP_THREADS) {
+            unsigned long long kk = 0ull;
+            if (i < m) {
+                const unsigned dev_bits = __float_as_uint(fabsf(neg_entropy - logf(cp[i] + 1e-10f)));
+                kk = ((unsigned long long) (0xFFFFFFFFu - dev_bits) << 32) | (unsigned long long) (0xFFFFFFFFu - (unsigned) i);
+            }
+            w.key[i] = kk;
+        }
+        __syncthreads();
+        smp_big_sort(w.key, np2, chunk);                               // ascending deviation, ties keep the list order
+        for (int i = tid; i < m; i += SMP_THREADS) {
+            const int src = (int) (0xFFFFFFFFu - (unsigned) (w.key[i] & 0xFFFFFFFFu));
+            cp2[i] = cp[src]; ci2[i] = ci[src];
+        }
+        __syncthreads();
+        { float* tf = cp; cp = cp2; cp2 = tf; int* ti = ci; ci = ci2; ci2 = ti; }
+        if (tid == 0) { sh_n = 0; sh_d = 0.0; }
+        const int list = m;
+        smp_walk(cp, list, stage, &sh_stop, [&](int i, float v) {
+            if (i == 0) { sh_d = (double) v; sh_n = 1; return list > 1; }
+            sh_d += (double) v;
+            if (sh_d > (double) a.s.typical) return false;
+            sh_n = i + 1;
+            return i + 1 < list;
+        });
+        m = sh_n;
+        __syncthreads();
+        normalize(m);
+    }
+
+    // ---- 6. the draw: inverse CDF over the surviving list in its order ---------------------------------------------------
+    float u;
+    if (a.uniforms) u = a.uniforms[pos_new];
+    else u = (float) (smp_philox(a.s.seed, (uint32_t) pos_new) >> 8) * (1.0f / 16777216.0f);
+    if (tid == 0) { sh_n = m - 1; sh_d = 0.0; }
+    smp_walk(cp, m, stage, &sh_stop, [&](int i, float v) {
+        sh_d += (double) v;
+        if ((double) u < sh_d) { sh_n = i; return false; }
+        return true;
+    });
+    if (tid == 0) {
+        const int pick = sh_n;
+        const int64_t tok = ci[pick];
+        *a.token_io = tok;
+        if (a.history_out) a.history_out[pos_new] = tok;
+        if (a.prob_out) *a.prob_out = cp[pick];
+    }
+}
+
 int launch_dec_sample(float* logits, float* probs, int64_t* history, int64_t* token_io, const int32_t* pos_dev, const float* uniforms,
                       float* prob_out, int vocab, const ExlSampler* s, hipStream_t stream)
 {
-    EXL_REQUIRE(s->top_k >= 1 && s->top_k <= SMP_MAXK, EXL_E_UNSUPPORTED,
-                "device sampler: top_k must be in 1..%d (got %d; top_k = 0, a sort of the whole vocabulary, stays on the host path)", SMP_MAXK, s->top_k);
+    EXL_REQUIRE(s->top_k >= 0, EXL_E_INVALID, "device sampler: top_k must be >= 0 (0 = the whole vocabulary, generator.py:110-111), got %d", s->top_k);
     EXL_REQUIRE(s->temperature > 0.f, EXL_E_INVALID, "device sampler: temperature must be positive");
     EXL_REQUIRE(s->rep_penalty_max > 0.f && s->rep_decay >= 0, EXL_E_INVALID, "device sampler: bad repetition-penalty settings");
     SamplerArgs a;
     a.logits = logits; a.probs = probs; a.history = history; a.history_out = history; a.token_io = token_io; a.pos_dev = pos_dev;
     a.uniforms = uniforms; a.prob_out = prob_out; a.vocab = vocab; a.s = *s;
-    hipLaunchKernelGGL(dec_sample_kernel, dim3(1), dim3(SMP_THREADS), 0, stream, a);
+    if (s->top_k >= 1 && (s->top_k < vocab ? s->top_k : vocab) <= SMP_MAXK) {
+        hipLaunchKernelGGL(dec_sample_kernel, dim3(1), dim3(SMP_THREADS), 0, stream, a);
+        EXL_LAUNCH_CHECK();
+        return 0;
+    }
+    // top_k = 0 or beyond the LDS network: the whole-vocabulary sort in the device's sampler workspace
+    EXL_REQUIRE(vocab <= SMP_BIG_MAX, EXL_E_UNSUPPORTED, "device sampler: top_k = %d needs the whole-vocabulary sort, which holds at most %d entries (vocabulary %d)",
+                s->top_k, SMP_BIG_MAX, vocab);
+    int dev = 0;
+    EXL_HIP(hipGetDevice(&dev));
+    void* base = nullptr;
+    EXL_TRY(exl_sampler_workspace(dev, SMP_BIG_BYTES, &base));          // allocated once per device (NOT capturable: exl_decoder_create does it up front)
+    SamplerBig w;
+    w.key = (unsigned long long*) base;
+    w.cp = (float*) (w.key + SMP_BIG_MAX);
+    w.cp2 = w.cp + SMP_BIG_MAX;
+    w.ci = (int*) (w.cp2 + SMP_BIG_MAX);
+    w.ci2 = w.ci + SMP_BIG_MAX;
+    hipLaunchKernelGGL(dec_sample_big_kernel, dim3(1), dim3(SMP_THREADS), 0, stream, a, w);
     EXL_LAUNCH_CHECK();
     return 0;
 }

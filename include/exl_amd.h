@@ -230,7 +230,7 @@ int exl_decoder_step_greedy(void* decoder, int64_t* token_io_dev, int32_t* pos_d
  * cpu_func/rep_penalty.cpp:36-74) ------------------------------------------------------------------------------ */
 typedef struct ExlSampler {
     float   temperature;        /* > 0                                                            (Settings.temperature, 0.95) */
-    int32_t top_k;              /* 1 .. 1024 on the device (0 = whole-vocabulary sort: host path only)          (top_k, 40) */
+    int32_t top_k;              /* 0 = the whole vocabulary, sorted, not renormalised (generator.py:110-111); > 1024 also sorts it (top_k, 40) */
     float   top_p;              /* 0 disables                                                                  (top_p, 0.65) */
     float   min_p;              /* cut inside the top-p loop (generator.py:128)                                 (min_p, 0.0) */
     float   typical;            /* 0 disables locally typical sampling                                        (typical, 0.0) */

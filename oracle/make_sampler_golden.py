@@ -43,6 +43,13 @@ CASES = [
     (32000, 9, 3.5, 0.95, 40, 0.65, 0.0, 0.0, 0.05),        # real vocabulary size
     (32000, 10, 3.5, 0.8, 300, 0.85, 0.01, 0.6, 0.58),
     (512, 11, 8.0, 0.5, 10, 0.5, 0.0, 0.0, 0.0),            # peaked, u = 0
+    # top_k = 0 (generator.py:110-111: the whole vocabulary is sorted, no renormalisation) and top_k beyond 1024
+    (32000, 12, 3.5, 0.95, 0, 0.65, 0.0, 0.0, 0.41),        # the default settings with top_k = 0
+    (32000, 13, 1.0, 1.5, 0, 0.9, 0.0, 0.0, 0.73),          # flat: thousands of survivors of the top-p loop
+    (4096, 14, 3.0, 1.0, 0, 0.0, 0.0, 0.0, 0.62),           # nothing cut at all: the draw runs over the whole sorted vocabulary
+    (4096, 15, 2.0, 1.0, 0, 0.0, 0.0, 0.5, 0.33),           # typical sampling over the whole vocabulary
+    (32000, 16, 2.5, 1.0, 5000, 0.95, 0.001, 0.0, 0.88),    # top_k = 5000 (renormalised), min-p cut
+    (4096, 17, 4.0, 0.9, 2000, 0.9, 0.0, 0.7, 0.15),        # top_k = 2000, top-p, typical
 ]
 
 

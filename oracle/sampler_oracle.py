@@ -62,9 +62,12 @@ def sample(logits, history, temperature=0.95, top_k=40, top_p=0.65, min_p=0.0, t
     lg = (lg + f32(1e-8)).astype(f32)                                                  # generator.py:105
     e = np.exp((lg - lg.max()).astype(f32)).astype(f32)
     probs = (e * f32(1.0 / float(e.astype(np.float64).sum()))).astype(f32)            # generator.py:106 softmax
-    assert top_k >= 1, "top_k = 0 (whole-vocabulary sort) is the host-only path"
-    order = np.lexsort((np.arange(probs.size), -probs.astype(np.float64)))[:top_k]     # generator.py:112-114, ties: lower id first
-    top_probs = _normalize(probs[order])
+    order = np.lexsort((np.arange(probs.size), -probs.astype(np.float64)))             # ties: lower id first
+    if top_k == 0:                                                                     # generator.py:110-111: torch.sort of the whole
+        top_probs = probs[order]                                                       # vocabulary, NOT renormalised
+    else:                                                                              # generator.py:112-114: topk + F.normalize
+        order = order[:top_k]
+        top_probs = _normalize(probs[order])
     top_idx = order
     if top_p > 0.0:                                                                    # generator.py:118-134
         num = 0

@@ -104,6 +104,14 @@ def test_device_sampler_matches_the_oracle_token_for_token():
         dict(top_k=40, top_p=0.65, typical=0.9, rep_penalty_max=1.3, rep_sustain=-1, rep_decay=0),
         dict(top_k=5, top_p=0.95, rep_sustain=8, rep_decay=16, banned_token=1),
         dict(top_k=1),
+        # the whole-vocabulary sort (dec_sample_big_kernel): top_k = 0 as the reference means it (generator.py:110-111: torch.sort, no
+        # renormalisation) and top_k beyond the 1024 entries of the LDS network
+        dict(top_k=0),
+        dict(top_k=0, top_p=0.0, rep_penalty_max=1.0),                              # nothing cut: the draw runs over the sorted vocabulary
+        dict(top_k=0, temperature=1.6, top_p=0.92, min_p=0.0002),                   # flat: thousands survive the top-p loop
+        dict(top_k=0, top_p=0.0, typical=0.5),                                      # typical sampling over everything
+        dict(top_k=3000, top_p=0.9, typical=0.8),
+        dict(top_k=5000, top_p=0.0, rep_penalty_max=1.0),
     ]
     near, total = 0, 0
     for ci, kw in enumerate(cases):
@@ -115,7 +123,6 @@ def test_device_sampler_matches_the_oracle_token_for_token():
                 hist = rs.randint(0, V, size=hist_len)
                 u = float(rs.rand())
                 k = dict(kw)
-                k["top_k"] = min(k.get("top_k", 40), 1024)
                 if k.get("banned_token", -1) >= V:
                     k["banned_token"] = 0
                 settings = _lib.ExlSampler(**k)
@@ -147,7 +154,7 @@ def test_device_sampler_matches_the_oracle_token_for_token():
     want = S.sample(logits, hist, top_k=200, top_p=0.95, u=S.uniform_from_philox(987654321, 77))[0]
     assert outs[0] == outs[1] == want
     with pytest.raises(RuntimeError, match="top_k"):
-        bad = _lib.ExlSampler(top_k=0)
+        bad = _lib.ExlSampler(top_k=-1)
         _lib.check(lib.exl_sample(0, lg.data_ptr(), probs.data_ptr(), 32000, history.data_ptr(), tok.data_ptr(), pos.data_ptr(), None, None,
                                   C.byref(bad), torch.cuda.current_stream().cuda_stream), "sample")
 
@@ -201,4 +208,21 @@ def test_generate_sample_inside_the_graph_equals_the_host_loop():
     again = model.generate_sample(torch.tensor([prompt[0].cpu().tolist() + got + more.cpu().tolist()]), cache, 4,
                                   settings=_lib.ExlSampler(top_k=1, rep_penalty_max=1.0))
     assert greedy.tolist() == again.tolist()
+    # top_k = 0 inside the captured graph (the sampler's whole-vocabulary workspace was allocated when the decoder was created)
+    start = cache.current_seq_len
+    seq0 = prompt[0].cpu().tolist() + got + more.cpu().tolist() + greedy.cpu().tolist()
+    s0 = _lib.ExlSampler(temperature=1.2, top_k=0, top_p=0.8, rep_penalty_max=1.1, rep_sustain=16, rep_decay=8)
+    wide = model.generate_sample(torch.tensor([seq0]), cache, 5, settings=s0, uniforms=unif).cpu().tolist()
+    cache.current_seq_len = start
+    model.enable_decode_graph(cache)
+    seq, near = list(seq0), 0
+    for i in range(5):
+        logits = model.forward(torch.tensor([[seq[-1]]], device="cuda:0"), cache)[0, 0].float().cpu().numpy()
+        u = float(unif[len(seq)])
+        want, _, idx, probs = S.sample(logits, seq, temperature=1.2, top_k=0, top_p=0.8, rep_penalty_max=1.1, rep_sustain=16, rep_decay=8, u=u)
+        if want != wide[i]:
+            assert S.boundary_distance(probs, u) < 1e-5, (i, want, wide[i])
+            near += 1
+        seq.append(wide[i])
+    assert near <= 1
     model.free_unmanaged()
