@@ -528,7 +528,9 @@ extern "C" int exl_embedding(const int64_t* ids_dev, const void* table, void* ou
 extern "C" int exl_head_matmul(const void* x, const void* w, float* out, int rows, int hidden, int vocab, void* stream)
 {
     EXL_REQUIRE(x && w && out, EXL_E_INVALID, "head_matmul: null pointer");
-    return launch_head_rows((const f16*) x, (const f16*) w, out, rows, hidden, vocab, (hipStream_t) stream);
+    const int r = launch_head_rows((const f16*) x, (const f16*) w, out, rows, hidden, vocab, (hipStream_t) stream);   // <= 8 rows: the GEMV
+    if (r != 1) return r;
+    return launch_head_gemm((const f16*) x, (const f16*) w, out, rows, hidden, vocab, (hipStream_t) stream);            // whole sequences: MFMA GEMM
 }
 
 extern "C" int exl_rope(void* x, const void* sin, const void* cos, int bsz, int rows_per_batch, int head_dim,

@@ -131,6 +131,7 @@ int launch_dec_sample(float* logits, float* probs, int64_t* history, int64_t* to
                       float* prob_out, int vocab, const ExlSampler* s, hipStream_t stream);
 int launch_embedding(const int64_t* ids, const f16* table, f16* out, int n_ids, int hidden, int vocab, hipStream_t s);
 int launch_head_rows(const f16* x, const f16* w, float* out, int rows, int hidden, int vocab, hipStream_t s);   // 1 = not covered
+int launch_head_gemm(const f16* x, const f16* w, float* out, int rows, int hidden, int vocab, hipStream_t s);   // 1 = not covered; half_gemm_nt.hip
 int launch_rms_norm(const f16* x, const f16* w, f16* out, float eps, int rows, int dim, hipStream_t s);
 int launch_rms_norm_gather(const f16* x, const f16* w, f16* out, const uint32_t* x_map, float eps, int rows, int dim, hipStream_t s);   // x_map NULL: plain norm
 // decode_fused.hip: one fused executor launch for the op-level entry points (0 done, 1 not covered, > 1 error)

@@ -705,12 +705,13 @@ class ExLlama:
         hidden = _move_tensor(hidden, cfg.device_map.lm_head, "hidden_states", cfg)
         logits = None
         rows = hidden.shape[0] * hidden.shape[1]
-        if hidden.is_cuda and hidden.dtype == torch.float16 and self.lm_head_weight.is_cuda and rows <= 8:
-            # the last-token logits of a prompt / a short prompt: HIP GEMV over the fp16 head (reference: nn.Linear, model.py:1077)
+        if hidden.is_cuda and hidden.dtype == torch.float16 and self.lm_head_weight.is_cuda:
+            # HIP kernels over the fp16 head (reference: nn.Linear + .float(), model.py:1077-1078): a GEMV for the last-token logits of
+            # a prompt / a short prompt, an LDS-DMA MFMA GEMM for whole-sequence logits (perplexity, validation)
             out = torch.empty((rows, self.lm_head_weight.shape[0]), dtype=torch.float32, device=hidden.device)
             if ext.head_matmul(hidden.reshape(rows, -1).contiguous(), self.lm_head_weight, out):
                 logits = out.view(hidden.shape[0], hidden.shape[1], -1)
-        if logits is None:                                          # whole-sequence logits (perplexity, validation): the BLAS GEMM
+        if logits is None:                                          # a head on the CPU, or a shape the kernels do not cover (hidden % 64, vocab % 4)
             logits = torch.matmul(hidden, self.lm_head_weight.t()).float()
         if cfg.tp is not None and self.lm_head_weight.shape[0] != cfg.vocab_size:      # this rank's vocabulary rows (tp.py): gather the rest
             logits = cfg.tp.all_gather_last(logits, cfg.tp.plan.vocab_sizes)

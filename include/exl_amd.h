@@ -306,8 +306,9 @@ int exl_decoder_free(void* decoder);
 /* ---- embedding lookup and the prompt pass' lm_head (reference: torch ops inside model.py, not exllama_ext functions:
  * model.py:1002 `self.embed_tokens(input_ids)`, :1077 `self.lm_head(hidden_states)`) -- so that no BLAS / ATen kernel is left on
  * the token path.  exl_embedding: out[i] = table[ids[i]] (fp16 rows, ids int64 in DEVICE memory, clamped to the table).
- * exl_head_matmul: out[r][v] = float(half(x[r] . w[v])) for rows <= 8 (the last-token logits of a prompt, a short prompt);
- * returns 1 (nothing launched) for more rows: the caller keeps its GEMM path for whole-sequence logits. */
+ * exl_head_matmul: out[r][v] = float(half(x[r] . w[v])): a GEMV for rows <= 8 (the last-token logits of a prompt, a short prompt),
+ * an fp16 MFMA GEMM with both tiles staged by LDS-DMA for whole sequences (the `-ppl` leg, perplexity.py:121-138); returns 1
+ * (nothing launched) only for shapes neither covers (hidden % 64 != 0, vocab % 4 != 0): the caller keeps its own GEMM then. */
 int exl_embedding(const int64_t* ids_dev, const void* table, void* out, int n_ids, int hidden, int vocab, void* stream);
 int exl_head_matmul(const void* x, const void* w, float* out, int rows, int hidden, int vocab, void* stream);
 

@@ -476,10 +476,31 @@ def test_embedding_and_head_matmul(ce, hidden, vocab, rows):
     assert ce.exllama_ext.head_matmul(x.to(DEV), table.to(DEV), logits)
     ref = O.half_matmul(x.numpy(), table.t().contiguous().numpy())          # fp32 products and sums, one rounding to fp16
     _close(logits.cpu().numpy(), ref, ulps=1.5)
-    big = torch.randn(9, hidden, generator=gen).half().to(DEV)              # more rows than the kernel stages: declined, nothing written
-    sentinel = torch.full((9, vocab), 7.0, dtype=torch.float32, device=DEV)
-    assert not ce.exllama_ext.head_matmul(big, table.to(DEV), sentinel)
-    assert float(sentinel.min()) == 7.0
+    big = torch.randn(9, hidden, generator=gen).half()                      # more rows than the GEMV stages: the MFMA GEMM, or -- a vocabulary
+    sentinel = torch.full((9, vocab), 7.0, dtype=torch.float32, device=DEV)  # that is no multiple of 4 -- declined with nothing written
+    if vocab % 4 == 0:
+        assert ce.exllama_ext.head_matmul(big.to(DEV), table.to(DEV), sentinel)
+        _close(sentinel.cpu().numpy(), O.half_matmul(big.numpy(), table.t().contiguous().numpy()), ulps=1.5)
+    else:
+        assert not ce.exllama_ext.head_matmul(big.to(DEV), table.to(DEV), sentinel)
+        assert float(sentinel.min()) == 7.0
+
+
+@pytest.mark.parametrize("hidden,vocab,rows", [(128, 512, 9), (512, 640, 300), (4096, 32000, 2048), (5120, 32000, 777), (1024, 1000, 130)])
+def test_whole_sequence_head_gemm(ce, hidden, vocab, rows):
+    """exl_head_matmul for more than 8 rows (half_gemm_nt.hip): the lm_head of a whole sequence -- the `-ppl` leg of the reference
+    (model.py:1077-1078 with last_id_only = False; perplexity.py:121-138) -- as an fp16 MFMA GEMM whose two tiles travel by LDS-DMA.
+    fp32 products and sums, ONE rounding to fp16, widened to fp32: against the oracle's half_matmul; ragged row / vocabulary tiles
+    (300 = 2 x 128 + 44 rows, 1000 = 7 x 128 + 104 columns), the shortest K the ring takes (two K steps), poisoned output."""
+    gen = torch.Generator().manual_seed(hidden + rows)
+    w = (torch.randn(vocab, hidden, generator=gen) * 0.05).half()
+    x = torch.randn(rows, hidden, generator=gen).half()
+    out = torch.full((rows, vocab), float("nan"), dtype=torch.float32, device=DEV)
+    assert ce.exllama_ext.head_matmul(x.to(DEV), w.to(DEV), out)
+    got = out.cpu().numpy()
+    assert np.array_equal(got, got.astype(np.float16).astype(np.float32))   # every value is an fp16 value
+    ref = (x.float() @ w.float().t()).half().float().numpy() if rows * vocab > 1 << 22 else O.half_matmul(x.numpy(), w.t().contiguous().numpy())
+    _close(got, ref, ulps=1.5)
 
 
 def test_q4_matmul_lora(ce):
