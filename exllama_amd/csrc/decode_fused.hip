@@ -11,7 +11,7 @@
 //   K2 attn     RoPE(q), RoPE(k_new) in registers, k_new/v_new appended to the cache, split-KV attention over the
 //               cache -> per (head, split): its own fp16 attention output + fp32 (max, sum); one split: the output itself
 //   K3 o_proj   log-sum-exp merge of the splits while the activation image is built (a kernel boundary costs more than
-//               the merge: the stand-alone K2b kernel is kept behind EXL_DEC_SEPARATE_MERGE as the A/B reference), then
+//               the merge: the stand-alone K2b kernel serves the models whose attention output is wider than one block stages, hidden > 4096), then
 //               hid += attn_out @ Wo   (residual added in the epilogue, fp16 residual stream updated in place)
 //   K4 gate_up  RMSNorm(hid); one block computes the SAME 16 columns of gate and up -> act = silu(gate) * up (fp16)
 //   K5 down     hid += act @ Wdown
@@ -1088,7 +1088,6 @@ struct Decoder {
     float* partial;
     float2* head_best;            // (largest logit, row) per head-kernel block, for exl_decoder_step_greedy
     float* probs;                 // [vocab] scratch of the sampler (exl_decoder_step_sample)
-    bool separate_merge;          // EXL_DEC_SEPARATE_MERGE: run the split merge as its own kernel (A/B switch)
     int nsplit;                   // KV splits of the attention kernel in use (<= nsplit_max)
     int nsplit_max;
     int max_blocks;               // persistent GEMV grid: blocks per CU x CUs
@@ -1181,7 +1180,6 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     d->ring_fence = getenv("EXL_DEC_RING_FENCE") ? atoi(getenv("EXL_DEC_RING_FENCE")) : 1;
     d->ring_depth = getenv("EXL_DEC_RING_DEPTH") ? atoi(getenv("EXL_DEC_RING_DEPTH")) : 3;
     d->ring_wide = getenv("EXL_DEC_RING_WIDE") ? atoi(getenv("EXL_DEC_RING_WIDE")) : 1;
-    d->separate_merge = getenv("EXL_DEC_SEPARATE_MERGE") != nullptr;
     int bpc = 2;
     if (const char* env = getenv("EXL_DEC_BLOCKS_PER_CU")) { bpc = atoi(env); if (bpc < 1) bpc = 1; if (bpc > 4) bpc = 4; }
     d->max_blocks = (cus > 0 ? cus : 256) * bpc;
@@ -1481,7 +1479,7 @@ int dec_op_gemv(int device, int cls, int pnorm, int emode, const f16* vec, const
 // trips of 16 x 16 bytes per thread); the switch that kept the wide fold reachable is gone.)
 static bool dec_folds_merge(const Decoder* d)
 {
-    return !d->separate_merge && d->qd() <= DEC_THREADS * 8;
+    return d->qd() <= DEC_THREADS * 8;
 }
 
 // One kernel class of one layer (EXL_DEC_* in include/exl_amd.h); EXL_DEC_HEAD ignores `i`.

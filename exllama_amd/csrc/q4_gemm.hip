@@ -1465,8 +1465,7 @@ int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
     }
     // short prompts: the decode-shaped kernel, 32 rows x (16 .. 64) columns per block, waves split K (q4_gemm_skinny.hip)
     static const int skinny_max = getenv("EXL_GEMM_SKINNY_MAX") ? atoi(getenv("EXL_GEMM_SKINNY_MAX")) : 256;
-    static const bool use_reg_b = getenv("EXL_GEMM_REGISTER_B") != nullptr;     // A/B switch: the generic register-B kernel
-    if (w->layout == EXL_LAYOUT_T16 && rows <= skinny_max && !use_reg_b) {
+    if (w->layout == EXL_LAYOUT_T16 && rows <= skinny_max) {
         const int r = launch_gemm_t16s(w, xin, rows, out, no_zero, s);
         if (r != 1) return r;
     }
@@ -1475,8 +1474,7 @@ int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
     const int mtiles = (rows + BM - 1) / BM;
     const int ntiles = (N + BN - 1) / BN;
     const int grid = 8 * ((ntiles + 7) / 8) * mtiles;
-    static const bool no_spec = getenv("EXL_GEMM_NO_LOADER_WAVES") != nullptr;   // A/B switch: mid-step kernel for every row count
-    if (w->layout == EXL_LAYOUT_T16 && !use_reg_b && (uint64_t) rows * (uint64_t) K < (1ull << 31)) {    // 32-bit activation byte offsets
+    if (w->layout == EXL_LAYOUT_T16 && (uint64_t) rows * (uint64_t) K < (1ull << 31)) {    // 32-bit activation byte offsets
         // 257 .. 512 rows: the 128 x 128 tile (about 10 % faster than the 256-row kernels at 300 - 384 rows).  Round 2 found it
         // corrupting accumulators at 400 rows x 11008 columns on cold launches (in-flight "redundant" fetches landing in registers the
         // compiler had reused; fixed by tying the final wait to those registers) and routed around it; round 3
@@ -1484,7 +1482,7 @@ int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
         // GEMM of a fresh process on poisoned memory) and scripts/isa_lint.py.  EXL_GEMM_NO_TILE128=1 restores the detour.
         static const bool tile128 = getenv("EXL_GEMM_NO_TILE128") == nullptr;
         const int big_rows = tile128 ? 512 : 256;
-        const bool spec = !no_spec && rows > big_rows && gshift >= 5 && (uint64_t) K * (uint64_t) N < (1ull << 32);   // loader waves: power-of-two groups, 32-bit weight offsets
+        const bool spec = rows > big_rows && gshift >= 5 && (uint64_t) K * (uint64_t) N < (1ull << 32);   // loader waves: power-of-two groups, 32-bit weight offsets
         if (spec) return launch_gemm_t16w(w, xin, rows, out, no_zero, gshift, s);                 // 256 x 128, 8 MFMA waves + 4 loader waves
         if (rows > big_rows) return launch_gemm_t16m<4, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s);  // 256 x 128, 8 waves
         // K cut in two for 257 .. 512 rows: 2 x the blocks at half the length (the 128-row tile alone leaves 344 blocks of a 7B

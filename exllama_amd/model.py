@@ -734,7 +734,7 @@ class ExLlama:
                 stages.append({"dev": dev, "layers": [i]})
         return stages
 
-    def enable_decode_graph(self, cache, use_graph=True, first_stage=True, last_stage=True):
+    def enable_decode_graph(self, cache, use_graph=True, first_stage=True, last_stage=True, hop=None, hop_capture=True):
         """Route bsz = 1, q_len = 1 forwards on `cache` through the native decode executor (5 kernels per layer,
         exllama_amd/csrc/decode_fused.hip) and, with use_graph, replay them as ONE captured hipGraph per token and device.
         The position lives in device memory, so the same graph serves every context length.
@@ -743,7 +743,12 @@ class ExLlama:
         one executor STAGE per device: the residual stream [hidden] fp16 is copied from stage to stage, one hop per device
         boundary, exactly the reference's `_move_tensor` between layers (model.py:1053-1058).  first_stage / last_stage =
         False make this model ONE LINK of a split across processes (exllama_amd/pipeline.py): without the embedding the
-        first stage starts from the hidden state handed to decode_stage_step(), without the head the last stage returns it."""
+        first stage starts from the hidden state handed to decode_stage_step(), without the head the last stage returns it.
+        `hop` (pipeline.LayerSplitRunner): an object whose before(st) / after(st) issue this rank's point-to-point exchanges -- the
+        incoming hidden state (or token) ahead of the first stage's kernels, the outgoing one behind the last stage's; they are
+        CAPTURED into the first / last stage's graph when the backend allows it (RCCL point-to-point is capturable), so that a
+        replay is receive -> kernels -> send with no host work per token; otherwise (hop_capture False, or a failed capture) they run
+        eagerly around the replays.  hop.bind(self) is called once the executor's buffers exist."""
         import ctypes as C
         cfg = self.config
         if cache.batch_size != 1:
@@ -798,8 +803,11 @@ class ExLlama:
                              if self.lm_head_weight.shape[0] != cfg.vocab_size else None),
             "pos": stages[0]["pos"], "dev_pos": -1,
             "kv_ptrs": [(k.data_ptr(), v.data_ptr()) for k, v in zip(cache.key_states, cache.value_states)],
+            "hop": hop, "hop_captured": False,
         }
         self._decoder = st
+        if hop is not None:
+            hop.bind(self)
         if use_graph:
             # one captured graph per context bucket and stage: short contexts use fewer KV splits (1 split = nothing to merge)
             st["bucket_splits"] = []
@@ -808,31 +816,46 @@ class ExLlama:
             self._decoder_launch(st, advance=0)                 # eager dry run with the full split count (the K/V written
             for sg in stages:                                    # at the current slot are overwritten by the real token later)
                 torch.cuda.synchronize(sg["tdev"])
-            for ns, bucket_limit in self.DECODE_BUCKETS:
-                lim = C.c_int()
-                if any(lib.exl_decoder_set_kv_splits(sg["handle"], ns, C.byref(lim)) != 0 for sg in stages):
-                    continue                                    # more splits than this decoder has: covered by the last bucket
-                limit = lim.value if bucket_limit is None else min(lim.value, bucket_limit)
-                if st["graphs"] and limit <= st["graphs"][-1][0]:
-                    continue
-                per_stage = []
-                try:
+            def capture_all(hop_in):
+                """One graph per context bucket and stage; returns False when a tensor-parallel capture had to be given up."""
+                for ns, bucket_limit in self.DECODE_BUCKETS:
+                    lim = C.c_int()
+                    if any(lib.exl_decoder_set_kv_splits(sg["handle"], ns, C.byref(lim)) != 0 for sg in stages):
+                        continue                                    # more splits than this decoder has: covered by the last bucket
+                    limit = lim.value if bucket_limit is None else min(lim.value, bucket_limit)
+                    if st["graphs"] and limit <= st["graphs"][-1][0]:
+                        continue
+                    per_stage = []
                     for k, sg in enumerate(stages):
                         g = torch.cuda.CUDAGraph()
                         with torch.cuda.device(sg["tdev"]), torch.cuda.graph(g):    # capture only records: nothing runs at this position
+                            if hop_in and k == 0:
+                                hop.before(st)
                             self._stage_launch(st, k, advance=1)
+                            if hop_in and k == len(stages) - 1:
+                                hop.after(st)
                         per_stage.append(g)
-                except Exception as e:                            # noqa: BLE001
-                    if cfg.tp is None:
-                        raise
+                    st["graphs"].append((limit, per_stage))
+                    st["bucket_splits"].append(ns)
+                st["hop_captured"] = bool(hop_in)
+
+            import warnings
+            hop_in = hop is not None and hop_capture
+            try:
+                capture_all(hop_in)
+            except Exception as e:                                # noqa: BLE001
+                st["graphs"], st["bucket_splits"], st["hop_captured"] = [], [], False
+                if hop_in:
+                    # the process group's point-to-point calls could not be captured: graphs of the kernels alone, the exchanges
+                    # issued eagerly around each replay (same results, two more host calls per token)
+                    warnings.warn(f"layer split: hipGraph capture of the hand-off failed ({e}); exchanging eagerly around the replays")
+                    capture_all(False)
+                elif cfg.tp is not None:
                     # a tensor-parallel step contains the process group's collectives: if this backend cannot be captured,
                     # the pieces run as eager launches (same results, more host time per token)
-                    import warnings
                     warnings.warn(f"tensor parallel: hipGraph capture of the token step failed ({e}); decoding with eager launches")
-                    st["graphs"], st["bucket_splits"] = [], []
-                    break
-                st["graphs"].append((limit, per_stage))
-                st["bucket_splits"].append(ns)
+                else:
+                    raise
             st["graph"] = st["graphs"][-1][1] if st["graphs"] else None
             self._set_positions(st, start)
 
@@ -888,13 +911,19 @@ class ExLlama:
         st["stages"][k]["hid"].copy_(st["stages"][k - 1]["hid"], non_blocking=True)
 
     def _decoder_launch(self, st, advance, graphs=None):
+        hop = st.get("hop")
+        eager_hop = hop is not None and advance and not (graphs is not None and st.get("hop_captured"))
         for k in range(len(st["stages"])):
             if k:
                 self._hop(st, k)
+            elif eager_hop:
+                hop.before(st)                                        # this rank's incoming hand-off (pipeline.LayerSplitRunner)
             if graphs is not None:
                 graphs[k].replay()
             else:
                 self._stage_launch(st, k, advance)
+        if eager_hop:
+            hop.after(st)
 
     def _check_cache_storage(self, st, cache):
         """The executor and its graphs hold raw K/V addresses: a cache whose tensors were rebound (not rolled / copied in
@@ -933,16 +962,27 @@ class ExLlama:
         """One token through THIS process's part of a layer split (enable_decode_graph(..., first_stage / last_stage)):
         the first link takes `input_ids` [1, 1], later links the hidden state [1, 1, hidden] fp16 of the previous one;
         returns fp32 logits [1, 1, vocab] from the last link, the outgoing hidden state (the executor's own buffer: send or
-        copy it before the next step) from the others."""
+        copy it before the next step) from the others.  With a `hop` (enable_decode_graph) the inputs arrive through it: pass
+        neither input_ids nor hidden_in (they are received straight into the executor's buffers, decode_hop_buffers())."""
         st = self._decoder
         if st is None or st["cache"] is not cache:
             raise RuntimeError("decode_stage_step needs enable_decode_graph(cache) first")
-        if st["has_embed"]:
+        if st["has_embed"] and input_ids is not None:
             st["tok"].copy_(input_ids.view(1, 1), non_blocking=True)
-        else:
+        elif not st["has_embed"] and hidden_in is not None:
             st["stages"][0]["hid"].copy_(hidden_in.view(1, 1, -1), non_blocking=True)
+        elif st.get("hop") is None:
+            raise RuntimeError("decode_stage_step: no input (input_ids for the first link, hidden_in for the others)")
         self._run_token(st, cache)
         return st["logits"].clone() if st["has_head"] else st["stages"][-1]["hid"]
+
+    def decode_hop_buffers(self):
+        """The executor's own device buffers a layer-split hand-off reads / writes: (token [1, 1] int64 -- first link only --, incoming
+        hidden state [1, 1, hidden] fp16, outgoing hidden state, logits [1, 1, vocab] fp32 -- last link only)."""
+        st = self._decoder
+        if st is None:
+            raise RuntimeError("decode_hop_buffers needs enable_decode_graph(cache) first")
+        return st["tok"], st["stages"][0]["hid"], st["stages"][-1]["hid"], st["logits"]
 
     def generate_greedy(self, first_token, cache, num_tokens):
         """num_tokens greedy steps entirely on the device: each replay of a captured hipGraph runs the decode kernels AND the

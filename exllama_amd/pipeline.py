@@ -46,6 +46,45 @@ def stage_tensors(tensors, first, last):
     return out
 
 
+class StageHop:
+    """This rank's point-to-point exchanges of ONE token step of a layer split, issued on the executor's own device buffers
+    (ExLlama.decode_hop_buffers): before() ahead of the first stage's kernels, after() behind the last stage's.
+
+        hidden-state chain:      rank r > 0 receives the fp16 hidden state [1, 1, hidden] from r - 1, rank r < last sends its own on
+        token ring (token_ring): in addition the last rank picks the greedy token from its logits (argmax on the device) and sends
+                                 it to rank 0, which receives it where its embedding lookup reads the token: no host sees a token
+
+    exllama_amd.model.ExLlama.enable_decode_graph(hop=...) captures these calls into the rank's hipGraph when the process group
+    allows it (backend "nccl" = RCCL: stream-ordered point-to-point kernels), so a replay is receive -> kernels -> send; with a
+    backend that cannot be captured (gloo) or a failed capture the same calls run eagerly around the replay."""
+
+    def __init__(self, dist, rank, world, token_ring=False):
+        self.dist, self.rank, self.world, self.token_ring = dist, rank, world, token_ring
+        self.next_tok = None                        # last rank: the token picked by the latest step (device tensor [1, 1] int64)
+
+    def bind(self, stage):
+        self.tok, self.hid_in, self.hid_out, self.logits = stage.decode_hop_buffers()
+        if self.rank == self.world - 1 and self.next_tok is None:
+            self.next_tok = torch.zeros((1, 1), dtype=torch.int64, device=self.logits.device)
+
+    def before(self, st=None):
+        if self.rank > 0:
+            self.dist.recv(self.hid_in, src=self.rank - 1)
+        elif self.token_ring and self.world > 1:
+            self.dist.recv(self.tok, src=self.world - 1)
+
+    def after(self, st=None):
+        if self.rank < self.world - 1:
+            self.dist.send(self.hid_out, dst=self.rank + 1)
+            return
+        torch.argmax(self.logits.view(1, -1), dim=-1, keepdim=True, out=self.next_tok)
+        if self.token_ring:
+            if self.world > 1:
+                self.dist.send(self.next_tok, dst=0)
+            else:
+                self.tok.copy_(self.next_tok)                          # one rank: the ring is a copy
+
+
 class LayerSplitRunner:
     """Drives one rank's stage.  forward() returns fp32 logits on the LAST rank and None elsewhere."""
 
@@ -54,23 +93,52 @@ class LayerSplitRunner:
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.hidden_size, self.device, self.dtype = hidden_size, device, dtype
 
-    def enable_decode_executor(self, use_graph=True):
+    def enable_decode_executor(self, use_graph=True, capture_hop=True, token_ring=False):
         """Single-token steps of this rank run through the native decode executor (exllama_amd.model.ExLlama.enable_decode_graph)
         as one link of the split: rank 0 owns the embedding, the last rank the head, the fp16 hidden state [1, 1, hidden]
-        travels between them exactly as in forward()."""
-        self.stage.enable_decode_graph(self.cache, use_graph=use_graph, first_stage=self.rank == 0, last_stage=self.rank == self.world - 1)
+        travels between them exactly as in forward() -- received straight into / sent straight from the executor's buffers
+        (StageHop), and, with capture_hop, INSIDE the rank's captured graph: no host round trip per token and boundary.
+        token_ring = True prepares generate_greedy() (the token travels from the last rank to rank 0 inside the graphs too);
+        single-token forward() calls then need token_ring = False (they bring their token from the host)."""
+        self.hop = StageHop(self.dist, self.rank, self.world, token_ring)
+        self.stage.enable_decode_graph(self.cache, use_graph=use_graph, first_stage=self.rank == 0, last_stage=self.rank == self.world - 1,
+                                       hop=self.hop, hop_capture=capture_hop)
         self._executor = True
 
     def _decode_token(self, input_ids):
-        hidden_in = None
-        if self.rank > 0:
-            hidden_in = torch.empty((1, 1, self.hidden_size), dtype=self.dtype, device=self.device)
-            self.dist.recv(hidden_in, src=self.rank - 1)
-        out = self.stage.decode_stage_step(self.cache, input_ids=input_ids if self.rank == 0 else None, hidden_in=hidden_in)
-        if self.rank < self.world - 1:
-            self.dist.send(out.contiguous(), dst=self.rank + 1)       # (the send completes before the next step overwrites the buffer)
-            return None
-        return out
+        if self.hop.token_ring:
+            raise RuntimeError("this executor was enabled with token_ring=True: use generate_greedy(), or enable it without the ring")
+        out = self.stage.decode_stage_step(self.cache, input_ids=input_ids if self.rank == 0 else None)
+        return out if self.rank == self.world - 1 else None
+
+    def generate_greedy(self, first_token, num_tokens):
+        """num_tokens greedy tokens after `first_token` (the token at the cache's position -- the same value on every rank, e.g. from
+        next_token()) with NO host in the loop: every rank runs its step num_tokens times -- rank 0: receive the token from the
+        last rank, embedding + its layers, send the hidden state; middle ranks: receive, layers, send; last rank: receive, layers +
+        head, argmax, send the token to rank 0 -- each step one graph replay when the hand-off was captured.  The reference's
+        loop does forward + torch.argmax per token across all its devices (test_benchmark_inference.py:188-191).  Returns the
+        tokens (LongTensor [num_tokens]) on every rank."""
+        if not getattr(self, "_executor", False) or not self.hop.token_ring:
+            raise RuntimeError("generate_greedy needs enable_decode_executor(token_ring=True)")
+        last = self.world - 1
+        first = first_token.view(1, 1).to(device=self.device, dtype=torch.int64)
+        if self.world > 1:
+            if self.rank == last:
+                self.dist.send(first, dst=0)                            # rank 0's step ALWAYS receives its token: this one is the first
+        else:
+            self.hop.tok.copy_(first)
+        picked = []
+        for _ in range(num_tokens):
+            self.stage.decode_stage_step(self.cache)                     # inputs and outputs travel through the hop
+            if self.rank == last:
+                picked.append(self.hop.next_tok.clone())
+        if self.world > 1 and self.rank == 0:
+            spare = torch.zeros((1, 1), dtype=torch.int64, device=self.device)
+            self.dist.recv(spare, src=last)                              # the token of the final step is on the wire: take it off
+        toks = torch.cat(picked).view(-1) if picked else torch.zeros((num_tokens,), dtype=torch.int64, device=self.device)
+        if self.world > 1:
+            self.dist.broadcast(toks, src=last)
+        return toks
 
     def forward(self, input_ids, last_id_only=True):
         """input_ids [bsz, q_len] must be the same on every rank (its VALUES are only read on rank 0)."""

@@ -27,7 +27,7 @@ REPEATS = 4            # processes per kernel: 7 kernels x 4 = 28 cold launches
 CASES = {
     "t16m128": (4096, 11008, 32, 400, {"EXL_GEMM_NO_SPLITK": "1"}),         # q4_gemm_t16m_kernel<2,2,4,4>: the round-2 failure, exactly
     "t16m128k": (4096, 11008, 32, 400, {}),                                  # the same tile with K cut in two (fp32 slices + reduce kernel; the default at 257 .. 512 rows)
-    "t16m256": (4096, 4096, 128, 700, {"EXL_GEMM_NO_LOADER_WAVES": "1"}),  # q4_gemm_t16m_kernel<4,2,4,4>
+    "t16m256": (4224, 4096, 96, 700, {}),                                    # q4_gemm_t16m_kernel<4,2,4,4>: the 256-row tile without loader waves (group size 96: no power of two)
     "t16w0": (4096, 11008, 128, 600, {}),                                    # q4_gemm_t16w_kernel<0>: loader waves
     "t16s": (4096, 11008, 128, 128, {}),                                     # q4_gemm_t16s_kernel: short prompts
     "t16d2": (4096, 11008, 128, 700, {}),                                    # q4_gemm_t16d2_kernel: gate / up + SiLU

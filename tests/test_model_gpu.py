@@ -655,3 +655,33 @@ def test_decode_executor_as_stages_matches_the_single_executor_bit_for_bit():
     for m in (whole, staged, lo, hi):
         m.disable_decode_graph()
     whole.free_unmanaged()
+
+
+def test_layer_split_runner_token_ring_on_one_rank_equals_generate_greedy():
+    """pipeline.LayerSplitRunner.generate_greedy with the hand-off captured INSIDE the rank's graphs (StageHop; one rank here: the
+    ring is a device-side copy of the argmax into the token buffer, the same torch ops the multi-rank graphs carry next to the
+    RCCL calls): the tokens of ExLlama.generate_greedy, whose argmax is the executor's own kernel; eager exchanges give the same."""
+    from exllama_amd.model import ExLlamaCache
+    from exllama_amd.pipeline import LayerSplitRunner
+
+    class _Solo:
+        def get_rank(self): return 0
+        def get_world_size(self): return 1
+        def broadcast(self, t, src): return None
+
+    model, cache, tensors, dims = _build("tiny_hd128", 128, True, seed=6, max_seq_len=256)
+    ids = torch.randint(1, dims.vocab_size, (1, 150), generator=torch.Generator().manual_seed(2)).to("cuda:0")   # crosses the 160-key bucket
+    n = 20
+    lg = model.forward(ids, cache)
+    first = lg[0, -1].argmax().view(1, 1)
+    model.enable_decode_graph(cache)
+    want = model.generate_greedy(first, cache, n).tolist()
+    for capture in (True, False):
+        cache.current_seq_len = 150
+        runner = LayerSplitRunner(model, cache, _Solo(), dims.hidden_size, "cuda:0")
+        runner.enable_decode_executor(use_graph=True, capture_hop=capture, token_ring=True)
+        assert bool(model._decoder["hop_captured"]) == capture
+        got = runner.generate_greedy(first, n)
+        assert got.tolist() == want, (capture, got.tolist(), want)
+        assert cache.current_seq_len == 150 + n
+    model.free_unmanaged()

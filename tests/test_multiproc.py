@@ -4,6 +4,8 @@ collective on the data path, so this is all the cross-rank logic 
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -225,3 +227,102 @@ def test_layer_split_of_a_real_checkpoint_layout_matches_the_unsplit_model():
         assert p.exitcode == 0
     assert got_toks == toks
     assert np.array_equal(got_logits.numpy(), logits)
+
+
+# ---- the executor-side hand-off (pipeline.StageHop) and the token ring of LayerSplitRunner.generate_greedy: every rank's single-token
+# step receives its input and sends its output ON THE STAGE'S OWN BUFFERS (on the GPU: inside the rank's captured hipGraph; RCCL
+# point-to-point is capturable), the greedy token travels from the last rank back to rank 0 without the host.  On CPU the stage is
+# the oracle model behind the executor's stage interface (enable_decode_graph / decode_hop_buffers / decode_stage_step) and gloo
+# carries the exchanges eagerly -- the protocol (who receives what, when; the pre-sent first token; the drained last one; the final
+# broadcast) is what is covered, against the unsplit model's greedy tokens.
+class _OracleExecutorStage(_OracleStage):
+    def enable_decode_graph(self, cache, use_graph=True, first_stage=True, last_stage=True, hop=None, hop_capture=True):
+        h, V = self.m.h, self.m.lm_head.shape[0]
+        self.first, self.last, self.hop = first_stage, last_stage, hop
+        self.tok = torch.zeros((1, 1), dtype=torch.int64)
+        self.hid_in = torch.zeros((1, 1, h), dtype=torch.float16)
+        self.hid_out = torch.zeros((1, 1, h), dtype=torch.float16)
+        self.logits = torch.zeros((1, 1, V), dtype=torch.float32)
+        self.steps = 0
+        if hop is not None:
+            hop.bind(self)
+
+    def decode_hop_buffers(self):
+        return self.tok, self.hid_in, self.hid_out, self.logits
+
+    def decode_stage_step(self, cache, input_ids=None, hidden_in=None):
+        if input_ids is not None:
+            self.tok.copy_(input_ids.view(1, 1))
+        if hidden_in is not None:
+            self.hid_in.copy_(hidden_in.view(1, 1, -1))
+        if self.hop is not None:
+            self.hop.before()
+        hidden = self.embed(self.tok) if self.first else self.hid_in
+        hidden = self.forward_layers(hidden, None)
+        if self.last:
+            self.logits.copy_(self.head(hidden))
+        else:
+            self.hid_out.copy_(hidden)
+        if self.hop is not None:
+            self.hop.after()
+        self.steps += 1
+        return self.logits.clone() if self.last else self.hid_out
+
+
+def _ring_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from exllama_amd import synth
+    from exllama_amd.pipeline import LayerSplitRunner, split_layers, stage_tensors
+    dims, L, tensors = _ckpt()
+    first, last = split_layers(L, world)[rank]
+    stage = _OracleExecutorStage(synth.config_dict(dims, last - first), stage_tensors(tensors, first, last), last - first)
+    runner = LayerSplitRunner(stage, None, dist, dims.hidden_size, "cpu")
+    ids = torch.tensor([[3, 7, 11, 13, 17]])
+    logits = runner.forward(ids)                                  # the prompt: the chain of forward()
+    tok = runner.next_token(logits)                               # known to every rank
+    runner.enable_decode_executor(use_graph=False, token_ring=True)
+    toks = runner.generate_greedy(tok, 4)
+    again = None
+    try:
+        runner.forward(tok)                                       # a host-fed single token needs the executor without the ring
+    except RuntimeError as e:
+        again = str(e)
+    # the plain chain through the executor stages (no ring): the hidden state arrives through the hop, the token from the host
+    runner.enable_decode_executor(use_graph=False, token_ring=False)
+    lg = runner.forward(toks[-1].view(1, 1))
+    out.put((rank, int(tok), toks.tolist(), again, stage.steps, None if lg is None else lg.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_layer_split_token_ring_generates_the_unsplit_models_tokens(world):
+    import numpy as np
+    from exllama_amd import synth
+    from oracle.model_oracle import OracleLlama
+    dims, L, tensors = _ckpt()
+    full = OracleLlama(synth.config_dict(dims, L), tensors, max_seq_len=32)
+    logits = full.forward(np.array([[3, 7, 11, 13, 17]]))
+    want = []
+    for _ in range(6):
+        t = int(np.argmax(logits[0, -1]))
+        want.append(t)
+        logits = full.forward(np.array([[t]]))
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ring_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([out.get(timeout=240) for _ in range(world)], key=lambda g: g[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, first, toks, refusal, steps, lg in got:
+        assert first == want[0] and toks == want[1:5], (rank, first, toks, want)       # every rank holds the same, right tokens
+        assert refusal is not None and "token_ring" in refusal
+        assert steps == 1                                          # (the second executor was stepped once)
+        if rank == world - 1:                                      # the chain step after the ring continues the same sequence
+            assert int(lg[0, -1].argmax()) == want[5]
