@@ -232,22 +232,37 @@ extern "C" int exl_make_q4(int device, int height, int width, int groups, uint32
         return e;
     };
     {
-        Q4Matrix* prev_h = nullptr;
+        // (the previous handle's fingerprint and shape are COPIED while the registry lock is held: a concurrent exl_free_q4 may delete it)
+        bool have_prev = false;
+        uint32_t prev_fp[8];
         {
             std::lock_guard<std::mutex> lock(g_reg_mutex);
             auto it = g_by_qweight.find(qweight);
-            if (it != g_by_qweight.end() && g_live.count(it->second)) prev_h = it->second;
+            if (it != g_by_qweight.end() && g_live.count(it->second)) {
+                const Q4Matrix* ph = it->second;
+                if (ph->fp_valid && ph->device == device && ph->height == height && ph->width == width) {
+                    memcpy(prev_fp, ph->fp, sizeof(prev_fp));
+                    have_prev = true;
+                }
+            }
         }
-        if (prev_h && prev_h->fp_valid && prev_h->device == device && prev_h->height == height && prev_h->width == width) {
+        if (have_prev) {
             uint32_t now[8];
             const hipError_t e = fingerprint(now);
             if (e != hipSuccess) { delete m; EXL_FAIL((int) e, "make_q4: %s", hipGetErrorString(e)); }
-            if (memcmp(now, prev_h->fp, sizeof(now)) == 0) {
+            if (memcmp(now, prev_fp, sizeof(now)) == 0) {
                 delete m;
                 EXL_FAIL(EXL_E_INVALID, "make_q4: this qweight tensor was already rewritten in place by a live handle (make_q4 consumes its "
                          "tensor: build a second handle from a fresh copy of the checkpoint tensor)");
             }
         }
+    }
+    // fingerprint of the tensor BEFORE the rewrite: words the rewrite leaves unchanged (uniform nibbles: all-zero or 0x88888888 synthetic
+    // weights) cannot tell a rewritten tensor from a fresh one, so such a handle takes no part in the guard
+    uint32_t fp_before[8];
+    {
+        const hipError_t e = fingerprint(fp_before);
+        if (e != hipSuccess) { delete m; EXL_FAIL((int) e, "make_q4: %s", hipGetErrorString(e)); }
     }
 
     if (g_idx_host) {
@@ -282,7 +297,7 @@ extern "C" int exl_make_q4(int device, int height, int width, int groups, uint32
     if (m->x_map || m->layout == EXL_LAYOUT_T16) {                    // the tensor was rewritten: remember what it looks like now
         const hipError_t e = fingerprint(m->fp);
         if (e != hipSuccess) { free_matrix(m); EXL_FAIL((int) e, "make_q4: %s", hipGetErrorString(e)); }
-        m->fp_valid = true;
+        m->fp_valid = memcmp(m->fp, fp_before, sizeof(fp_before)) != 0;
     }
     {
         std::lock_guard<std::mutex> lock(g_reg_mutex);

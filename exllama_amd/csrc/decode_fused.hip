@@ -20,6 +20,7 @@
 // Every GEMV block streams one contiguous 16-column weight tile over the FULL K range (T16 layout, gemv_t16.h), so
 // there is no split-K, no partial-sum slab, no atomics: results are bit-reproducible run to run.  The position is
 // read from device memory, so one captured graph serves every context length.
+#include <mutex>
 #include "decode_args.h"
 
 #include <vector>
@@ -1440,9 +1441,11 @@ int dec_op_gemv(int device, int cls, int pnorm, int emode, const f16* vec, const
 {
     static Decoder cfg[EXL_MAX_DEVICES];
     static bool ready[EXL_MAX_DEVICES] = {};
+    static std::mutex init_mutex;                                    // (a loader thread next to a serving thread: the per-device configuration is built once)
     if (device < 0 || device >= EXL_MAX_DEVICES) return 1;
     static const bool off = getenv("EXL_OPS_UNFUSED") != nullptr;    // A/B switch: the op-by-op launches
     if (off) return 1;
+    std::lock_guard<std::mutex> init_lock(init_mutex);
     if (!ready[device]) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 1;

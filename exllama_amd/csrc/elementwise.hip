@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void head_rows_kernel(const f16* __restrict__ 
 int launch_head_rows(const f16* x, const f16* w, float* out, int rows, int hidden, int vocab, hipStream_t s)
 {
     if (rows <= 0) return 0;
-    if (rows > HEAD_MAX_ROWS || hidden % 8 != 0 || (size_t) HEAD_MAX_ROWS * hidden * 2 > 64 * 1024) return 1;
+    if (rows > HEAD_MAX_ROWS || hidden % 8 != 0 || (size_t) rows * hidden * 2 > 64 * 1024) return 1;     // the rows it stages must fit 64 KiB of LDS
     const int rpb = 32;
     const dim3 grid((vocab + rpb - 1) / rpb);
     const size_t smem = (size_t) rows * hidden * 2;

@@ -671,9 +671,16 @@ class ExLlama:
     # The three stages of a forward pass, also used one stage per process by exllama_amd/pipeline.py (layer split
     # across processes: rank 0 embeds, every rank runs its own layers, the last rank applies norm + lm_head).
     def embed(self, input_ids):
+        """Embedding lookup.  The HIP gather clamps ids to the table (a device-side id cannot raise); ids that arrive from the HOST
+        are checked here first, so a tokenizer / vocabulary mismatch fails as loudly as torch's embedding (and the reference,
+        model.py:1002) does.  Ids that are already device tensors (the decode loop's own tokens) are not synchronised on."""
         cfg = self.config
+        if not input_ids.is_cuda and input_ids.numel():
+            lo, hi = int(input_ids.min()), int(input_ids.max())
+            if lo < 0 or hi >= self.embed_weight.shape[0]:
+                raise IndexError(f"token id out of range: [{lo}, {hi}] not within the embedding table's {self.embed_weight.shape[0]} rows")
         ids = _move_tensor(input_ids, cfg.device_map.embed_tokens, "input_ids", cfg)
-        if ids.is_cuda and self.embed_weight.is_cuda and self.embed_weight.dtype == torch.float16:
+        if ids.is_cuda and self.embed_weight.is_cuda and self.embed_weight.dtype == torch.float16 and self.embed_weight.shape[1] % 8 == 0:
             out = torch.empty(tuple(ids.shape) + (self.embed_weight.shape[1],), dtype=torch.float16, device=ids.device)
             ext.embedding(ids.contiguous().to(torch.int64), self.embed_weight, out)      # HIP gather (reference: torch embedding, model.py:1002)
             return out
