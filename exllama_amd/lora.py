@@ -83,4 +83,14 @@ class ExLlamaLora:
         if half == "lora_B" and self.lora_scaling != 1.0:
             t = t * self.lora_scaling                        # in the source dtype, then one rounding to fp16 (lora.py:104-115)
         t = t.to(torch.float16)
+        # an act-order down_proj folded into its producers at load (exllama_amd.model._fold_act_order_down_proj): the intermediate
+        # activations travel in down_proj's row order, so the adapter halves that touch them are put into the same order
+        parts = norm.split(".")
+        if parts[3] == "mlp":
+            fold = getattr(self.model.layers[int(parts[2])].mlp, "fold_map", None)
+            if fold is not None:
+                if parts[4] in ("gate_proj", "up_proj") and half == "lora_B":
+                    t = t[:, fold].contiguous()
+                elif parts[4] == "down_proj" and half == "lora_A":
+                    t = t[fold, :].contiguous()
         self.tensors[norm] = t.to(self.config.device_map.map(norm), non_blocking=True)

@@ -194,9 +194,65 @@ class ExLlamaRMSNorm:
         return cuda_ext.ext_rms_norm(hidden_states, self.weight, self.variance_epsilon)
 
 
+def _fold_act_order_down_proj(tensors, key):
+    """Act-order down_proj, resolved at LOAD time instead of per forward pass.  The reference gathers down_proj's input through
+    its row map before every matmul (column_remap, q4_matmul.cu:320-325) after repacking the rows into group order
+    (make_sequential, q4_matrix.cu:104-168).  down_proj's input has ONE producer -- silu(gate) * up, elementwise in the columns of
+    gate_proj / up_proj -- so the permutation can live in the producers instead: the COLUMNS of gate_proj and up_proj (qweight,
+    scales, qzeros nibbles) are put into down_proj's sequential row order, and down_proj's own rows are repacked into that order
+    here (the same integer repack make_q4 would do).  down_proj then is an ordinary matrix without a group index: no gather in
+    the prompt pass (113 MB per 13B layer), no permuted store in the decode executor.  Every output element is computed from the
+    same weights and activations in the same summation order, so the logits do not change by a bit (tested).  In place on the
+    device tensors (the weight arena keeps its layout); returns the map (new row -> old row, CPU int64) or None."""
+    gk = key + ".down_proj.g_idx"
+    if gk not in tensors:
+        return None
+    g_idx = tensors[gk].detach().cpu().to(torch.int64)
+    if bool((g_idx == 0).all()):
+        return None
+    names = ("qweight", "qzeros", "scales")
+    gate, up, down = ({n: tensors[f"{key}.{p}.{n}"] for n in names} for p in ("gate_proj", "up_proj", "down_proj"))
+    dev = down["qweight"].device
+    K8, N = down["qweight"].shape
+    K = K8 * 8
+    if any(t.device != dev for d in (gate, up) for t in d.values()) or gate["qweight"].shape[1] != K or up["qweight"].shape[1] != K:
+        return None
+    x_map = torch.sort(g_idx, stable=True).indices                      # make_q4's counting sort: new row -> old row
+    xm = x_map.to(dev)
+    with torch.no_grad():
+        # down_proj: nibble k of packed row r is weight row 8 r + k (matrix.cuh:73-77); new row i takes old row x_map[i]
+        qw = down["qweight"]
+        nib = torch.empty((K, N), dtype=torch.uint8, device=dev)
+        for k in range(8):
+            nib[k::8] = ((qw >> (4 * k)) & 0xF).to(torch.uint8)
+        nib = nib[xm]
+        acc = torch.zeros_like(qw)
+        for k in range(8):
+            acc |= nib[k::8].to(torch.int32) << (4 * k)
+        qw.copy_(acc)
+        del nib, acc
+        # gate_proj / up_proj: column c of the new matrices is old column x_map[c]
+        sh = torch.arange(0, 32, 4, device=dev, dtype=torch.int32)
+        for m in (gate, up):
+            m["qweight"].copy_(m["qweight"][:, xm])
+            m["scales"].copy_(m["scales"][:, xm])
+            qz = m["qzeros"]                                             # [G, N / 8]: nibble j of word w is column 8 w + j
+            z = ((qz.unsqueeze(-1) >> sh) & 0xF).reshape(qz.shape[0], -1)[:, xm].reshape(qz.shape[0], -1, 8)
+            packed = torch.zeros_like(qz)
+            for j in range(8):
+                packed |= z[:, :, j].to(torch.int32) << (4 * j)
+            qz.copy_(packed)
+    del tensors[gk]
+    return x_map
+
+
 class ExLlamaMLP:
     def __init__(self, config, tensors, key):
         self.config = config
+        # act-order down_proj folded into the column order of gate_proj / up_proj (not for tensor-parallel shards, whose cuts assume
+        # the checkpoint's order; config.fold_act_order_mlp = False keeps the reference's run-time gather)
+        self.fold_map = (_fold_act_order_down_proj(tensors, key)
+                         if config.tp is None and getattr(config, "fold_act_order_mlp", True) and tensors[key + ".down_proj.qweight"].is_cuda else None)
         h, i = config.hidden_size, config.intermediate_size
         self.gate_proj = Ex4bitLinear(config, h, i, False, tensors, key + ".gate_proj")
         self.up_proj = Ex4bitLinear(config, h, i, False, tensors, key + ".up_proj")

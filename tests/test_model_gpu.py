@@ -685,3 +685,42 @@ def test_layer_split_runner_token_ring_on_one_rank_equals_generate_greedy():
         assert got.tolist() == want, (capture, got.tolist(), want)
         assert cache.current_seq_len == 150 + n
     model.free_unmanaged()
+
+
+@pytest.mark.parametrize("name,gs", [("tiny_hd128", 128), ("tiny_gqa", 64)])
+def test_act_order_down_proj_folded_at_load_changes_no_bit(name, gs):
+    """exllama_amd.model._fold_act_order_down_proj: an act-order down_proj's row permutation is moved into the COLUMN order of its
+    producers (gate_proj, up_proj) when the model is loaded, and down_proj becomes an ordinary matrix: the reference's column_remap
+    of the intermediate activations (q4_matmul.cu:320-325; the largest gather of a layer) and the decode executor's permuted store
+    disappear.  Same weights, same activations, same summation order: prompt logits (short-prompt kernels and the fused long-prompt
+    launches), K / V rows and decode steps (op path and executor) must be IDENTICAL to the model loaded with the fold switched off."""
+    from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
+    dims = synth.PRESETS[name]
+    tensors = synth.make_checkpoint(dims, groupsize=gs, act_order="gptq", seed=41, device="cpu", zeros="rand")
+    runs = {}
+    for fold in (True, False):
+        cfg = ExLlamaConfig(synth.config_dict(dims))
+        cfg.max_seq_len = 700
+        cfg.max_input_len = 640
+        cfg.fold_act_order_mlp = fold
+        model = ExLlama(cfg, tensors={k: v.clone() for k, v in tensors.items()})
+        assert all((l.mlp.fold_map is not None) == fold for l in model.layers)
+        assert all((l.mlp.down_proj.g_idx is None) == fold for l in model.layers)
+        out = {}
+        for S in (40, 600):                                           # <= 256 rows: skinny GEMM; > 512: the fused prompt launches
+            ids = torch.randint(1, dims.vocab_size, (1, S), generator=torch.Generator().manual_seed(S)).to("cuda:0")
+            cache = ExLlamaCache(model)
+            out[f"prefill{S}"] = model.forward(ids, cache, last_id_only=False).cpu()
+            out[f"k{S}"] = cache.key_states[-1][:, :, :S].cpu()
+            tok = out[f"prefill{S}"][0, -1].argmax().view(1, 1).to("cuda:0")
+            out[f"ops{S}"] = model.forward(tok, cache).cpu()              # q4_attn / q4_mlp op path
+            cache.current_seq_len = S
+            if dims.head_dim == 128:
+                model.enable_decode_graph(cache)
+                out[f"exec{S}"] = torch.stack([model.forward(tok, cache).cpu() for _ in range(3)])
+                model.disable_decode_graph()
+        runs[fold] = out
+        model.free_unmanaged()
+    for k, v in runs[True].items():
+        assert torch.isfinite(v.float()).all(), k
+        assert torch.equal(v, runs[False][k]), k
