@@ -552,8 +552,9 @@ def main():
     # scripts/bench_dropin.py (it executes reference code, which exists only where the archive was staged) and quoted here
     if rank == 0 and args.model == "7b" and args.groupsize == 128:
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_dropin_reference_model_py.json")) as f:
-                result["dropin_reference_model_py"] = dict(json.load(f), source="offline: scripts/bench_dropin.py, committed under profiles/; not re-measured in this run")
+            with open(os.path.join(ROOT, "profiles", "r04_dropin_reference_model_py_compiled_binding.json")) as f:
+                result["dropin_reference_model_py"] = dict(json.load(f), source="offline: scripts/bench_dropin.py (round 4, compiled binding; same box on the ctypes path: "
+                                                           "profiles/r04_dropin_reference_model_py_ctypes_same_box.json), committed under profiles/; not re-measured in this run")
         except Exception:
             pass
 
@@ -593,20 +594,20 @@ def decoder_roofline_probe(model, cache, dims, g, ctx, steps=6):
     dom = "gate_up"
     achieved = per_launch[dom] / (ms[dom] / L / 1e3) / 1e9
     # HBM traffic of the same kernel from the PMC counters: collected OFFLINE in separate rocprofv3 --pmc passes
-    # (scripts/gpu_r03_profiles.sh -> profiles/r03_pmc_traffic.json); only valid for the shapes it was measured on
+    # (scripts/gpu_r04_profiles.sh -> profiles/r04_pmc_traffic.json); only valid for the shapes it was measured on
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) as f:
             pmc = json.load(f)
         if (h, I, g) == (4096, 11008, 128):
-            traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+            traffic = pmc["decode_classes"][dom]["hbm_bytes_per_launch"]
     except Exception:
         traffic = None
     return {"bound": "hbm", "kernel": "dec_ring_kernel<PNORM=1, EMODE=2> (fused RMSNorm + gate/up projections + SiLU*mul, one launch per layer)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
-            "traffic_source": ("offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (scripts/gpu_r03_profiles.sh), FETCH_SIZE doubled per "
-                               "MI355X_MICROARCH.md, committed as profiles/r03_pmc_traffic.json; not re-measured in this run") if traffic else None,
+            "traffic_source": ("offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (scripts/gpu_r04_profiles.sh), FETCH_SIZE doubled per "
+                               "MI355X_MICROARCH.md, committed as profiles/r04_pmc_traffic.json; not re-measured in this run") if traffic else None,
             "launches": L * steps, "avg_launch_us": round(ms[dom] * 1e3 / L, 3),
             "algorithmic_bytes_per_launch": int(per_launch[dom]), "classes": classes,
             "token_ms_sum_of_classes": round(sum(ms.values()), 4),
@@ -638,9 +639,19 @@ def prefill_gemm_probe(model, dims, S, dev, reps=2):
     us = e0.elapsed_time(e1) * 1e3 / (reps * len(mlps))
     flops = 2 * 2.0 * S * h * I
     tf = flops / us / 1e6
+    traffic = None
+    try:                                                          # L2 <-> fabric bytes of the same kernel at the 7B shape (offline PMC passes)
+        with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) as f:
+            pre = json.load(f)["prefill"]
+        if (h, I, S) == (4096, 11008, 2048):
+            traffic = [v["hbm_bytes_per_launch"] for k, v in pre.items() if "q4_gemm_t16d2" in k][0]
+    except Exception:
+        traffic = None
     return {"bound": "mfma", "kernel": "q4_gemm_t16d2_kernel (fused int4 dequant + gate/up MFMA GEMMs + SiLU*mul, one launch per layer)",
             "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
-            "launches": reps * len(mlps), "avg_launch_us": round(us, 2), "flops_per_launch": int(flops), "rows": S}
+            "launches": reps * len(mlps), "avg_launch_us": round(us, 2), "flops_per_launch": int(flops), "rows": S,
+            "traffic": traffic, "algorithmic_bytes_per_launch": int(h * I + 2.5 * 2 * (h // 128) * I + 2 * S * (h + I)),
+            "traffic_source": "offline: profiles/r04_pmc_traffic.json (scripts/gpu_r04_profiles.sh)" if traffic else None}
 
 
 def gemv_roofline_probe(model, groupsize, dev, tokens=3):
