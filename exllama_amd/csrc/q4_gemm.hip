@@ -570,7 +570,30 @@ __global__ __launch_bounds__(256) void q4_gemm_splitk_reduce_kernel(const float*
 // head of q, k or v (three matrices sharing x and K, tiles numbered across them); the epilogue applies RoPE to q and k
 // (the partner column d +- 64 sits in the other column wave: exchanged through LDS) and writes q to its buffer, k and v
 // straight into the KV cache -- the reference runs 3 matmuls, 2 RoPE kernels and a cache scatter (model.py:431-445).
-struct GemmTail { int b_split, parts; float* ws; };      // see plan_gemm_tail
+struct GemmTail { int b_split, parts; float* ws; int mr; };      // see plan_gemm_tail; mr: row tiles per XCD rectangle (gemm_tile_of)
+
+// Logical block -> (row tile, column tile).  Block b runs on XCD b % 8 (observed dispatch order; speed only), so the blocks b, b + 8,
+// b + 16 ... are what ONE XCD's 32 CUs hold at a time and its 4 MiB L2 serves.  They walk the column tiles the XCD owns (nt % 8 ==
+// xcd) for `mr` row tiles at a time: with mr = 2 the concurrent set is 2 row tiles x up to 16 column tiles, whose K slices of
+// activations (2 x 256 rows) and of weights (16 x 128 columns, packed) are about the same size -- the rectangle that needs the
+// fewest bytes from outside the L2 per tile.  mr = mtiles is the order of rounds 1-3 (every row tile of 4 column tiles at a time:
+// the whole activation matrix, 16.8 MB at K = 4096, streamed through each L2 for every four column tiles -- PMC in round 4: 667 MB
+// of fabric traffic per q/k/v launch against 93 MB of algorithmic bytes, profiles/r04_pmc_traffic.json).
+__host__ __device__ __forceinline__ bool gemm_tile_of(int b, int mtiles, int ntiles, int mr, int* mt, int* nt)
+{
+    const int xcd = b & 7, idx = b >> 3;
+    const int nper = (ntiles + 7) >> 3;
+    const int grp = mr * nper;
+    const int mg = idx / grp, r = idx - mg * grp;
+    const int m0 = mg * mr;
+    int gsz = mtiles - m0;
+    if (gsz > mr) gsz = mr;
+    if (gsz <= 0) return false;
+    const int j = r / gsz;
+    *mt = m0 + (r - j * gsz);
+    *nt = j * 8 + xcd;
+    return j < nper && *nt < ntiles;
+}
 struct GwQkv {
     const uint4* qw[3]; const uint32_t* qz[3]; const f16* sc[3];
     int n[3];                      // out_features of q, k, v
@@ -603,12 +626,8 @@ __global__ __launch_bounds__((GW_CONS + GW_PROD) * 64) void q4_gemm_t16w_kernel(
         b = tail.b_split + tseq;
         nparts = tail.parts;
     }
-    const int xcd = b & 7;
-    const int idx = b >> 3;
-    const int nl = idx / mtiles;
-    const int mt = idx - nl * mtiles;
-    int nt = nl * 8 + xcd;
-    if (nt >= ntiles) return;
+    int mt, nt;
+    if (!gemm_tile_of(b, mtiles, ntiles, tail.mr, &mt, &nt)) return;
     const int m0 = mt * TBM;
     int mi = 0;                                                        // EPI 1: which of q / k / v this block works on
     if constexpr (EPI == 1) {
@@ -922,10 +941,8 @@ __global__ __launch_bounds__(256) void q4_gemm_tail_reduce_kernel(f16* __restric
                                                                   int mtiles, int ntiles, const GemmTail tail)
 {
     const int b = tail.b_split + blockIdx.x;
-    const int xcd = b & 7, idx = b >> 3;
-    const int nl = idx / mtiles, mt = idx - nl * mtiles;
-    const int nt = nl * 8 + xcd;
-    if (nt >= ntiles) return;
+    int mt, nt;
+    if (!gemm_tile_of(b, mtiles, ntiles, tail.mr, &mt, &nt)) return;
     const int m0 = mt * 256, n0 = nt * GT_BN;
     constexpr int SLICE = (DUAL ? 2 : 1) * 256 * 128;
     const float* w0 = tail.ws + (size_t) blockIdx.x * tail.parts * SLICE;
@@ -982,7 +999,9 @@ static int plan_gemm_tail(int device, int mtiles, int ntiles, int K, int slices_
 {
     static const bool off = getenv("EXL_GEMM_NO_TAIL_SPLIT") != nullptr;      // A/B switch
     const int padded = 8 * ((ntiles + 7) / 8) * mtiles;
+    static const int mr_env = getenv("EXL_GEMM_TILE_ROWS") ? atoi(getenv("EXL_GEMM_TILE_ROWS")) : 2;   // A/B switch: 0 = the order of rounds 1-3
     t->b_split = padded; t->parts = 1; t->ws = nullptr;
+    t->mr = mr_env > 0 && mr_env < mtiles ? mr_env : mtiles;
     *n_tail = 0;
     int ncu = 256;
     {
@@ -1015,8 +1034,8 @@ static int plan_gemm_tail(int device, int mtiles, int ntiles, int K, int slices_
     // the logical block after which `full` valid tiles have been dispatched
     int valid = 0, bs = 0;
     for (; bs < padded && valid < full; ++bs) {
-        const int nt = (bs >> 3) / mtiles * 8 + (bs & 7);
-        if (nt < ntiles) ++valid;
+        int mt_, nt_;
+        if (gemm_tile_of(bs, mtiles, ntiles, t->mr, &mt_, &nt_)) ++valid;
     }
     const int nl_tail = padded - bs;
     float* ws = nullptr;
@@ -1099,11 +1118,14 @@ int launch_q4_qkv_rope_cache(const Q4Matrix* wq, const Q4Matrix* wk, const Q4Mat
     e.q_len = q_len; e.past_len = past_len; e.max_seq = max_seq; e.kv_heads = kv_heads;
     const int mtiles = (rows + 255) / 256;
     const int grid = 8 * ((tiles + 7) / 8) * mtiles;
+    GemmTail qkv_order;
+    int no_tail = 0;
+    (void) plan_gemm_tail(-1, mtiles, tiles, 128, 1, &qkv_order, &no_tail);        // (K = 128: no part count divides it -> the tile order only, whole tiles)
     const size_t smem = 3 * (size_t) 256 * 128 + 2 * GT_BTILE_BYTES;
     static bool big[EXL_MAX_DEVICES] = {};
     EXL_TRY(exl_lds_opt_in((const void*) q4_gemm_t16w_kernel<1>, big));
     hipLaunchKernelGGL(q4_gemm_t16w_kernel<1>, dim3(grid), dim3((GW_CONS + GW_PROD) * 64), smem, s, x, (const uint4*) nullptr, (const uint32_t*) nullptr,
-                       (const f16*) nullptr, (f16*) nullptr, rows, K, 0, gshift, 0, mtiles, tiles, e, GemmTail{1 << 30, 1, nullptr});
+                       (const f16*) nullptr, (f16*) nullptr, rows, K, 0, gshift, 0, mtiles, tiles, e, qkv_order);
     EXL_LAUNCH_CHECK();
     return 0;
 }
@@ -1146,12 +1168,8 @@ __global__ __launch_bounds__(512) void q4_gemm_t16d2_kernel(const f16* __restric
         b = tail.b_split + tseq;
         nparts = tail.parts;
     }
-    const int xcd = b & 7;
-    const int idx = b >> 3;
-    const int nl = idx / mtiles;
-    const int mt = idx - nl * mtiles;
-    const int nt = nl * 8 + xcd;
-    if (nt >= ntiles) return;
+    int mt, nt;
+    if (!gemm_tile_of(b, mtiles, ntiles, tail.mr, &mt, &nt)) return;
     const int m0 = mt * TBM;
     const int n0 = nt * GT_BN;
 
@@ -1392,7 +1410,7 @@ int launch_q4_gemm_dual(const Q4Matrix* w1, const Q4Matrix* w2, const f16* x, in
     if ((w1->groupsize & (w1->groupsize - 1)) == 0) { gshift = 0; while ((1 << gshift) < w1->groupsize) ++gshift; }
     const int mtiles = (rows + 255) / 256;
     const int ntiles = (N + GT_BN - 1) / GT_BN;
-    GemmTail tail = {1 << 30, 1, nullptr};
+    GemmTail tail = {1 << 30, 1, nullptr, mtiles};
     int n_tail = 0;
     const int grid = plan_gemm_tail(w1->device, mtiles, ntiles, K, 2, &tail, &n_tail);                 // the same split as either product alone: same bits
 #define GD_ARGS x, (const uint4*) w1->qweight, w1->qzeros, w1->scales, (const uint4*) w2->qweight, w2->qzeros, w2->scales, out1, out2, \
