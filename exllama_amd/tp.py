@@ -9,10 +9,13 @@ Partitioning (Megatron-style, restated for GPTQ tensors):
   * o / down projections: split by INPUT rows -- the rows that multiply the columns this rank produced -- so a layer needs no
     exchange between its two matmuls; every rank ends with a partial sum of the full output and ONE all-reduce per half layer
     (2 per layer) restores the replicated residual stream.  qweight is cut along K/8, qzeros / scales along their group axis.
-  * act-order (g_idx) o / down matrices cannot be cut by rows: the rows of a quantisation group are scattered over the input
-    features, a row range holds ragged pieces of many groups.  They are cut by output columns instead; the rank then needs the
-    FULL input (all-gather of the attention output / activation) and the outputs are all-gathered ("gather mode": two
-    all-gathers instead of one all-reduce, op-by-op path only).
+  * act-order (g_idx) matrices cannot be cut by rows as they are: the rows of a quantisation group are scattered over the input
+    features, a row range holds ragged pieces of many groups.  down_proj's row permutation is therefore FOLDED into the column
+    order of its producers first (exllama_amd.model._fold_act_order_down_proj, round 4: gate / up columns and down rows in
+    down_proj's sequential order, bit-identical results) -- after which down_proj is an ordinary matrix, cut by rows, in the
+    executor like any other.  o_proj's input is the attention output, whose column order belongs to the heads: an act-order o_proj
+    is cut by output columns instead; the rank then needs the FULL input (all-gather of the attention output) and the outputs are
+    all-gathered ("gather mode": two all-gathers instead of one all-reduce, op-by-op path only).
   * lm_head is cut by vocabulary rows (the logits are all-gathered); embedding (one row read per token) and norms are replicated.
 The KV cache of a rank holds its own kv heads only.
 
@@ -131,8 +134,19 @@ def shard_tensors(tensors, config_dict, rank, world):
     hd = plan.head_dim
     out = {}
     done = set()
+    plan.fold_maps = {}                                             # layer -> down_proj's row map folded into gate / up (new row -> old row)
+    from .model import _fold_act_order_down_proj
+    tensors = dict(tensors)                                         # (folded MLP tensors replace the caller's in this view only)
     for i in range(config_dict["num_hidden_layers"]):
         p = f"model.layers.{i}."
+        gd = tensors.get(p + "mlp.down_proj.g_idx")
+        if gd is not None and _is_act_order(gd, tensors[p + "mlp.down_proj.qweight"].shape[0] * 8 // tensors[p + "mlp.down_proj.qzeros"].shape[0]):
+            for leaf in ("gate_proj", "up_proj", "down_proj"):      # the fold works in place: on copies
+                for suffix in (".qweight", ".qzeros", ".scales"):
+                    tensors[p + "mlp." + leaf + suffix] = tensors[p + "mlp." + leaf + suffix].clone()
+            fm = _fold_act_order_down_proj(tensors, p + "mlp")
+            if fm is not None:
+                plan.fold_maps[i] = fm
         _cols(tensors, p + "self_attn.q_proj", plan.heads[0] * hd, plan.heads[1] * hd, out)
         _cols(tensors, p + "self_attn.k_proj", plan.kv_heads[0] * hd, plan.kv_heads[1] * hd, out)
         _cols(tensors, p + "self_attn.v_proj", plan.kv_heads[0] * hd, plan.kv_heads[1] * hd, out)

@@ -39,13 +39,21 @@ def test_shards_tile_the_full_matrices(preset, gs, act, world):
     assert [pl.heads for pl in plans][0][0] == 0 and plans[-1].heads[1] == dims.num_attention_heads
     assert all(plans[r].heads[1] == plans[r + 1].heads[0] and plans[r].inter[1] == plans[r + 1].inter[0] for r in range(world - 1))
     assert plans[0].inter[0] == 0 and plans[-1].inter[1] == dims.intermediate_size
+    # act-order: down_proj's row map is folded into the column order of gate / up before the cut (every rank computes the same map)
+    fold = plans[0].fold_maps.get(0)
+    assert (fold is not None) == bool(act) and all(torch.equal(pl.fold_maps[0], fold) for pl in plans if act)
+    fm = None if fold is None else fold.numpy()
     for name in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "mlp.gate_proj", "mlp.up_proj"):
         full = _w(t, p + name)
+        if fm is not None and name.startswith("mlp."):
+            full = full[:, fm]
         assert np.array_equal(np.concatenate([_w(s, p + name) for s, _ in shards], axis=1), full), name
-    for name in ("self_attn.o_proj", "mlp.down_proj"):
-        full = _w(t, p + name)
-        axis = 1 if act else 0                                            # act-order: gather mode = cut by output columns
-        assert np.array_equal(np.concatenate([_w(s, p + name) for s, _ in shards], axis=axis), full), name
+    full = _w(t, p + "self_attn.o_proj")                                  # act-order: gather mode = cut by output columns
+    assert np.array_equal(np.concatenate([_w(s, p + "self_attn.o_proj") for s, _ in shards], axis=1 if act else 0), full)
+    full = _w(t, p + "mlp.down_proj")                                     # always by rows -- the sequential rows once the map is folded
+    assert all((p + "mlp.down_proj.g_idx") not in s for s, _ in shards if act)
+    assert np.array_equal(np.concatenate([_w(s, p + "mlp.down_proj") for s, _ in shards], axis=0), full if fm is None else full[fm])
+    assert torch.equal(t[p + "mlp.gate_proj.qweight"], _ckpt(preset, gs, act)[2][p + "mlp.gate_proj.qweight"])   # the caller's checkpoint is untouched
     # replicated tensors are the same objects; the local config describes the local shapes
     assert torch.equal(torch.cat([s["lm_head.weight"] for s, _ in shards], dim=0), t["lm_head.weight"])     # vocabulary rows
     for s, pl in shards:
@@ -110,13 +118,9 @@ def _worker(rank, world, port, act, out):
     rng = np.random.default_rng(0)
     x = rng.standard_normal((5, dims.hidden_size)).astype(np.float32)
     attn_full = rng.standard_normal((5, dims.hidden_size)).astype(np.float32)     # stands for the attention output, head-major
-    # MLP: column-parallel gate / up, then row-parallel down + all-reduce (gather mode for act-order)
+    # MLP: column-parallel gate / up, then row-parallel down + all-reduce (act-order too: down_proj's map is folded into gate / up)
     a = _silu(x @ _w(local, p + "mlp.gate_proj")) * (x @ _w(local, p + "mlp.up_proj"))
-    if act:
-        a_full = comm.all_gather_last(torch.from_numpy(a), plan.inter_sizes).numpy()
-        y = comm.all_gather_last(torch.from_numpy(a_full @ _w(local, p + "mlp.down_proj")), plan.hidden_sizes).numpy()
-    else:
-        y = comm.all_reduce(torch.from_numpy(a @ _w(local, p + "mlp.down_proj"))).numpy()
+    y = comm.all_reduce(torch.from_numpy(a @ _w(local, p + "mlp.down_proj"))).numpy()
     # o_proj over this rank's heads
     hd = plan.head_dim
     mine = attn_full[:, plan.heads[0] * hd:plan.heads[1] * hd]
