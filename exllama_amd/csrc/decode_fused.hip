@@ -952,6 +952,12 @@ __global__ void dec_map16_kernel(const uint32_t* __restrict__ x_map, uint16_t* _
     inv16[src] = (uint16_t) c;
 }
 
+__global__ void dec_ident16_kernel(uint16_t* __restrict__ m, int K)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < K) m[c] = (uint16_t) c;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // K6: final RMSNorm + fp16 lm_head GEMV (one wave per vocabulary row, 128-bit loads) -> fp32 logits
 // ---------------------------------------------------------------------------------------------------------------
@@ -1235,6 +1241,15 @@ extern "C" int exl_decoder_set_layer(void* dec, int index, void* q, void* k, voi
             uint16_t* m16 = base; uint16_t* i16 = base + K;
             base += 2 * (size_t) K;
             *mp[i] = nullptr;
+            if (i == 6 && !ms[i]->x_map && l.gate->x_map) {
+                // act-order gate / up in front of a down_proj WITHOUT a map (its permutation folded into their column order at load,
+                // model.py: _fold_act_order_down_proj): the gathering launch stores through a map by construction (decode_ring.hip:
+                // its requests are part of the hand-counted stream) -- here the identity, i.e. the natural order
+                hipLaunchKernelGGL(dec_ident16_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t) 0, i16, K);
+                e = hipGetLastError();
+                inv[i] = i16;
+                continue;
+            }
             if (!ms[i]->x_map) continue;
             hipLaunchKernelGGL(dec_map16_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t) 0, ms[i]->x_map, m16, i16, K);
             e = hipGetLastError();

@@ -1630,9 +1630,91 @@ __global__ __launch_bounds__(256) void half_gemm64_kernel(const f16* __restrict_
     }
 }
 
+// LoRA down-projection of a few rows: out[M <= 8, N <= 64] (+)= x[M, K] @ w[K, N] with a LONG K (hidden / intermediate size) and a
+// handful of output columns (the adapter rank).  The 64 x 64 tile kernels above walk that K in ONE block (64-170 us per call:
+// 7 such products per layer made decoding with an adapter 11 x slower than without, profiles/r04_lora.json); here K is cut over
+// up to 64 blocks, each lane owns 8 consecutive columns of one k row (16-byte loads, rows of w are contiguous), the lanes of a
+// wave that share the column chunk are summed by shuffles, the waves through LDS, and the blocks' fp32 partial sums land in a
+// workspace that half_skinny_finish_kernel adds up in a fixed order (deterministic; one rounding to fp16, like the tile kernels).
+#define HS_MAXM 8
+__global__ __launch_bounds__(256) void half_skinny_partial_kernel(const f16* __restrict__ x, const f16* __restrict__ w, float* __restrict__ part,
+                                                                  int M, int K, int N, int kslice)
+{
+    __shared__ float red[4][8][HS_MAXM][8];                          // [wave][column chunk][row][column in chunk]
+    const int nc = (N + 7) >> 3;                                      // column chunks of 8 (<= 8)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane % nc, kl = lane / nc;                          // lanes of a wave: (k row in the pass, column chunk); 64 / nc rows per wave and pass
+    const int rows_per_wave = 64 / nc;                                // (nc in {1, 2, 4, 8}: the launcher pads N to that)
+    const int k0 = blockIdx.x * kslice, k1 = min(K, k0 + kslice);
+    float acc[HS_MAXM][8];
+#pragma unroll
+    for (int m = 0; m < HS_MAXM; ++m)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[m][j] = 0.f;
+    for (int k = k0 + wave * rows_per_wave + kl; k < k1; k += 4 * rows_per_wave) {
+        f16x8 wv = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (c * 8 + 8 <= N) wv = *(const f16x8*) (w + (size_t) k * N + c * 8);
+        else for (int j = 0; j < 8 && c * 8 + j < N; ++j) wv[j] = w[(size_t) k * N + c * 8 + j];
+#pragma unroll
+        for (int m = 0; m < HS_MAXM; ++m) {
+            if (m >= M) break;
+            const float xv = (float) x[(size_t) m * K + k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[m][j] = fmaf(xv, (float) wv[j], acc[m][j]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < HS_MAXM; ++m) {
+        if (m >= M) break;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = acc[m][j];
+            for (int off = nc; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);    // lanes with the same column chunk
+            if (kl == 0) red[wave][c][m][j] = v;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < M * nc * 8; i += 256) {
+        const int m = i / (nc * 8), cc = (i / 8) % nc, j = i & 7;
+        const float v = red[0][cc][m][j] + red[1][cc][m][j] + red[2][cc][m][j] + red[3][cc][m][j];
+        if (cc * 8 + j < N) part[((size_t) blockIdx.x * M + m) * N + cc * 8 + j] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void half_skinny_finish_kernel(const float* __restrict__ part, f16* __restrict__ out, int cells, int nparts, int no_zero)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cells) return;
+    float v = 0.f;
+    for (int p = 0; p < nparts; ++p) v += part[(size_t) p * cells + i];
+    if (no_zero) v += (float) out[i];
+    out[i] = (f16) v;
+}
+
 int launch_half_gemm(const f16* x, const f16* w, f16* out, int M, int K, int N, int no_zero, hipStream_t s)
 {
     if (M <= 0 || N <= 0) return 0;
+    if (M <= HS_MAXM && N <= 64 && K >= 1024 && N % 8 == 0 && (((uintptr_t) w) & 15) == 0) {
+        int nc = N / 8;
+        if (nc == 3) nc = 4; else if (nc > 4) nc = 8;                 // a power of two chunks per k row (the lanes of a wave split evenly)
+        // (the kernel derives its chunk count from N: pass the padded width through the launch geometry only when N itself is 8, 16, 32 or 64)
+        if (nc * 8 == N) {
+            int dev = 0;
+            EXL_HIP(hipGetDevice(&dev));
+            int nparts = (K + 255) / 256;
+            if (nparts > 64) nparts = 64;
+            const int kslice = ((K + nparts - 1) / nparts + 7) & ~7;
+            nparts = (K + kslice - 1) / kslice;
+            float* ws = nullptr;
+            if (exl_gemm_workspace(dev, (size_t) nparts * M * N, &ws) == 0) {
+                hipLaunchKernelGGL(half_skinny_partial_kernel, dim3(nparts), dim3(256), 0, s, x, w, ws, M, K, N, kslice);
+                EXL_LAUNCH_CHECK();
+                hipLaunchKernelGGL(half_skinny_finish_kernel, dim3((M * N + 255) / 256), dim3(256), 0, s, ws, out, M * N, nparts, no_zero);
+                EXL_LAUNCH_CHECK();
+                return 0;
+            }
+        }
+    }
     dim3 grid((N + 63) / 64, (M + 63) / 64);
     const bool vec = K % 8 == 0 && N % 8 == 0 && (((uintptr_t) x | (uintptr_t) w) & 15) == 0;
     if (vec) hipLaunchKernelGGL(half_gemm64_kernel, grid, dim3(256), 0, s, x, w, out, M, K, N, no_zero);

@@ -327,7 +327,23 @@ def test_lora_adapter_end_to_end(name, gs, act):
     cache2 = ExLlamaCache(model)
     got = model.forward(ids.to("cuda:0"), cache2, last_id_only=False, lora=lora).float().cpu()
     orc = OracleLlama(synth.config_dict(dims), tensors, max_seq_len=64)
-    orc.set_lora({k: v.cpu() for k, v in lora.tensors.items()})
+    # the product's loader put the adapter halves that touch the MLP's intermediate activations into the order of the folded
+    # act-order down_proj (exllama_amd.lora / model._fold_act_order_down_proj); the oracle works on the checkpoint as it is
+    plain = {k: v.cpu() for k, v in lora.tensors.items()}
+    for i, layer in enumerate(model.layers):
+        fold = layer.mlp.fold_map
+        if fold is None:
+            continue
+        inv = torch.empty_like(fold)
+        inv[fold] = torch.arange(fold.numel())
+        for proj in ("gate_proj", "up_proj"):
+            k = f"model.layers.{i}.mlp.{proj}.lora_B.weight"
+            if k in plain:
+                plain[k] = plain[k][:, inv].contiguous()
+        k = f"model.layers.{i}.mlp.down_proj.lora_A.weight"
+        if k in plain:
+            plain[k] = plain[k][inv, :].contiguous()
+    orc.set_lora(plain)
     ref = torch.from_numpy(np.asarray(orc.forward(ids.numpy(), last_id_only=False), dtype=np.float32))
     scale = ref.abs().max().item()
     _model_close(got, ref, LORA_TOL, f"LoRA prefill {name}")
