@@ -574,11 +574,15 @@ struct GemmTail { int b_split, parts; float* ws; int mr; };      // see plan_gem
 
 // Logical block -> (row tile, column tile).  Block b runs on XCD b % 8 (observed dispatch order; speed only), so the blocks b, b + 8,
 // b + 16 ... are what ONE XCD's 32 CUs hold at a time and its 4 MiB L2 serves.  They walk the column tiles the XCD owns (nt % 8 ==
-// xcd) for `mr` row tiles at a time: with mr = 2 the concurrent set is 2 row tiles x up to 16 column tiles, whose K slices of
-// activations (2 x 256 rows) and of weights (16 x 128 columns, packed) are about the same size -- the rectangle that needs the
-// fewest bytes from outside the L2 per tile.  mr = mtiles is the order of rounds 1-3 (every row tile of 4 column tiles at a time:
-// the whole activation matrix, 16.8 MB at K = 4096, streamed through each L2 for every four column tiles -- PMC in round 4: 667 MB
-// of fabric traffic per q/k/v launch against 93 MB of algorithmic bytes, profiles/r04_pmc_traffic.json).
+// xcd) for `mr` row tiles at a time.  mr = mtiles (the default, the order of rounds 1-3): every row tile of 4 column tiles at a
+// time -- a weight tile is shared by 8 blocks, but the whole activation matrix (16.8 MB at K = 4096) streams through each L2 for
+// every four column tiles: PMC in round 4 saw 667 MB of fabric traffic per q/k/v launch against 93 MB of algorithmic bytes
+// (profiles/r04_pmc_traffic.json).  mr = 2 (EXL_GEMM_TILE_ROWS=2): 2 row tiles x up to 16 column tiles, K slices of activations
+// and packed weights of about equal size, the rectangle with the fewest bytes from outside the L2 per tile -- 283 MB for the same
+// launch.  MEASURED AND NOT MADE THE DEFAULT: 13B act-order prompt 38.5 / 38.7 k tokens/s with the rectangles against 39.8 / 39.6 k
+// with the old order (alternating runs on one box), 7B 78.5 vs 78.0 k: the traffic is not what bounds these kernels (the loader
+// waves wait 111 of 1473 cycles per K step), and a weight tile shared by 2 blocks instead of 8 makes the
+// latency-critical register loads of B miss the L2 more often than the deep activation DMA ring ever stalled.
 __host__ __device__ __forceinline__ bool gemm_tile_of(int b, int mtiles, int ntiles, int mr, int* mt, int* nt)
 {
     const int xcd = b & 7, idx = b >> 3;
@@ -999,7 +1003,7 @@ static int plan_gemm_tail(int device, int mtiles, int ntiles, int K, int slices_
 {
     static const bool off = getenv("EXL_GEMM_NO_TAIL_SPLIT") != nullptr;      // A/B switch
     const int padded = 8 * ((ntiles + 7) / 8) * mtiles;
-    static const int mr_env = getenv("EXL_GEMM_TILE_ROWS") ? atoi(getenv("EXL_GEMM_TILE_ROWS")) : 2;   // A/B switch: 0 = the order of rounds 1-3
+    static const int mr_env = getenv("EXL_GEMM_TILE_ROWS") ? atoi(getenv("EXL_GEMM_TILE_ROWS")) : 0;   // 0 (default) = every row tile of 4 column tiles; 2 = the low-traffic rectangles (measured slower)
     t->b_split = padded; t->parts = 1; t->ws = nullptr;
     t->mr = mr_env > 0 && mr_env < mtiles ? mr_env : mtiles;
     *n_tail = 0;
