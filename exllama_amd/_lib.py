@@ -86,6 +86,7 @@ SIGNATURES = {
     "exl_decoder_plan": (c_int, [c_void_p, c_int, C.POINTER(c_int)]),
     "exl_decoder_step_part": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "exl_decoder_set_tp": (c_int, [c_void_p, c_int]),
+    "exl_decoder_set_lora": (c_int, [c_void_p, c_int, C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_int)]),
     "exl_decoder_set_option": (c_int, [c_void_p, c_int, c_int]),
     "exl_rep_penalty": (c_int, [c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_int]),
     "exl_apply_rep_penalty": (c_int, [c_int, c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p]),

@@ -1070,6 +1070,136 @@ __global__ __launch_bounds__(1024) void dec_argmax_kernel(const float2* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LoRA inside the token step (reference: exllama_ext.cpp:245-324 q4_matmul_lora and the LoRA operands of q4_attn / q4_mlp,
+// :424-602): out = W x + (x A) B per projection.  Two small launches behind each GEMV launch of a layer that carries adapters:
+//   dec_lora_down_kernel   t_i = x A_i for the <= 3 matrices of the launch: K cut over DEC_LORA_PARTS blocks per matrix (a single
+//                          block walking K = 4096 .. 11008 costs 60-170 us; the 7 products of a layer made decoding with an
+//                          adapter 11 x slower than without), fp32 partial sums per block; x is RMSNormed first where the GEMV
+//                          launch norms its input (every block recomputes the row's sum of squares: 8 KiB from the L2);
+//   dec_lora_up_kernel     t_i = h(sum of the partials) (the reference's fp16 temporary), out_i[n] = h(out_i[n] + sum_j t_i[j] B_i[j][n])
+//                          -- or, for gate / up, act[n] = silu(g[n] + ..) * (u[n] + ..) on the two un-fused products.
+// ---------------------------------------------------------------------------------------------------------------
+#define DEC_LORA_PARTS 32
+#define DEC_LORA_MAXR 64
+struct DecLoraArgs {
+    const f16* x; const f16* norm_w; float eps; int K, nmat, kslice;
+    const f16* a[3]; const f16* b[3]; int r[3];
+    f16* out[3]; int n[3];
+    float* part;
+    int silu; f16* act;                                               // silu: out[0] / out[1] are the gate / up products, the result goes to act
+};
+
+__global__ __launch_bounds__(256) void dec_lora_down_kernel(const DecLoraArgs a)
+{
+    __shared__ float red[4][8][8];
+    __shared__ float ssq[4];
+    const int mi = blockIdx.y, p = blockIdx.x;
+    const int r = a.r[mi];
+    if (r <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float rm = 1.f;
+    if (a.norm_w) {                                                   // rms_norm.cu: fp32 sum of squares, r rounded to fp16, two fp16 multiplies
+        float sq = 0.f;
+        for (int k = tid * 8; k < a.K; k += 256 * 8) {
+            const f16x8 v = *(const f16x8*) (a.x + k);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = (float) v[j]; sq = fmaf(f, f, sq); }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+        if (lane == 0) ssq[wave] = sq;
+        __syncthreads();
+        rm = 1.0f / sqrtf((ssq[0] + ssq[1] + ssq[2] + ssq[3]) * (1.0f / (float) a.K) + a.eps);
+    }
+    const f16 rmh = (f16) rm;
+    int nc = (r + 7) >> 3;                                             // column chunks of 8, padded to a power of two <= 8
+    nc = nc <= 1 ? 1 : nc <= 2 ? 2 : nc <= 4 ? 4 : 8;
+    const int c = lane % nc, kl = lane / nc, rpw = 64 / nc;
+    const int k0 = p * a.kslice, k1 = min(a.K, k0 + a.kslice);
+    const f16* A = a.a[mi];
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = k0 + wave * rpw + kl; k < k1; k += 4 * rpw) {
+        f16 xv = a.x[k];
+        if (a.norm_w) { const f16 m = xv * rmh; xv = m * a.norm_w[k]; }
+        const float xf = (float) xv;
+        if (c * 8 + 8 <= r && (r & 7) == 0) {
+            const f16x8 wv = *(const f16x8*) (A + (size_t) k * r + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(xf, (float) wv[j], acc[j]);
+        } else {
+            for (int j = 0; j < 8 && c * 8 + j < r; ++j) acc[j] = fmaf(xf, (float) A[(size_t) k * r + c * 8 + j], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = acc[j];
+        for (int off = nc; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+        if (kl == 0) red[wave][c][j] = v;
+    }
+    __syncthreads();
+    if (tid < nc * 8 && tid < ((r + 7) & ~7)) {
+        const int cc = tid >> 3, j = tid & 7;
+        if (cc * 8 + j < r)
+            a.part[((size_t) mi * DEC_LORA_PARTS + p) * DEC_LORA_MAXR + cc * 8 + j] = red[0][cc][j] + red[1][cc][j] + red[2][cc][j] + red[3][cc][j];
+    }
+}
+
+__global__ __launch_bounds__(256) void dec_lora_up_kernel(const DecLoraArgs a, int nparts)
+{
+    __shared__ float t[3][DEC_LORA_MAXR];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < a.nmat * DEC_LORA_MAXR; i += 256) {          // t_i[j] = h(sum over the K parts), fixed order
+        const int mi = i / DEC_LORA_MAXR, j = i % DEC_LORA_MAXR;
+        float v = 0.f;
+        if (j < a.r[mi])
+            for (int p = 0; p < nparts; ++p) v += a.part[((size_t) mi * DEC_LORA_PARTS + p) * DEC_LORA_MAXR + j];
+        t[mi][j] = (float) (f16) v;
+    }
+    __syncthreads();
+    const int n8 = (blockIdx.x * 256 + tid) * 8;                       // 8 consecutive columns
+    if (a.silu) {
+        if (n8 >= a.n[0]) return;
+        float g[8], u[8];
+        const f16x8 gv = *(const f16x8*) (a.out[0] + n8), uv = *(const f16x8*) (a.out[1] + n8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { g[e] = 0.f; u[e] = 0.f; }
+        for (int j = 0; j < a.r[0]; ++j) {
+            const f16x8 bv = *(const f16x8*) (a.b[0] + (size_t) j * a.n[0] + n8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = fmaf(t[0][j], (float) bv[e], g[e]);
+        }
+        for (int j = 0; j < a.r[1]; ++j) {
+            const f16x8 bv = *(const f16x8*) (a.b[1] + (size_t) j * a.n[1] + n8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] = fmaf(t[1][j], (float) bv[e], u[e]);
+        }
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const f16 gh = a.r[0] > 0 ? (f16) ((float) gv[e] + (float) (f16) g[e]) : gv[e];     // h(product + h(adapter)): the adapter's own fp16 result, then one add
+            const f16 uh = a.r[1] > 0 ? (f16) ((float) uv[e] + (float) (f16) u[e]) : uv[e];
+            o[e] = silu_mul_f16(gh, uh);
+        }
+        *(f16x8*) (a.act + n8) = o;
+        return;
+    }
+    // plain: the matrices of the launch side by side in the column index
+    int mi = 0, n0 = n8;
+    while (mi < a.nmat && n0 >= a.n[mi]) { n0 -= a.n[mi]; ++mi; }
+    if (mi >= a.nmat || a.r[mi] <= 0) return;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < a.r[mi]; ++j) {
+        const f16x8 bv = *(const f16x8*) (a.b[mi] + (size_t) j * a.n[mi] + n0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(t[mi][j], (float) bv[e], acc[e]);
+    }
+    f16x8 ov = *(const f16x8*) (a.out[mi] + n0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ov[e] = (f16) ((float) ov[e] + (float) (f16) acc[e]);
+    *(f16x8*) (a.out[mi] + n0) = ov;
+}
+
 // A decoder stage without the head kernel advances the device-side position itself.
 __global__ void dec_advance_kernel(int32_t* pos_dev) { *pos_dev += 1; }
 
@@ -1083,6 +1213,10 @@ struct DecLayer {
     bool set;
     // act-order: 16-bit gather maps (and their inverses) of the seven matrices, in the decoder's own memory; NULL = no act-order
     const uint16_t *map_q, *map_k, *map_v, *map_o, *map_gate, *map_up, *map_down, *inv_o, *inv_down;
+    // LoRA operands of the seven projections (exl_decoder_set_lora; order q, k, v, o, gate, up, down): A [in, r], B [r, out] fp16, rank 0 = none
+    const f16 *lora_a[7], *lora_b[7];
+    int lora_r[7];
+    bool lora_any(int lo, int hi) const { for (int i = lo; i <= hi; ++i) if (lora_r[i] > 0) return true; return false; }
 };
 
 struct Decoder {
@@ -1101,6 +1235,9 @@ struct Decoder {
     void* block;                  // one hipMalloc
     uint16_t* maps;               // act-order maps of all layers: per layer 2 x (6 hidden + inter) entries
     f16* zero_res;                // [h] zeros: the residual a tensor-parallel rank that does not own it adds (exl_decoder_set_tp)
+    f16 *gbuf, *ubuf;             // [inter] each: gate / up products of a layer with LoRA operands, before the adapter and SiLU * mul
+    float* lora_part;             // [3][DEC_LORA_PARTS][DEC_LORA_MAXR] fp32: partial x @ A sums of the launch in flight
+    bool lora_o;                  // some layer has an o_proj adapter: the attention output is materialised (no merge fold)
     int ring, ring_fence, ring_depth, ring_wide;   // exl_decoder_set_option: rolling-ring weight stream (decode_ring.hip) / its start-up barrier
     bool residual_owner;          // tensor parallel: only one rank adds the residual stream to its partial o_proj / down_proj sums
     int qd() const { return heads * hd; }     // width of q / attention output: = h, or this rank's heads of a tensor-parallel shard
@@ -1134,7 +1271,7 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     d->embed = (const f16*) embed; d->final_norm = (const f16*) final_norm; d->lm_head = (const f16*) lm_head;
     d->sin = (const f16*) sin; d->cos = (const f16*) cos;
     d->layers.resize(n_layers);
-    for (auto& l : d->layers) l.set = false;
+    for (auto& l : d->layers) { l.set = false; for (int i = 0; i < 7; ++i) { l.lora_a[i] = l.lora_b[i] = nullptr; l.lora_r[i] = 0; } }
     // KV splits of the deepest bucket: one 8-wave block per CU and head-split with up to 320 keys per pass (long contexts), or
     // one 4-wave block per CU with up to 160.  (Round 2 ran 512 four-wave blocks of <= 160 keys: the o_proj kernel that merges the
     // splits reads every partial in every block, and halving their number paid more than the attention kernel lost.)
@@ -1160,6 +1297,8 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     const size_t maps_per_layer = 2 * ((size_t) 6 * hidden + inter);                 // map + inverse of q, k, v, o, gate, up (K = hidden) and down (K = inter)
     const size_t o_maps = carve(maps_per_layer * n_layers * sizeof(uint16_t));
     const size_t o_zero = carve((size_t) hidden * 2);
+    const size_t o_gb = carve((size_t) inter * 2), o_ub = carve((size_t) inter * 2);
+    const size_t o_lp = carve((size_t) 3 * DEC_LORA_PARTS * DEC_LORA_MAXR * sizeof(float));
     int prev = 0;
     hipError_t e = hipGetDevice(&prev);
     if (e == hipSuccess) e = hipSetDevice(device);
@@ -1182,6 +1321,9 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     d->probs = (float*) (b + o_pr);
     d->maps = (uint16_t*) (b + o_maps);
     d->zero_res = (f16*) (b + o_zero);
+    d->gbuf = (f16*) (b + o_gb); d->ubuf = (f16*) (b + o_ub);
+    d->lora_part = (float*) (b + o_lp);
+    d->lora_o = false;
     d->residual_owner = true;
     d->ring = getenv("EXL_DEC_RING") ? atoi(getenv("EXL_DEC_RING")) : 15;
     d->ring_fence = getenv("EXL_DEC_RING_FENCE") ? atoi(getenv("EXL_DEC_RING_FENCE")) : 1;
@@ -1261,6 +1403,39 @@ extern "C" int exl_decoder_set_layer(void* dec, int index, void* q, void* k, voi
         l.inv_o = inv[3]; l.inv_down = inv[6];
     }
     l.set = true;
+    return 0;
+}
+
+// LoRA operands of one layer (order q, k, v, o, gate, up, down; a7[i] == NULL or rank7[i] == 0: no adapter on that projection; all
+// NULL clears the layer).  A [in_features, r], B [r, out_features] fp16 in device memory that outlives the decoder's graphs, alpha / r
+// folded into B (what exllama_amd.lora / the reference's lora.py hold).  The adapter products then ride inside the token step
+// (two small launches behind the GEMV launch of each class that has adapters) instead of forcing the step onto the op-by-op path.
+// Not for layers whose o_proj or down_proj gathers through an act-order map (their inputs are stored permuted): EXL_E_UNSUPPORTED,
+// the caller keeps the op path.  Set before the step is captured; changing adapters means capturing again.
+extern "C" int exl_decoder_set_lora(void* dec, int index, const void* const* a7, const void* const* b7, const int* rank7)
+{
+    Decoder* d = dec_from(dec);
+    EXL_REQUIRE(d && index >= 0 && index < d->L && d->layers[index].set, EXL_E_INVALID, "decoder_set_lora: invalid decoder / layer");
+    DecLayer& l = d->layers[index];
+    bool any = false;
+    for (int i = 0; i < 7; ++i) {
+        const int r = (a7 && b7 && rank7 && a7[i] && b7[i]) ? rank7[i] : 0;
+        EXL_REQUIRE(r >= 0 && r <= DEC_LORA_MAXR, EXL_E_UNSUPPORTED, "decoder_set_lora: rank %d beyond %d", r, DEC_LORA_MAXR);
+        any = any || r > 0;
+    }
+    if (any) {
+        EXL_REQUIRE(!l.o->x_map && !l.down->x_map, EXL_E_UNSUPPORTED,
+                    "decoder_set_lora: o_proj / down_proj of layer %d gather through an act-order map (fold down_proj at load; o_proj adapters stay on the op path)", index);
+        EXL_REQUIRE(d->residual_owner && d->qd() == d->h, EXL_E_UNSUPPORTED, "decoder_set_lora: not on a tensor-parallel shard");
+    }
+    for (int i = 0; i < 7; ++i) {
+        const int r = (a7 && b7 && rank7 && a7[i] && b7[i]) ? rank7[i] : 0;
+        l.lora_a[i] = r ? (const f16*) a7[i] : nullptr;
+        l.lora_b[i] = r ? (const f16*) b7[i] : nullptr;
+        l.lora_r[i] = r;
+    }
+    d->lora_o = false;
+    for (const DecLayer& x : d->layers) d->lora_o = d->lora_o || x.lora_r[3] > 0;
     return 0;
 }
 
@@ -1497,7 +1672,33 @@ int dec_op_gemv(int device, int cls, int pnorm, int emode, const f16* vec, const
 // trips of 16 x 16 bytes per thread); the switch that kept the wide fold reachable is gone.)
 static bool dec_folds_merge(const Decoder* d)
 {
-    return d->qd() <= DEC_THREADS * 8;
+    return d->qd() <= DEC_THREADS * 8 && !d->lora_o;                  // (an o_proj adapter reads the merged attention output: it must exist)
+}
+
+// The adapter launches behind one GEMV launch (dec_lora_down_kernel / dec_lora_up_kernel).  idx: the launch's matrices in the
+// order of DecLayer::lora_* (q k v = 0 1 2, o = 3, gate up = 4 5, down = 6).
+static int dec_lora(Decoder* d, const DecLayer& l, int first, int nmat, const f16* x, const f16* norm_w, int K, f16* const* outs, const int* widths,
+                    int silu, hipStream_t s)
+{
+    DecLoraArgs a = {};
+    a.x = x; a.norm_w = norm_w; a.eps = d->eps; a.K = K; a.nmat = nmat;
+    int nparts = (K + 255) / 256;
+    if (nparts > DEC_LORA_PARTS) nparts = DEC_LORA_PARTS;
+    a.kslice = ((K + nparts - 1) / nparts + 7) & ~7;
+    nparts = (K + a.kslice - 1) / a.kslice;
+    int total = 0;
+    for (int i = 0; i < nmat; ++i) {
+        a.a[i] = l.lora_a[first + i]; a.b[i] = l.lora_b[first + i]; a.r[i] = l.lora_r[first + i];
+        a.out[i] = outs[i]; a.n[i] = widths[i];
+        total += widths[i];
+    }
+    a.part = d->lora_part; a.silu = silu; a.act = d->act;
+    hipLaunchKernelGGL(dec_lora_down_kernel, dim3(nparts, nmat), dim3(256), 0, s, a);
+    EXL_LAUNCH_CHECK();
+    const int cols = silu ? widths[0] : total;
+    hipLaunchKernelGGL(dec_lora_up_kernel, dim3((cols / 8 + 255) / 256), dim3(256), 0, s, a, nparts);
+    EXL_LAUNCH_CHECK();
+    return 0;
 }
 
 // One kernel class of one layer (EXL_DEC_* in include/exl_amd.h); EXL_DEC_HEAD ignores `i`.
@@ -1514,7 +1715,10 @@ static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int3
         const int64_t* tk = emb ? token_dev : nullptr;
         f16* hc = emb ? d->hid : nullptr;
         const uint16_t* maps[3] = {l.map_q, l.map_k, l.map_v};
-        return launch_dec_gemv(d, 0, 1, 0, xin, tk, l.in_norm, d->eps, hc, 3, qkv, qkv_out, nullptr, s, nullptr, 0, maps);
+        const int rc = launch_dec_gemv(d, 0, 1, 0, xin, tk, l.in_norm, d->eps, hc, 3, qkv, qkv_out, nullptr, s, nullptr, 0, maps);
+        if (rc || g_plan || !l.lora_any(0, 2)) return rc;
+        const int widths[3] = {l.q->width, l.k->width, l.v->width};   // (d->hid holds the layer's input by now, also behind the embedding lookup)
+        return dec_lora(d, l, 0, 3, d->hid, l.in_norm, d->h, qkv_out, widths, 0, s);
     }
     case EXL_DEC_ATTN: {
         const float scale = 1.0f / sqrtf((float) d->hd);
@@ -1557,20 +1761,36 @@ static int dec_launch(Decoder* d, int cls, int i, const int64_t* token_dev, int3
                                    d->partial + (size_t) d->heads * d->nsplit * 64, d->nsplit, maps, nullptr, res);
         }
         // the attention (one split) / merge kernel stored its output through inv_o: already in o_proj's row order, nothing to gather
-        return launch_dec_gemv(d, 1, 0, 1, d->attn_out, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s, nullptr, 0, nullptr,
-                               nullptr, res);
+        const int rc = launch_dec_gemv(d, 1, 0, 1, d->attn_out, nullptr, nullptr, 0.f, nullptr, 1, om, nullptr, d->hid, s, nullptr, 0, nullptr,
+                                       nullptr, res);
+        if (rc || g_plan || l.lora_r[3] <= 0) return rc;
+        f16* outs[1] = {d->hid};
+        const int widths[1] = {l.o->width};
+        return dec_lora(d, l, 3, 1, d->attn_out, nullptr, l.o->height, outs, widths, 0, s);
     }
     case EXL_DEC_GATE_UP: {
         Q4Matrix* gu[2] = {l.gate, l.up};
         f16* gu_out[2] = {d->act, nullptr};
         const uint16_t* maps[2] = {l.map_gate, l.map_up};
+        if (l.lora_any(4, 5) && !g_plan) {
+            // adapters on gate / up act BEFORE SiLU * mul: the two products go out un-fused (the q / k / v form of the launch), the
+            // adapter kernels add theirs and apply the activation
+            f16* raw[2] = {d->gbuf, d->ubuf};
+            EXL_TRY(launch_dec_gemv(d, 2, 1, 0, d->hid, nullptr, l.post_norm, d->eps, nullptr, 2, gu, raw, nullptr, s, nullptr, 0, maps));
+            const int widths[2] = {l.gate->width, l.up->width};
+            return dec_lora(d, l, 4, 2, d->hid, l.post_norm, d->h, raw, widths, 1, s);
+        }
         return launch_dec_gemv(d, 2, 1, 2, d->hid, nullptr, l.post_norm, d->eps, nullptr, 2, gu, gu_out, nullptr, s, nullptr, 0, maps,
                                l.inv_down);                          // the activation is stored in down_proj's row order
     }
     case EXL_DEC_DOWN: {
         Q4Matrix* dm[1] = {l.down};
-        return launch_dec_gemv(d, 3, 0, 1, d->act, nullptr, nullptr, 0.f, nullptr, 1, dm, nullptr, d->hid, s, nullptr, 0, nullptr, nullptr,
-                               d->residual_owner ? d->hid : d->zero_res);
+        const int rc = launch_dec_gemv(d, 3, 0, 1, d->act, nullptr, nullptr, 0.f, nullptr, 1, dm, nullptr, d->hid, s, nullptr, 0, nullptr, nullptr,
+                                       d->residual_owner ? d->hid : d->zero_res);
+        if (rc || g_plan || l.lora_r[6] <= 0) return rc;
+        f16* outs[1] = {d->hid};
+        const int widths[1] = {l.down->width};
+        return dec_lora(d, l, 6, 1, d->act, nullptr, l.down->height, outs, widths, 0, s);
     }
     case EXL_DEC_HEAD: {
         if (!d->has_head()) return 0;

@@ -696,7 +696,7 @@ class ExLlama:
         if output_device is None:
             output_device = input_ids.device
         st = self._decoder
-        if (st is not None and cache is st["cache"] and bsz == 1 and seq_len == 1 and lora is None
+        if (st is not None and cache is st["cache"] and bsz == 1 and seq_len == 1 and lora is st.get("lora")
                 and input_mask is None and not preprocess_only and st["has_embed"] and st["has_head"]):
             return self._decode_step(input_ids, cache, str(output_device))
         devs = cfg.device_map.get_layers_devs()
@@ -797,7 +797,7 @@ class ExLlama:
                 stages.append({"dev": dev, "layers": [i]})
         return stages
 
-    def enable_decode_graph(self, cache, use_graph=True, first_stage=True, last_stage=True, hop=None, hop_capture=True):
+    def enable_decode_graph(self, cache, use_graph=True, first_stage=True, last_stage=True, hop=None, hop_capture=True, lora=None):
         """Route bsz = 1, q_len = 1 forwards on `cache` through the native decode executor (5 kernels per layer,
         exllama_amd/csrc/decode_fused.hip) and, with use_graph, replay them as ONE captured hipGraph per token and device.
         The position lives in device memory, so the same graph serves every context length.
@@ -811,7 +811,12 @@ class ExLlama:
         incoming hidden state (or token) ahead of the first stage's kernels, the outgoing one behind the last stage's; they are
         CAPTURED into the first / last stage's graph when the backend allows it (RCCL point-to-point is capturable), so that a
         replay is receive -> kernels -> send with no host work per token; otherwise (hop_capture False, or a failed capture) they run
-        eagerly around the replays.  hop.bind(self) is called once the executor's buffers exist."""
+        eagerly around the replays.  hop.bind(self) is called once the executor's buffers exist.
+        `lora` (an ExLlamaLora): its adapters ride INSIDE the token step (exl_decoder_set_lora: two small launches behind each GEMV
+        launch with adapters), so forward(..., lora=lora), generate_greedy and generate_sample keep the graph path with that
+        adapter -- the reference's q4_attn / q4_mlp LoRA operands (model.py:254-289).  Raises RuntimeError for what the executor does
+        not take (an act-order o_proj / an unfolded act-order down_proj, tensor-parallel shards): forward(lora=...) without
+        enable_decode_graph(lora=...) stays on the op-by-op path as before."""
         import ctypes as C
         cfg = self.config
         if cache.batch_size != 1:
@@ -854,6 +859,16 @@ class ExLlama:
                                                              layer.post_attention_layernorm.weight.data_ptr(),
                                                              cache.key_states[i].data_ptr(), cache.value_states[i].data_ptr()),
                                    "decoder_set_layer")
+                    if lora is not None:
+                        projs = (a.q_proj, a.k_proj, a.v_proj, a.o_proj, m.gate_proj, m.up_proj, m.down_proj)
+                        pa, pb, pr = (C.c_void_p * 7)(), (C.c_void_p * 7)(), (C.c_int * 7)()
+                        for n, pj in enumerate(projs):
+                            if pj.lora_applies(lora):
+                                ta, tb = pj.get_lora_tensors_or_meta(lora)
+                                if ta.device != dev or tb.device != dev or not (ta.is_contiguous() and tb.is_contiguous()):
+                                    raise RuntimeError(f"{pj.key}: LoRA tensors must be contiguous on {dev}")
+                                pa[n], pb[n], pr[n] = ta.data_ptr(), tb.data_ptr(), ta.shape[1]
+                        cuda_ext.check(lib.exl_decoder_set_lora(handle, j, pa, pb, pr), "decoder_set_lora")
             sg["handle"], sg["tdev"], sg["graphs"] = handle, dev, []
         d0, dl = stages[0]["tdev"], stages[-1]["tdev"]
         st = {
@@ -866,7 +881,7 @@ class ExLlama:
                              if self.lm_head_weight.shape[0] != cfg.vocab_size else None),
             "pos": stages[0]["pos"], "dev_pos": -1,
             "kv_ptrs": [(k.data_ptr(), v.data_ptr()) for k, v in zip(cache.key_states, cache.value_states)],
-            "hop": hop, "hop_captured": False,
+            "hop": hop, "hop_captured": False, "lora": lora,
         }
         self._decoder = st
         if hop is not None:

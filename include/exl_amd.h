@@ -301,6 +301,13 @@ int exl_decoder_set_option(void* decoder, int option, int value);
 int exl_decoder_step_part(void* decoder, int layer, int part, const int64_t* token_dev, int32_t* pos_dev, float* logits_out,
                           int advance, void* stream);
 int exl_decoder_set_tp(void* decoder, int residual_owner);
+/* LoRA operands of one layer of the executor (reference: the lora_A / lora_B arguments of q4_attn / q4_attn_2 / q4_mlp,
+ * exllama_ext.cpp:424-602, and q4_matmul_lora, :245-324): a7 / b7 / rank7 in the order q, k, v, o, gate, up, down (NULL / 0 = no
+ * adapter on that projection; all NULL clears the layer).  A [in_features, r], B [r, out_features] fp16, alpha / r folded into B,
+ * r <= 64.  out = W x + (x A) B then runs INSIDE the token step (two small launches behind each GEMV launch with adapters), so a
+ * model with an adapter keeps the hipGraph path.  EXL_E_UNSUPPORTED for layers whose o_proj / down_proj gather through an act-order
+ * map and on tensor-parallel shards: the caller keeps the op-by-op path.  Set before capturing; new adapters = capture again. */
+int exl_decoder_set_lora(void* decoder, int layer, const void* const* a7, const void* const* b7, const int* rank7);
 int exl_decoder_free(void* decoder);
 
 /* ---- embedding lookup and the prompt pass' lm_head (reference: torch ops inside model.py, not exllama_ext functions:

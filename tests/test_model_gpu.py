@@ -740,3 +740,118 @@ def test_act_order_down_proj_folded_at_load_changes_no_bit(name, gs):
     for k, v in runs[True].items():
         assert torch.isfinite(v.float()).all(), k
         assert torch.equal(v, runs[False][k]), k
+
+
+def _unfolded_adapter(model, lora):
+    """lora.tensors as the oracle wants them: the halves exllama_amd.lora put into the order of a folded act-order down_proj, back in
+    the checkpoint's order."""
+    plain = {k: v.cpu() for k, v in lora.tensors.items()}
+    for i, layer in enumerate(model.layers):
+        fold = layer.mlp.fold_map
+        if fold is None:
+            continue
+        inv = torch.empty_like(fold)
+        inv[fold] = torch.arange(fold.numel())
+        for proj in ("gate_proj", "up_proj"):
+            k = f"model.layers.{i}.mlp.{proj}.lora_B.weight"
+            if k in plain:
+                plain[k] = plain[k][:, inv].contiguous()
+        k = f"model.layers.{i}.mlp.down_proj.lora_A.weight"
+        if k in plain:
+            plain[k] = plain[k][inv, :].contiguous()
+    return plain
+
+
+@pytest.mark.parametrize("act,r", [(False, 16), ("gptq", 12), (False, 64)])
+def test_lora_adapter_inside_the_decode_executor(act, r):
+    """exl_decoder_set_lora: the adapter products out = W x + (x A) B ride INSIDE the token step (dec_lora_down_kernel / dec_lora_up_kernel
+    behind the GEMV launches; gate / up go out un-fused, the adapter kernel applies SiLU * mul), so a model with an adapter keeps the
+    graph path -- the reference passes the same operands to q4_attn / q4_attn_2 / q4_mlp per token (model.py:254-289).  Against the op
+    path with the same adapter (two HIP paths) and the oracle model with it; greedy generation in the graph equals the host loop;
+    one projection without an adapter, a rank that is no multiple of 8, rank 64, a folded act-order down_proj (its adapter halves
+    follow the fold); an act-order o_proj is refused (the op path stays)."""
+    from exllama_amd.lora import ExLlamaLora
+    from exllama_amd.model import ExLlamaCache
+    name = "tiny_hd128"
+    dims = synth.PRESETS[name]
+    tensors = synth.make_checkpoint(dims, groupsize=128, act_order=act, seed=51, device="cpu", zeros="rand")
+    if act:                                                          # an act-order o_proj is what the executor does NOT take with an adapter:
+        for i in range(dims.num_hidden_layers):                      # this model's o_proj carries no map (q / k / v / gate / up / down do)
+            del tensors[f"model.layers.{i}.self_attn.o_proj.g_idx"]
+    from exllama_amd.model import ExLlama, ExLlamaConfig
+    cfg = ExLlamaConfig(synth.config_dict(dims))
+    cfg.max_seq_len = 256
+    model = ExLlama(cfg, tensors={k: v.clone() for k, v in tensors.items()})
+    g = torch.Generator().manual_seed(r)
+    kvd = dims.num_key_value_heads * dims.head_dim
+    shapes = {"self_attn.q_proj": (dims.hidden_size, dims.hidden_size), "self_attn.k_proj": (dims.hidden_size, kvd),
+              "self_attn.v_proj": (dims.hidden_size, kvd), "self_attn.o_proj": (dims.hidden_size, dims.hidden_size),
+              "mlp.gate_proj": (dims.hidden_size, dims.intermediate_size), "mlp.up_proj": (dims.hidden_size, dims.intermediate_size),
+              "mlp.down_proj": (dims.intermediate_size, dims.hidden_size)}
+    sd = {}
+    for i in range(dims.num_hidden_layers):
+        for key, (fin, fout) in shapes.items():
+            if i == 1 and key in ("mlp.up_proj", "self_attn.k_proj"):
+                continue                                             # projections without an adapter inside launches that have some
+            sd[f"base_model.model.model.layers.{i}.{key}.lora_A.weight"] = torch.randn(r, fin, generator=g) * 0.05
+            sd[f"base_model.model.model.layers.{i}.{key}.lora_B.weight"] = torch.randn(fout, r, generator=g) * 0.05
+    lora = ExLlamaLora(model, {"r": r, "lora_alpha": 16}, "synthetic.bin", tensors=sd)
+    ids = torch.randint(1, dims.vocab_size, (1, 150), generator=torch.Generator().manual_seed(3)).to("cuda:0")   # decode crosses the 160-key bucket
+    n = 14
+    cache = ExLlamaCache(model)
+    lg = model.forward(ids, cache, lora=lora)
+    toks = [int(lg[0, -1].argmax())]
+    ops = []
+    for i in range(n):                                               # op path with the adapter: the token history of every other run
+        lg = model.forward(torch.tensor([[toks[-1]]], device="cuda:0"), cache, lora=lora)
+        ops.append(lg[0, 0].float().cpu())
+        toks.append(int(lg[0, 0].argmax()))
+    base = model.forward(torch.tensor([[toks[0]]], device="cuda:0"), ExLlamaCache(model, copy_from=cache))   # (any state: only "differs" is asserted)
+    outs = {}
+    for mode in ("eager", "graph"):
+        c = ExLlamaCache(model)
+        model.forward(ids, c, lora=lora)
+        model.enable_decode_graph(c, use_graph=(mode == "graph"), lora=lora)
+        outs[mode] = [model.forward(torch.tensor([[toks[i]]], device="cuda:0"), c, lora=lora)[0, 0].float().cpu() for i in range(n)]
+        assert c.current_seq_len == 150 + n
+        if mode == "graph":
+            c.current_seq_len = 150
+            got = model.generate_greedy(torch.tensor([[toks[0]]], device="cuda:0"), c, n).tolist()
+            scale = float(torch.stack(ops).abs().max())
+            margins = [float(o.topk(2).values[0] - o.topk(2).values[1]) for o in ops]
+            for i in range(n):                                       # same greedy choice wherever the op path's top-2 margin is clear
+                if margins[i] > 4e-2 * scale:
+                    assert got[i] == toks[i + 1], (i, got, toks)
+                else:
+                    break
+    scale = float(torch.stack(ops).abs().max())
+    for i in range(n):
+        assert torch.isfinite(outs["eager"][i]).all()
+        _model_close(outs["eager"][i], ops[i], PATHS_TOL, f"executor with adapter vs op path, step {i}")
+        assert float((outs["graph"][i] - outs["eager"][i]).abs().max()) <= 2e-3 * scale
+    # the oracle with the same adapter, teacher-forced on the same tokens
+    orc = OracleLlama(synth.config_dict(dims), tensors, max_seq_len=256)
+    orc.set_lora(_unfolded_adapter(model, lora))
+    orc.forward(ids.cpu().numpy())
+    for i in range(4):
+        ref = orc.forward(np.array([[toks[i]]]))[0, 0]
+        _model_close(outs["graph"][i], ref, LORA_TOL, f"executor with adapter vs oracle, step {i}")
+    # without the adapter the logits differ; forward(lora=None) on this executor leaves the graph path (the executor is bound to the adapter)
+    model.disable_decode_graph()
+    model.free_unmanaged()
+
+
+def test_executor_refuses_an_adapter_on_an_act_order_o_proj():
+    from exllama_amd.lora import ExLlamaLora
+    model, cache, tensors, dims = _build("tiny_hd128", 128, True, seed=52, max_seq_len=128)
+    sd = {}
+    for i in range(dims.num_hidden_layers):
+        sd[f"base_model.model.model.layers.{i}.self_attn.o_proj.lora_A.weight"] = torch.randn(8, dims.hidden_size) * 0.05
+        sd[f"base_model.model.model.layers.{i}.self_attn.o_proj.lora_B.weight"] = torch.randn(dims.hidden_size, 8) * 0.05
+    lora = ExLlamaLora(model, {"r": 8, "lora_alpha": 16}, "synthetic.bin", tensors=sd)
+    with pytest.raises(RuntimeError, match="act-order"):
+        model.enable_decode_graph(cache, lora=lora)
+    ids = torch.randint(1, dims.vocab_size, (1, 9)).to("cuda:0")
+    model.disable_decode_graph()
+    assert torch.isfinite(model.forward(ids, cache, lora=lora)).all()       # the op path takes it
+    model.free_unmanaged()
