@@ -1145,11 +1145,13 @@ __global__ __launch_bounds__(256) void dec_lora_down_kernel(const DecLoraArgs a)
     }
 }
 
-__global__ __launch_bounds__(256) void dec_lora_up_kernel(const DecLoraArgs a, int nparts)
+__global__ __launch_bounds__(128) void dec_lora_up_kernel(const DecLoraArgs a, int nparts)
 {
+    // one thread = 2 consecutive columns (the rows of B are read 256 bytes per wave and rank), 256 columns per block: a launch is
+    // 16 .. 48 blocks -- with 8 columns per thread and 256 threads it was 6 blocks on 6 CUs, 11 us per launch
     __shared__ float t[3][DEC_LORA_MAXR];
     const int tid = threadIdx.x;
-    for (int i = tid; i < a.nmat * DEC_LORA_MAXR; i += 256) {          // t_i[j] = h(sum over the K parts), fixed order
+    for (int i = tid; i < a.nmat * DEC_LORA_MAXR; i += 128) {          // t_i[j] = h(sum over the K parts), fixed order
         const int mi = i / DEC_LORA_MAXR, j = i % DEC_LORA_MAXR;
         float v = 0.f;
         if (j < a.r[mi])
@@ -1157,47 +1159,38 @@ __global__ __launch_bounds__(256) void dec_lora_up_kernel(const DecLoraArgs a, i
         t[mi][j] = (float) (f16) v;
     }
     __syncthreads();
-    const int n8 = (blockIdx.x * 256 + tid) * 8;                       // 8 consecutive columns
+    const int n2 = (blockIdx.x * 128 + tid) * 2;
     if (a.silu) {
-        if (n8 >= a.n[0]) return;
-        float g[8], u[8];
-        const f16x8 gv = *(const f16x8*) (a.out[0] + n8), uv = *(const f16x8*) (a.out[1] + n8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { g[e] = 0.f; u[e] = 0.f; }
+        if (n2 >= a.n[0]) return;
+        float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
         for (int j = 0; j < a.r[0]; ++j) {
-            const f16x8 bv = *(const f16x8*) (a.b[0] + (size_t) j * a.n[0] + n8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) g[e] = fmaf(t[0][j], (float) bv[e], g[e]);
+            const f16x2 bv = *(const f16x2*) (a.b[0] + (size_t) j * a.n[0] + n2);
+            g0 = fmaf(t[0][j], (float) bv[0], g0); g1 = fmaf(t[0][j], (float) bv[1], g1);
         }
         for (int j = 0; j < a.r[1]; ++j) {
-            const f16x8 bv = *(const f16x8*) (a.b[1] + (size_t) j * a.n[1] + n8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) u[e] = fmaf(t[1][j], (float) bv[e], u[e]);
+            const f16x2 bv = *(const f16x2*) (a.b[1] + (size_t) j * a.n[1] + n2);
+            u0 = fmaf(t[1][j], (float) bv[0], u0); u1 = fmaf(t[1][j], (float) bv[1], u1);
         }
-        f16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const f16 gh = a.r[0] > 0 ? (f16) ((float) gv[e] + (float) (f16) g[e]) : gv[e];     // h(product + h(adapter)): the adapter's own fp16 result, then one add
-            const f16 uh = a.r[1] > 0 ? (f16) ((float) uv[e] + (float) (f16) u[e]) : uv[e];
-            o[e] = silu_mul_f16(gh, uh);
-        }
-        *(f16x8*) (a.act + n8) = o;
+        const f16x2 gv = *(const f16x2*) (a.out[0] + n2), uv = *(const f16x2*) (a.out[1] + n2);
+        // h(product + h(adapter)): the adapter's own fp16 result, then one add
+        const f16 gh0 = a.r[0] > 0 ? (f16) ((float) gv[0] + (float) (f16) g0) : gv[0], gh1 = a.r[0] > 0 ? (f16) ((float) gv[1] + (float) (f16) g1) : gv[1];
+        const f16 uh0 = a.r[1] > 0 ? (f16) ((float) uv[0] + (float) (f16) u0) : uv[0], uh1 = a.r[1] > 0 ? (f16) ((float) uv[1] + (float) (f16) u1) : uv[1];
+        *(f16x2*) (a.act + n2) = (f16x2){silu_mul_f16(gh0, uh0), silu_mul_f16(gh1, uh1)};
         return;
     }
     // plain: the matrices of the launch side by side in the column index
-    int mi = 0, n0 = n8;
+    int mi = 0, n0 = n2;
     while (mi < a.nmat && n0 >= a.n[mi]) { n0 -= a.n[mi]; ++mi; }
     if (mi >= a.nmat || a.r[mi] <= 0) return;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float c0 = 0.f, c1 = 0.f;
     for (int j = 0; j < a.r[mi]; ++j) {
-        const f16x8 bv = *(const f16x8*) (a.b[mi] + (size_t) j * a.n[mi] + n0);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = fmaf(t[mi][j], (float) bv[e], acc[e]);
+        const f16x2 bv = *(const f16x2*) (a.b[mi] + (size_t) j * a.n[mi] + n0);
+        c0 = fmaf(t[mi][j], (float) bv[0], c0); c1 = fmaf(t[mi][j], (float) bv[1], c1);
     }
-    f16x8 ov = *(const f16x8*) (a.out[mi] + n0);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ov[e] = (f16) ((float) ov[e] + (float) (f16) acc[e]);
-    *(f16x8*) (a.out[mi] + n0) = ov;
+    f16x2 ov = *(const f16x2*) (a.out[mi] + n0);
+    ov[0] = (f16) ((float) ov[0] + (float) (f16) c0);
+    ov[1] = (f16) ((float) ov[1] + (float) (f16) c1);
+    *(f16x2*) (a.out[mi] + n0) = ov;
 }
 
 // A decoder stage without the head kernel advances the device-side position itself.
@@ -1696,7 +1689,7 @@ static int dec_lora(Decoder* d, const DecLayer& l, int first, int nmat, const f1
     hipLaunchKernelGGL(dec_lora_down_kernel, dim3(nparts, nmat), dim3(256), 0, s, a);
     EXL_LAUNCH_CHECK();
     const int cols = silu ? widths[0] : total;
-    hipLaunchKernelGGL(dec_lora_up_kernel, dim3((cols / 8 + 255) / 256), dim3(256), 0, s, a, nparts);
+    hipLaunchKernelGGL(dec_lora_up_kernel, dim3((cols / 2 + 127) / 128), dim3(128), 0, s, a, nparts);
     EXL_LAUNCH_CHECK();
     return 0;
 }

@@ -205,7 +205,7 @@ class TruthLlama(OracleLlama):
     dequantised weights h(h(q - z) * s) of q4_matrix.cu:170-210 -- all of them exact in float64).  It states what the fp16 pipeline
     approximates, so a test can require  |HIP - truth| <= c * |fp16 oracle - truth|  instead of widening a bound where the fp16
     oracle itself is ill-conditioned (tests/test_model_gpu.py: _truth_close).  K / V rows are cached unrounded (float64 cache);
-    rows copied in from an fp16 cache are taken as given.  LoRA operands are not supported here."""
+    rows copied in from an fp16 cache are taken as given.  LoRA operands (set_lora): out = x W + (x A) B, all in float64."""
 
     @classmethod
     def from_oracle(cls, ref, past=None):
@@ -242,7 +242,17 @@ class TruthLlama(OracleLlama):
         out = np.concatenate([l * c[:, :, :hd2] - r * s[:, :, :hd2], r * c[:, :, hd2:] + l * s[:, :, hd2:]], axis=-1)
         return out.reshape(x.shape)
 
+    _KEYS = {"q": "self_attn.q_proj", "k": "self_attn.k_proj", "v": "self_attn.v_proj", "o": "self_attn.o_proj",
+             "gate": "mlp.gate_proj", "up": "mlp.up_proj", "down": "mlp.down_proj"}
+
     def _mm(self, i, which, x):
+        ab = self.lora.get(f"model.layers.{i}.{self._KEYS[which]}")
+        base = self._mm_base(i, which, x)
+        if ab is None:
+            return base
+        return base + (x @ np.asarray(ab[0]).astype(np.float64)) @ np.asarray(ab[1]).astype(np.float64)
+
+    def _mm_base(self, i, which, x):
         lin = self.layers[i][which]
         if lin.w32 is None:
             lin.prepare()
@@ -253,7 +263,6 @@ class TruthLlama(OracleLlama):
         return acc
 
     def layer_forward(self, i, hidden):
-        assert not self.lora, "TruthLlama: no LoRA operands"
         l = self.layers[i]
         bsz, q_len, h = hidden.shape
         x2 = hidden.reshape(-1, h)

@@ -806,7 +806,9 @@ def test_lora_adapter_inside_the_decode_executor(act, r):
         lg = model.forward(torch.tensor([[toks[-1]]], device="cuda:0"), cache, lora=lora)
         ops.append(lg[0, 0].float().cpu())
         toks.append(int(lg[0, 0].argmax()))
-    base = model.forward(torch.tensor([[toks[0]]], device="cuda:0"), ExLlamaCache(model, copy_from=cache))   # (any state: only "differs" is asserted)
+    c0 = ExLlamaCache(model)
+    model.forward(ids, c0, lora=lora)
+    base = model.forward(torch.tensor([[toks[0]]], device="cuda:0"), c0)                # the same step WITHOUT the adapter
     outs = {}
     for mode in ("eager", "graph"):
         c = ExLlamaCache(model)
@@ -827,15 +829,21 @@ def test_lora_adapter_inside_the_decode_executor(act, r):
     scale = float(torch.stack(ops).abs().max())
     for i in range(n):
         assert torch.isfinite(outs["eager"][i]).all()
-        _model_close(outs["eager"][i], ops[i], PATHS_TOL, f"executor with adapter vs op path, step {i}")
         assert float((outs["graph"][i] - outs["eager"][i]).abs().max()) <= 2e-3 * scale
-    # the oracle with the same adapter, teacher-forced on the same tokens
+    # every step of the three paths against the float64 truth WITH the adapter (TruthLlama adds (x A) B in float64), the fp16 oracle
+    # with the same adapter as the yardstick: the decode steps of a random model with a strong adapter are often ill-conditioned
+    # (round 4, first attempt: executor vs op path 6.7e-3 RMS at one step, both inside the oracle's own spread)
     orc = OracleLlama(synth.config_dict(dims), tensors, max_seq_len=256)
     orc.set_lora(_unfolded_adapter(model, lora))
-    orc.forward(ids.cpu().numpy())
-    for i in range(4):
-        ref = orc.forward(np.array([[toks[i]]]))[0, 0]
-        _model_close(outs["graph"][i], ref, LORA_TOL, f"executor with adapter vs oracle, step {i}")
+    for l in range(dims.num_hidden_layers):                           # the steps are compared in isolation: same cached rows as the GPU
+        orc.kc[l][0, :, :150] = cache.key_states[l][0, :, :150].cpu().numpy()
+        orc.vc[l][0, :, :150] = cache.value_states[l][0, :, :150].cpu().numpy()
+    _, runs, truth = _oracle_steps(orc, toks[:n], 150)
+    for i in range(n):
+        _truth_close(ops[i], runs, truth, i, f"op path with adapter, step {i}")
+        _truth_close(outs["eager"][i], runs, truth, i, f"executor (eager) with adapter, step {i}")
+        _truth_close(outs["graph"][i], runs, truth, i, f"executor (graph) with adapter, step {i}")
+    assert float((ops[0] - base[0, 0].float().cpu()).abs().max()) > 2e-2 * scale       # the adapter is not a no-op
     # without the adapter the logits differ; forward(lora=None) on this executor leaves the graph path (the executor is bound to the adapter)
     model.disable_decode_graph()
     model.free_unmanaged()
