@@ -1119,16 +1119,27 @@ __global__ __launch_bounds__(256) void dec_lora_down_kernel(const DecLoraArgs a)
     const int k0 = p * a.kslice, k1 = min(a.K, k0 + a.kslice);
     const f16* A = a.a[mi];
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int k = k0 + wave * rpw + kl; k < k1; k += 4 * rpw) {
-        f16 xv = a.x[k];
-        if (a.norm_w) { const f16 m = xv * rmh; xv = m * a.norm_w[k]; }
-        const float xf = (float) xv;
-        if (c * 8 + 8 <= r && (r & 7) == 0) {
-            const f16x8 wv = *(const f16x8*) (A + (size_t) k * r + c * 8);
+    const bool vec = (r & 7) == 0;                                      // 16-byte rows of A (else element by element)
+    for (int kb = k0 + wave * rpw + kl; kb < k1; kb += 16 * rpw) {     // 4 rows per lane requested together: a load per iteration would
+        f16 xv[4], nw[4];                                                // serialise the L2 latency (round 4, first version: 11 us per launch)
+        f16x8 wv[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf(xf, (float) wv[j], acc[j]);
-        } else {
-            for (int j = 0; j < 8 && c * 8 + j < r; ++j) acc[j] = fmaf(xf, (float) A[(size_t) k * r + c * 8 + j], acc[j]);
+        for (int u = 0; u < 4; ++u) {
+            const int k = kb + u * 4 * rpw;
+            const bool ok = k < k1;
+            xv[u] = ok ? a.x[k] : (f16) 0.f;
+            nw[u] = (ok && a.norm_w) ? a.norm_w[k] : (f16) 1.f;
+            wv[u] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok && vec && c * 8 < r) wv[u] = *(const f16x8*) (A + (size_t) k * r + c * 8);
+            else if (ok && !vec) for (int j = 0; j < 8 && c * 8 + j < r; ++j) wv[u][j] = A[(size_t) k * r + c * 8 + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f16 x1 = xv[u];
+            if (a.norm_w) { const f16 m = x1 * rmh; x1 = m * nw[u]; }
+            const float xf = (float) x1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(xf, (float) wv[u][j], acc[j]);
         }
     }
 #pragma unroll
@@ -1142,6 +1153,21 @@ __global__ __launch_bounds__(256) void dec_lora_down_kernel(const DecLoraArgs a)
         const int cc = tid >> 3, j = tid & 7;
         if (cc * 8 + j < r)
             a.part[((size_t) mi * DEC_LORA_PARTS + p) * DEC_LORA_MAXR + cc * 8 + j] = red[0][cc][j] + red[1][cc][j] + red[2][cc][j] + red[3][cc][j];
+    }
+}
+
+// (c0, c1) += sum_j t[j] * B[j][n .. n + 1]: the rows of B requested 8 at a time (a load per iteration serialises the L2 latency)
+__device__ __forceinline__ void lora_dot2(const f16* __restrict__ B, int N, int n, int r, const float* t, float& c0, float& c1)
+{
+    for (int j0 = 0; j0 < r; j0 += 8) {
+        f16x2 bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bv[u] = j0 + u < r ? *(const f16x2*) (B + (size_t) (j0 + u) * N + n) : (f16x2){(f16) 0.f, (f16) 0.f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float tj = j0 + u < r ? t[j0 + u] : 0.f;
+            c0 = fmaf(tj, (float) bv[u][0], c0); c1 = fmaf(tj, (float) bv[u][1], c1);
+        }
     }
 }
 
@@ -1163,14 +1189,8 @@ __global__ __launch_bounds__(128) void dec_lora_up_kernel(const DecLoraArgs a, i
     if (a.silu) {
         if (n2 >= a.n[0]) return;
         float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
-        for (int j = 0; j < a.r[0]; ++j) {
-            const f16x2 bv = *(const f16x2*) (a.b[0] + (size_t) j * a.n[0] + n2);
-            g0 = fmaf(t[0][j], (float) bv[0], g0); g1 = fmaf(t[0][j], (float) bv[1], g1);
-        }
-        for (int j = 0; j < a.r[1]; ++j) {
-            const f16x2 bv = *(const f16x2*) (a.b[1] + (size_t) j * a.n[1] + n2);
-            u0 = fmaf(t[1][j], (float) bv[0], u0); u1 = fmaf(t[1][j], (float) bv[1], u1);
-        }
+        lora_dot2(a.b[0], a.n[0], n2, a.r[0], t[0], g0, g1);
+        lora_dot2(a.b[1], a.n[1], n2, a.r[1], t[1], u0, u1);
         const f16x2 gv = *(const f16x2*) (a.out[0] + n2), uv = *(const f16x2*) (a.out[1] + n2);
         // h(product + h(adapter)): the adapter's own fp16 result, then one add
         const f16 gh0 = a.r[0] > 0 ? (f16) ((float) gv[0] + (float) (f16) g0) : gv[0], gh1 = a.r[0] > 0 ? (f16) ((float) gv[1] + (float) (f16) g1) : gv[1];
@@ -1183,10 +1203,7 @@ __global__ __launch_bounds__(128) void dec_lora_up_kernel(const DecLoraArgs a, i
     while (mi < a.nmat && n0 >= a.n[mi]) { n0 -= a.n[mi]; ++mi; }
     if (mi >= a.nmat || a.r[mi] <= 0) return;
     float c0 = 0.f, c1 = 0.f;
-    for (int j = 0; j < a.r[mi]; ++j) {
-        const f16x2 bv = *(const f16x2*) (a.b[mi] + (size_t) j * a.n[mi] + n0);
-        c0 = fmaf(t[mi][j], (float) bv[0], c0); c1 = fmaf(t[mi][j], (float) bv[1], c1);
-    }
+    lora_dot2(a.b[mi], a.n[mi], n0, a.r[mi], t[mi], c0, c1);
     f16x2 ov = *(const f16x2*) (a.out[mi] + n0);
     ov[0] = (f16) ((float) ov[0] + (float) (f16) c0);
     ov[1] = (f16) ((float) ov[1] + (float) (f16) c1);

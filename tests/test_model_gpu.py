@@ -793,8 +793,8 @@ def test_lora_adapter_inside_the_decode_executor(act, r):
         for key, (fin, fout) in shapes.items():
             if i == 1 and key in ("mlp.up_proj", "self_attn.k_proj"):
                 continue                                             # projections without an adapter inside launches that have some
-            sd[f"base_model.model.model.layers.{i}.{key}.lora_A.weight"] = torch.randn(r, fin, generator=g) * 0.05
-            sd[f"base_model.model.model.layers.{i}.{key}.lora_B.weight"] = torch.randn(fout, r, generator=g) * 0.05
+            sd[f"base_model.model.model.layers.{i}.{key}.lora_A.weight"] = torch.randn(r, fin, generator=g) * 0.05 * (16.0 / r) ** 0.5
+            sd[f"base_model.model.model.layers.{i}.{key}.lora_B.weight"] = torch.randn(fout, r, generator=g) * 0.05     # (same strength at every rank)
     lora = ExLlamaLora(model, {"r": r, "lora_alpha": 16}, "synthetic.bin", tensors=sd)
     ids = torch.randint(1, dims.vocab_size, (1, 150), generator=torch.Generator().manual_seed(3)).to("cuda:0")   # decode crosses the 160-key bucket
     n = 14
