@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(256) void dec_lora_down_kernel(const DecLoraArgs a)
     __shared__ float red[4][8][8];
     __shared__ float ssq[4];
     const int mi = blockIdx.y, p = blockIdx.x;
-    const int r = a.r[mi];
+    const int r = mi == 0 ? a.r[0] : mi == 1 ? a.r[1] : a.r[2];      // (static selects: no run-time index into the argument struct)
     if (r <= 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float rm = 1.f;
@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(256) void dec_lora_down_kernel(const DecLoraArgs a)
     nc = nc <= 1 ? 1 : nc <= 2 ? 2 : nc <= 4 ? 4 : 8;
     const int c = lane % nc, kl = lane / nc, rpw = 64 / nc;
     const int k0 = p * a.kslice, k1 = min(a.K, k0 + a.kslice);
-    const f16* A = a.a[mi];
+    const f16* A = mi == 0 ? a.a[0] : mi == 1 ? a.a[1] : a.a[2];
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bool vec = (r & 7) == 0;                                      // 16-byte rows of A (else element by element)
     for (int kb = k0 + wave * rpw + kl; kb < k1; kb += 16 * rpw) {     // 4 rows per lane requested together: a load per iteration would
@@ -1177,11 +1177,19 @@ __global__ __launch_bounds__(128) void dec_lora_up_kernel(const DecLoraArgs a, i
     // 16 .. 48 blocks -- with 8 columns per thread and 256 threads it was 6 blocks on 6 CUs, 11 us per launch
     __shared__ float t[3][DEC_LORA_MAXR];
     const int tid = threadIdx.x;
-    for (int i = tid; i < a.nmat * DEC_LORA_MAXR; i += 128) {          // t_i[j] = h(sum over the K parts), fixed order
+    // t_i[j] = h(sum over the K parts), fixed order.  All <= 32 partial sums of an element are requested TOGETHER: a loop that adds
+    // one load per iteration waits out the L2 latency 16-32 times in a row (rocprofv3, first version: 12 us minimum, 27 us average
+    // per launch of this kernel)
+    for (int i = tid; i < a.nmat * DEC_LORA_MAXR; i += 128) {
         const int mi = i / DEC_LORA_MAXR, j = i % DEC_LORA_MAXR;
+        const int r_mi = mi == 0 ? a.r[0] : mi == 1 ? a.r[1] : a.r[2];
+        float pv[DEC_LORA_PARTS];
+#pragma unroll
+        for (int p = 0; p < DEC_LORA_PARTS; ++p)
+            pv[p] = (j < r_mi && p < nparts) ? a.part[((size_t) mi * DEC_LORA_PARTS + p) * DEC_LORA_MAXR + j] : 0.f;
         float v = 0.f;
-        if (j < a.r[mi])
-            for (int p = 0; p < nparts; ++p) v += a.part[((size_t) mi * DEC_LORA_PARTS + p) * DEC_LORA_MAXR + j];
+#pragma unroll
+        for (int p = 0; p < DEC_LORA_PARTS; ++p) v += pv[p];
         t[mi][j] = (float) (f16) v;
     }
     __syncthreads();
@@ -1199,15 +1207,21 @@ __global__ __launch_bounds__(128) void dec_lora_up_kernel(const DecLoraArgs a, i
         return;
     }
     // plain: the matrices of the launch side by side in the column index
+    // (static selects instead of a[mi]: indexing the by-value argument struct with a run-time index would put it into scratch)
     int mi = 0, n0 = n2;
-    while (mi < a.nmat && n0 >= a.n[mi]) { n0 -= a.n[mi]; ++mi; }
-    if (mi >= a.nmat || a.r[mi] <= 0) return;
+    if (n0 >= a.n[0]) { n0 -= a.n[0]; mi = 1; if (a.nmat > 1 && n0 >= a.n[1]) { n0 -= a.n[1]; mi = 2; } }
+    if (mi >= a.nmat) return;
+    const int N = mi == 0 ? a.n[0] : mi == 1 ? a.n[1] : a.n[2];
+    const int r = mi == 0 ? a.r[0] : mi == 1 ? a.r[1] : a.r[2];
+    const f16* B = mi == 0 ? a.b[0] : mi == 1 ? a.b[1] : a.b[2];
+    f16* out = mi == 0 ? a.out[0] : mi == 1 ? a.out[1] : a.out[2];
+    if (n0 >= N || r <= 0) return;
     float c0 = 0.f, c1 = 0.f;
-    lora_dot2(a.b[mi], a.n[mi], n0, a.r[mi], t[mi], c0, c1);
-    f16x2 ov = *(const f16x2*) (a.out[mi] + n0);
+    lora_dot2(B, N, n0, r, mi == 0 ? t[0] : mi == 1 ? t[1] : t[2], c0, c1);
+    f16x2 ov = *(const f16x2*) (out + n0);
     ov[0] = (f16) ((float) ov[0] + (float) (f16) c0);
     ov[1] = (f16) ((float) ov[1] + (float) (f16) c1);
-    *(f16x2*) (a.out[mi] + n0) = ov;
+    *(f16x2*) (out + n0) = ov;
 }
 
 // A decoder stage without the head kernel advances the device-side position itself.
