@@ -1098,6 +1098,30 @@ __global__ __launch_bounds__(256) void dec_lora_down_kernel(const DecLoraArgs a)
     const int r = mi == 0 ? a.r[0] : mi == 1 ? a.r[1] : a.r[2];      // (static selects: no run-time index into the argument struct)
     if (r <= 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int nc = (r + 7) >> 3;                                             // column chunks of 8, padded to a power of two <= 8
+    nc = nc <= 1 ? 1 : nc <= 2 ? 2 : nc <= 4 ? 4 : 8;
+    const int c = lane % nc, kl = lane / nc, rpw = 64 / nc;
+    const int k0 = p * a.kslice, k1 = min(a.K, k0 + a.kslice);
+    const f16* A = mi == 0 ? a.a[0] : mi == 1 ? a.a[1] : a.a[2];
+    const bool vec = (r & 7) == 0;                                      // 16-byte rows of A (else element by element)
+    // 4 rows per lane and batch, requested together -- and the FIRST batch before the RMSNorm reduction below (its loads do not
+    // depend on it): a load per iteration would serialise the L2 / HBM latency
+    f16 xv[4], nw[4];
+    f16x8 wv[4];
+    auto request = [&](int kb) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = kb + u * 4 * rpw;
+            const bool ok = k < k1;
+            xv[u] = ok ? a.x[k] : (f16) 0.f;
+            nw[u] = (ok && a.norm_w) ? a.norm_w[k] : (f16) 1.f;
+            wv[u] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok && vec && c * 8 < r) wv[u] = *(const f16x8*) (A + (size_t) k * r + c * 8);
+            else if (ok && !vec) for (int j = 0; j < 8 && c * 8 + j < r; ++j) wv[u][j] = A[(size_t) k * r + c * 8 + j];
+        }
+    };
+    const int kfirst = k0 + wave * rpw + kl;
+    request(kfirst);
     float rm = 1.f;
     if (a.norm_w) {                                                   // rms_norm.cu: fp32 sum of squares, r rounded to fp16, two fp16 multiplies
         float sq = 0.f;
@@ -1113,26 +1137,9 @@ __global__ __launch_bounds__(256) void dec_lora_down_kernel(const DecLoraArgs a)
         rm = 1.0f / sqrtf((ssq[0] + ssq[1] + ssq[2] + ssq[3]) * (1.0f / (float) a.K) + a.eps);
     }
     const f16 rmh = (f16) rm;
-    int nc = (r + 7) >> 3;                                             // column chunks of 8, padded to a power of two <= 8
-    nc = nc <= 1 ? 1 : nc <= 2 ? 2 : nc <= 4 ? 4 : 8;
-    const int c = lane % nc, kl = lane / nc, rpw = 64 / nc;
-    const int k0 = p * a.kslice, k1 = min(a.K, k0 + a.kslice);
-    const f16* A = mi == 0 ? a.a[0] : mi == 1 ? a.a[1] : a.a[2];
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const bool vec = (r & 7) == 0;                                      // 16-byte rows of A (else element by element)
-    for (int kb = k0 + wave * rpw + kl; kb < k1; kb += 16 * rpw) {     // 4 rows per lane requested together: a load per iteration would
-        f16 xv[4], nw[4];                                                // serialise the L2 latency (round 4, first version: 11 us per launch)
-        f16x8 wv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = kb + u * 4 * rpw;
-            const bool ok = k < k1;
-            xv[u] = ok ? a.x[k] : (f16) 0.f;
-            nw[u] = (ok && a.norm_w) ? a.norm_w[k] : (f16) 1.f;
-            wv[u] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok && vec && c * 8 < r) wv[u] = *(const f16x8*) (A + (size_t) k * r + c * 8);
-            else if (ok && !vec) for (int j = 0; j < 8 && c * 8 + j < r; ++j) wv[u][j] = A[(size_t) k * r + c * 8 + j];
-        }
+    for (int kb = kfirst; kb < k1; kb += 16 * rpw) {
+        if (kb != kfirst) request(kb);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             f16 x1 = xv[u];
@@ -1156,72 +1163,81 @@ __global__ __launch_bounds__(256) void dec_lora_down_kernel(const DecLoraArgs a)
     }
 }
 
-// (c0, c1) += sum_j t[j] * B[j][n .. n + 1]: the rows of B requested 8 at a time (a load per iteration serialises the L2 latency)
-__device__ __forceinline__ void lora_dot2(const f16* __restrict__ B, int N, int n, int r, const float* t, float& c0, float& c1)
+// The rows j0 .. j0 + 31 of B at columns n, n + 1 (requested together: one L2 / HBM latency for the lot)
+struct LoraRows { f16x2 v[32]; };
+__device__ __forceinline__ void lora_rows_load(LoraRows& R, const f16* __restrict__ B, int N, int n, int r, int j0)
 {
-    for (int j0 = 0; j0 < r; j0 += 8) {
-        f16x2 bv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) bv[u] = j0 + u < r ? *(const f16x2*) (B + (size_t) (j0 + u) * N + n) : (f16x2){(f16) 0.f, (f16) 0.f};
+    for (int u = 0; u < 32; ++u) R.v[u] = j0 + u < r ? *(const f16x2*) (B + (size_t) (j0 + u) * N + n) : (f16x2){(f16) 0.f, (f16) 0.f};
+}
+__device__ __forceinline__ void lora_rows_fma(const LoraRows& R, const float* t, int r, int j0, float& c0, float& c1)
+{
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float tj = j0 + u < r ? t[j0 + u] : 0.f;
-            c0 = fmaf(tj, (float) bv[u][0], c0); c1 = fmaf(tj, (float) bv[u][1], c1);
-        }
+    for (int u = 0; u < 32; ++u) {
+        const float tj = j0 + u < r ? t[j0 + u] : 0.f;
+        c0 = fmaf(tj, (float) R.v[u][0], c0); c1 = fmaf(tj, (float) R.v[u][1], c1);
     }
 }
 
 __global__ __launch_bounds__(128) void dec_lora_up_kernel(const DecLoraArgs a, int nparts)
 {
     // one thread = 2 consecutive columns (the rows of B are read 256 bytes per wave and rank), 256 columns per block: a launch is
-    // 16 .. 48 blocks -- with 8 columns per thread and 256 threads it was 6 blocks on 6 CUs, 11 us per launch
+    // 16 .. 48 blocks.  Everything a thread reads -- its first 32 rows of B, the product(s) it adds to, the partial sums of t -- is
+    // requested BEFORE anything is waited for: the launch is a latency chain (rocprofv3, earlier versions: 27 us with one load per
+    // loop iteration, 22 us with batches of 8 behind the t reduction), not a stream.
     __shared__ float t[3][DEC_LORA_MAXR];
     const int tid = threadIdx.x;
-    // t_i[j] = h(sum over the K parts), fixed order.  All <= 32 partial sums of an element are requested TOGETHER: a loop that adds
-    // one load per iteration waits out the L2 latency 16-32 times in a row (rocprofv3, first version: 12 us minimum, 27 us average
-    // per launch of this kernel)
-    for (int i = tid; i < a.nmat * DEC_LORA_MAXR; i += 128) {
-        const int mi = i / DEC_LORA_MAXR, j = i % DEC_LORA_MAXR;
-        const int r_mi = mi == 0 ? a.r[0] : mi == 1 ? a.r[1] : a.r[2];
-        float pv[DEC_LORA_PARTS];
-#pragma unroll
-        for (int p = 0; p < DEC_LORA_PARTS; ++p)
-            pv[p] = (j < r_mi && p < nparts) ? a.part[((size_t) mi * DEC_LORA_PARTS + p) * DEC_LORA_MAXR + j] : 0.f;
-        float v = 0.f;
-#pragma unroll
-        for (int p = 0; p < DEC_LORA_PARTS; ++p) v += pv[p];
-        t[mi][j] = (float) (f16) v;
-    }
-    __syncthreads();
     const int n2 = (blockIdx.x * 128 + tid) * 2;
-    if (a.silu) {
-        if (n2 >= a.n[0]) return;
-        float g0 = 0.f, g1 = 0.f, u0 = 0.f, u1 = 0.f;
-        lora_dot2(a.b[0], a.n[0], n2, a.r[0], t[0], g0, g1);
-        lora_dot2(a.b[1], a.n[1], n2, a.r[1], t[1], u0, u1);
-        const f16x2 gv = *(const f16x2*) (a.out[0] + n2), uv = *(const f16x2*) (a.out[1] + n2);
-        // h(product + h(adapter)): the adapter's own fp16 result, then one add
-        const f16 gh0 = a.r[0] > 0 ? (f16) ((float) gv[0] + (float) (f16) g0) : gv[0], gh1 = a.r[0] > 0 ? (f16) ((float) gv[1] + (float) (f16) g1) : gv[1];
-        const f16 uh0 = a.r[1] > 0 ? (f16) ((float) uv[0] + (float) (f16) u0) : uv[0], uh1 = a.r[1] > 0 ? (f16) ((float) uv[1] + (float) (f16) u1) : uv[1];
-        *(f16x2*) (a.act + n2) = (f16x2){silu_mul_f16(gh0, uh0), silu_mul_f16(gh1, uh1)};
-        return;
-    }
-    // plain: the matrices of the launch side by side in the column index
-    // (static selects instead of a[mi]: indexing the by-value argument struct with a run-time index would put it into scratch)
+    // which matrix / column this thread works on (static selects: no run-time index into the by-value argument struct)
     int mi = 0, n0 = n2;
-    if (n0 >= a.n[0]) { n0 -= a.n[0]; mi = 1; if (a.nmat > 1 && n0 >= a.n[1]) { n0 -= a.n[1]; mi = 2; } }
-    if (mi >= a.nmat) return;
+    if (!a.silu) {
+        if (n0 >= a.n[0]) { n0 -= a.n[0]; mi = 1; if (a.nmat > 1 && n0 >= a.n[1]) { n0 -= a.n[1]; mi = 2; } }
+    }
     const int N = mi == 0 ? a.n[0] : mi == 1 ? a.n[1] : a.n[2];
     const int r = mi == 0 ? a.r[0] : mi == 1 ? a.r[1] : a.r[2];
     const f16* B = mi == 0 ? a.b[0] : mi == 1 ? a.b[1] : a.b[2];
     f16* out = mi == 0 ? a.out[0] : mi == 1 ? a.out[1] : a.out[2];
-    if (n0 >= N || r <= 0) return;
-    float c0 = 0.f, c1 = 0.f;
-    lora_dot2(B, N, n0, r, mi == 0 ? t[0] : mi == 1 ? t[1] : t[2], c0, c1);
-    f16x2 ov = *(const f16x2*) (out + n0);
-    ov[0] = (f16) ((float) ov[0] + (float) (f16) c0);
-    ov[1] = (f16) ((float) ov[1] + (float) (f16) c1);
-    *(f16x2*) (out + n0) = ov;
+    const bool live = mi < a.nmat && n0 < N;
+    LoraRows R0, R1;                                                     // silu: gate rows / up rows; plain: rows of the one matrix
+    f16x2 prev0 = {(f16) 0.f, (f16) 0.f}, prev1 = prev0;
+    const int r1 = a.silu ? a.r[1] : 0;
+    if (live) {
+        lora_rows_load(R0, B, N, n0, r, 0);
+        prev0 = *(const f16x2*) (out + n0);
+        if (a.silu) { lora_rows_load(R1, a.b[1], a.n[1], n0, r1, 0); prev1 = *(const f16x2*) (a.out[1] + n0); }
+    }
+    // t_i[j] = h(sum over the K parts), fixed order; all <= 32 partial sums of an element requested together
+    for (int i = tid; i < a.nmat * DEC_LORA_MAXR; i += 128) {
+        const int ti = i / DEC_LORA_MAXR, j = i % DEC_LORA_MAXR;
+        const int r_ti = ti == 0 ? a.r[0] : ti == 1 ? a.r[1] : a.r[2];
+        float pv[DEC_LORA_PARTS];
+#pragma unroll
+        for (int p = 0; p < DEC_LORA_PARTS; ++p)
+            pv[p] = (j < r_ti && p < nparts) ? a.part[((size_t) ti * DEC_LORA_PARTS + p) * DEC_LORA_MAXR + j] : 0.f;
+        float v = 0.f;
+#pragma unroll
+        for (int p = 0; p < DEC_LORA_PARTS; ++p) v += pv[p];
+        t[ti][j] = (float) (f16) v;
+    }
+    __syncthreads();
+    if (!live) return;
+    const float* tm = mi == 0 ? t[0] : mi == 1 ? t[1] : t[2];
+    float c0 = 0.f, c1 = 0.f, d0 = 0.f, d1 = 0.f;
+    lora_rows_fma(R0, tm, r, 0, c0, c1);
+    if (r > 32) { lora_rows_load(R0, B, N, n0, r, 32); lora_rows_fma(R0, tm, r, 32, c0, c1); }
+    if (a.silu) {
+        lora_rows_fma(R1, t[1], r1, 0, d0, d1);
+        if (r1 > 32) { lora_rows_load(R1, a.b[1], a.n[1], n0, r1, 32); lora_rows_fma(R1, t[1], r1, 32, d0, d1); }
+        // h(product + h(adapter)): the adapter's own fp16 result, then one add; then silu(gate) * up as the fused launch does
+        const f16 gh0 = r > 0 ? (f16) ((float) prev0[0] + (float) (f16) c0) : prev0[0], gh1 = r > 0 ? (f16) ((float) prev0[1] + (float) (f16) c1) : prev0[1];
+        const f16 uh0 = r1 > 0 ? (f16) ((float) prev1[0] + (float) (f16) d0) : prev1[0], uh1 = r1 > 0 ? (f16) ((float) prev1[1] + (float) (f16) d1) : prev1[1];
+        *(f16x2*) (a.act + n0) = (f16x2){silu_mul_f16(gh0, uh0), silu_mul_f16(gh1, uh1)};
+        return;
+    }
+    if (r <= 0) return;
+    prev0[0] = (f16) ((float) prev0[0] + (float) (f16) c0);
+    prev0[1] = (f16) ((float) prev0[1] + (float) (f16) c1);
+    *(f16x2*) (out + n0) = prev0;
 }
 
 // A decoder stage without the head kernel advances the device-side position itself.
