@@ -1695,9 +1695,81 @@ __global__ __launch_bounds__(256) void half_skinny_finish_kernel(const float* __
     out[i] = (f16) v;
 }
 
+// LoRA down-projection of a PROMPT: out[M, N <= 64] (+)= x[M, K] @ w[K, N] -- many rows, a long K, a handful of columns.  The 64 x 64
+// tile kernels give that shape M / 64 blocks (32 for a 2048-token prompt on 256 CUs) each walking the whole K: 70 us per call, seven
+// calls per layer -- the prompt pass with an adapter ran at half the rate without (profiles/r04_lora.json).  Here a block is ONE
+// wave owning 16 rows and 1 / KS of K (grid M / 16 x KS: >= 1024 waves): per 32-k step the x fragment is a 16-byte load per lane
+// (the MFMA's B operand: lane = (row, k-group)), the [32][N] slab of w -- contiguous in memory -- goes through LDS and comes back
+// as the A operand (lane = (column, k-group): 8 strided 2-byte reads), one v_mfma_f32_16x16x32_f16 per 16 columns; the next step's
+// loads are requested before the current step's MFMAs.  fp32 partial tiles per K part, summed by half_skinny_finish_kernel.
+template <int NT>
+__global__ __launch_bounds__(64) void half_tall_partial_kernel(const f16* __restrict__ x, const f16* __restrict__ w, float* __restrict__ part,
+                                                               int M, int K, int N, int kslice)
+{
+    __shared__ __attribute__((aligned(16))) f16 slab[32 * NT * 16];
+    const int lane = threadIdx.x;
+    const int m0 = blockIdx.x * 16, ks = blockIdx.y;
+    const int k0 = ks * kslice, k1 = min(K, k0 + kslice);               // kslice % 32 == 0, K % 32 == 0
+    const int fr = lane & 15, kg = lane >> 4;
+    const f16* xp = x + (size_t) min(m0 + fr, M - 1) * K + kg * 8;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int SLAB16 = 32 * NT * 16 / 8;                             // 16-byte pieces of a slab (64 NT)
+    f16x8 xf = *(const f16x8*) (xp + k0);
+    uint4 sl[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) sl[i] = *(const uint4*) (w + (size_t) k0 * N + (size_t) (i * 64 + lane) * 8);
+    for (int k = k0; k < k1; k += 32) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) *(uint4*) (slab + (size_t) (i * 64 + lane) * 8) = sl[i];
+        const f16x8 xc = xf;
+        if (k + 32 < k1) {                                               // next step in flight during this step's LDS reads and MFMAs
+            xf = *(const f16x8*) (xp + k + 32);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) sl[i] = *(const uint4*) (w + (size_t) (k + 32) * N + (size_t) (i * 64 + lane) * 8);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // this wave's slab is in LDS (one wave per block: no barrier)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f16x8 wf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wf[j] = slab[(kg * 8 + j) * (NT * 16) + nt * 16 + fr];
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xc, acc[nt], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the reads are done before the next step overwrites the slab
+    }
+    if (m0 + fr < M) {
+        float* pp = part + ((size_t) ks * M + m0 + fr) * N;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) *(f32x4*) (pp + nt * 16 + kg * 4) = acc[nt];       // lane: row fr, columns nt * 16 + 4 kg .. + 3
+    }
+}
+
 int launch_half_gemm(const f16* x, const f16* w, f16* out, int M, int K, int N, int no_zero, hipStream_t s)
 {
     if (M <= 0 || N <= 0) return 0;
+    if (M > 64 && N <= 64 && N % 16 == 0 && K % 32 == 0 && K >= 1024 && (((uintptr_t) w | (uintptr_t) x) & 15) == 0 && (uint64_t) M * K < (1ull << 31)) {
+        int dev = 0;
+        EXL_HIP(hipGetDevice(&dev));
+        int ks = 8;
+        while (ks > 1 && (K / ks) % 32 != 0) ks >>= 1;
+        const int kslice = K / ks;
+        float* ws = nullptr;
+        if (kslice % 32 == 0 && exl_gemm_workspace(dev, (size_t) ks * M * N, &ws) == 0) {
+            const dim3 grid((M + 15) / 16, ks);
+            switch (N / 16) {
+            case 1: hipLaunchKernelGGL(half_tall_partial_kernel<1>, grid, dim3(64), 0, s, x, w, ws, M, K, N, kslice); break;
+            case 2: hipLaunchKernelGGL(half_tall_partial_kernel<2>, grid, dim3(64), 0, s, x, w, ws, M, K, N, kslice); break;
+            case 3: hipLaunchKernelGGL(half_tall_partial_kernel<3>, grid, dim3(64), 0, s, x, w, ws, M, K, N, kslice); break;
+            default: hipLaunchKernelGGL(half_tall_partial_kernel<4>, grid, dim3(64), 0, s, x, w, ws, M, K, N, kslice); break;
+            }
+            EXL_LAUNCH_CHECK();
+            hipLaunchKernelGGL(half_skinny_finish_kernel, dim3((M * N + 255) / 256), dim3(256), 0, s, ws, out, M * N, ks, no_zero);
+            EXL_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (M <= HS_MAXM && N <= 64 && K >= 1024 && N % 8 == 0 && (((uintptr_t) w) & 15) == 0) {
         int nc = N / 8;
         if (nc == 3) nc = 4; else if (nc > 4) nc = 8;                 // a power of two chunks per k row (the lanes of a wave split evenly)

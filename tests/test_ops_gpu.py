@@ -517,7 +517,12 @@ def test_q4_matmul_lora(ce):
 
 
 @pytest.mark.parametrize("M,K,N", [(1, 512, 16), (3, 64, 200), (70, 130 // 2 * 2, 96), (130, 256, 64),
-                                   (1, 4096, 16), (600, 4096, 64), (600, 64, 4096), (77, 200, 72), (5, 136, 8)])    # LoRA down / up shapes, ragged K
+                                   (1, 4096, 16), (600, 4096, 64), (600, 64, 4096), (77, 200, 72), (5, 136, 8),     # LoRA down / up shapes, ragged K
+                                   # few rows x long K (half_skinny_partial_kernel: K cut over up to 64 blocks): ranks 8 / 16 / 32 / 64, 7 rows, K = 11008
+                                   (1, 11008, 64), (7, 4096, 32), (8, 5120, 8), (2, 1024, 16),
+                                   # many rows x long K x <= 64 columns (half_tall_partial_kernel: one wave per 16 rows and K part, MFMA): ragged
+                                   # last row tile, 48 columns, the down_proj K
+                                   (2048, 4096, 16), (777, 11008, 32), (70, 1024, 48), (2048, 5120, 64)])
 def test_half_matmul(ce, M, K, N):
     gen = torch.Generator().manual_seed(M * K + N)
     x = torch.randn(M, K, generator=gen).half()
