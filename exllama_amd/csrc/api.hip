@@ -620,13 +620,22 @@ extern "C" int exl_q4_attn(int device, const void* x, const void* rms_norm_weigh
     f16* remap_tmp = bufs->temp_state + (size_t) rows * dim;     // act-order gather scratch for the GEMM path
     const size_t remap_numel = bufs->temp_state_numel - (size_t) rows * dim;
     bool fused = false;
-    if (rows == 1 && !(q_a && q_rank > 0) && !(k_a && k_rank > 0) && !(v_a && v_rank > 0)) {
-        // one token, no adapter: RMSNorm + q / k / v as ONE launch of the decode executor's kernel (decode_fused.hip: dec_op_gemv)
+    const int ranks[3] = {(q_a && q_b) ? q_rank : 0, (k_a && k_b) ? k_rank : 0, (v_a && v_b) ? v_rank : 0};
+    const bool any_lora = ranks[0] > 0 || ranks[1] > 0 || ranks[2] > 0;
+    if (rows == 1 && ranks[0] <= 64 && ranks[1] <= 64 && ranks[2] <= 64) {
+        // one token: RMSNorm + q / k / v as ONE launch of the decode executor's kernel (decode_fused.hip: dec_op_gemv); adapters: the
+        // executor's two adapter launches behind it (x A for the three matrices, then += (x A) B), 3 launches instead of 13
         Q4Matrix* mats[3] = {qm, km, vm};
         f16* outs[3] = {(f16*) query_states, (f16*) key_states, (f16*) value_states};
         const int r = dec_op_gemv(device, 0, 1, 0, (const f16*) x, (const f16*) rms_norm_weight, epsilon, 3, mats, outs, nullptr, s);
         if (r > 1) return r;
         fused = r == 0;
+        if (fused && any_lora) {
+            const f16* la[3] = {(const f16*) q_a, (const f16*) k_a, (const f16*) v_a};
+            const f16* lb[3] = {(const f16*) q_b, (const f16*) k_b, (const f16*) v_b};
+            const int widths[3] = {qm->width, km->width, vm->width};
+            EXL_TRY(dec_op_lora(device, 3, (const f16*) x, (const f16*) rms_norm_weight, epsilon, dim, la, lb, ranks, outs, widths, 0, nullptr, s));
+        }
     }
     if (!fused) EXL_TRY(launch_rms_norm((const f16*) x, (const f16*) rms_norm_weight, temp_x, epsilon, rows, dim, s));
 
@@ -660,15 +669,24 @@ extern "C" int exl_q4_attn_2(void* x, const void* attn_output, void* o_proj, int
     DeviceGuard guard(om->device);
     DeviceBuffers* bufs = exl_buffers(om->device);
     hipStream_t s = (hipStream_t) stream;
-    if (o_a && o_b && o_rank > 0) {
+    const int orank = (o_a && o_b) ? o_rank : 0;
+    if (height == 1 && orank <= 64) {                            // one token: o_proj + residual through the executor's kernel, the adapter behind it
+        Q4Matrix* mats[1] = {om};
+        const int r = dec_op_gemv(om->device, 1, 0, 1, (const f16*) attn_output, nullptr, 0.f, 1, mats, nullptr, (f16*) x, s);
+        if (r > 1) return r;
+        if (r == 0) {
+            if (orank <= 0) return 0;
+            const f16* la[1] = {(const f16*) o_a};
+            const f16* lb[1] = {(const f16*) o_b};
+            f16* outs[1] = {(f16*) x};
+            const int widths[1] = {om->width};
+            return dec_op_lora(om->device, 1, (const f16*) attn_output, nullptr, 0.f, om->height, la, lb, &orank, outs, widths, 0, nullptr, s);
+        }
+    }
+    if (orank > 0) {
         EXL_REQUIRE(lora_temp, EXL_E_INVALID, "q4_attn_2: lora_temp missing");
         EXL_TRY(launch_half_gemm((const f16*) attn_output, (const f16*) o_a, (f16*) lora_temp, height, om->height, o_rank, 0, s));
         EXL_TRY(launch_half_gemm((const f16*) lora_temp, (const f16*) o_b, (f16*) x, height, o_rank, om->width, 1, s));
-    }
-    if (height == 1 && !(o_a && o_b && o_rank > 0)) {             // one token, no adapter: o_proj + residual through the executor's kernel
-        Q4Matrix* mats[1] = {om};
-        const int r = dec_op_gemv(om->device, 1, 0, 1, (const f16*) attn_output, nullptr, 0.f, 1, mats, nullptr, (f16*) x, s);
-        if (r != 1) return r;
     }
     if (height <= 8) return q4_gemv(om, attn_output, height, x, 1, s);
     return q4_gemm(om, attn_output, height, x, 1, bufs->temp_state, bufs->temp_state_numel, s);
@@ -701,17 +719,41 @@ extern "C" int exl_q4_mlp(int device, void* x, const void* rms_norm_weight, floa
     const size_t remap_numel = bufs->temp_state_numel - (size_t) height * dim;
     f16* t0 = bufs->temp_mlp;
     f16* t1 = bufs->temp_mlp + (size_t) height * inter;
-    if (height == 1 && !(gate_a && gate_rank > 0) && !(up_a && up_rank > 0) && !(down_a && down_rank > 0)) {
-        // one token, no adapter: RMSNorm + gate / up + SiLU in one launch, down_proj + residual in the next (the executor's kernels)
+    const int gr = (gate_a && gate_b) ? gate_rank : 0, ur = (up_a && up_b) ? up_rank : 0, dr = (down_a && down_b) ? down_rank : 0;
+    if (height == 1 && gr <= 64 && ur <= 64 && dr <= 64) {
+        // one token: RMSNorm + gate / up + SiLU in one launch, down_proj + residual in the next (the executor's kernels).  Adapters on
+        // gate / up: the two products go out un-fused and the executor's adapter launches add theirs and apply SiLU * mul; an adapter
+        // on down_proj: the same pair of launches behind its GEMV.  6-8 launches where the separate products took ~20
         Q4Matrix* gu[2] = {gm, um};
-        f16* outs[1] = {t0};
-        const int r = dec_op_gemv(device, 2, 1, 2, (const f16*) x, (const f16*) rms_norm_weight, epsilon, 2, gu, outs, nullptr, s);
-        if (r > 1) return r;
+        int r;
+        if (gr > 0 || ur > 0) {
+            f16* raw[2] = {t0, t1};
+            r = dec_op_gemv(device, 2, 1, 0, (const f16*) x, (const f16*) rms_norm_weight, epsilon, 2, gu, raw, nullptr, s);
+            if (r > 1) return r;
+            if (r == 0) {
+                const f16* la[2] = {(const f16*) gate_a, (const f16*) up_a};
+                const f16* lb[2] = {(const f16*) gate_b, (const f16*) up_b};
+                const int rk[2] = {gr, ur}, widths[2] = {inter, inter};
+                EXL_TRY(dec_op_lora(device, 2, (const f16*) x, (const f16*) rms_norm_weight, epsilon, dim, la, lb, rk, raw, widths, 1, t0, s));
+            }
+        } else {
+            f16* outs[1] = {t0};
+            r = dec_op_gemv(device, 2, 1, 2, (const f16*) x, (const f16*) rms_norm_weight, epsilon, 2, gu, outs, nullptr, s);
+            if (r > 1) return r;
+        }
         if (r == 0) {
             Q4Matrix* dn[1] = {dm};
             const int r2 = dec_op_gemv(device, 3, 0, 1, t0, nullptr, 0.f, 1, dn, nullptr, (f16*) x, s);
-            if (r2 != 1) return r2;
-            return q4_gemv(dm, t0, height, x, 1, s);                 // (down_proj alone not covered: its own GEMV on the fused activation)
+            if (r2 > 1) return r2;
+            if (r2 == 1) EXL_TRY(q4_gemv(dm, t0, height, x, 1, s));  // (down_proj alone not covered: its own GEMV on the fused activation)
+            if (dr > 0) {
+                const f16* la[1] = {(const f16*) down_a};
+                const f16* lb[1] = {(const f16*) down_b};
+                f16* outs[1] = {(f16*) x};
+                const int widths[1] = {dim};
+                return dec_op_lora(device, 1, t0, nullptr, 0.f, inter, la, lb, &dr, outs, widths, 0, nullptr, s);
+            }
+            return 0;
         }
     }
     EXL_TRY(launch_rms_norm((const f16*) x, (const f16*) rms_norm_weight, temp_x, epsilon, height, dim, s));

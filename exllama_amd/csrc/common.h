@@ -137,6 +137,9 @@ int launch_rms_norm_gather(const f16* x, const f16* w, f16* out, const uint32_t*
 // decode_fused.hip: one fused executor launch for the op-level entry points (0 done, 1 not covered, > 1 error)
 int dec_op_gemv(int device, int cls, int pnorm, int emode, const f16* vec, const f16* norm_w, float eps, int nmat,
                 Q4Matrix* const* mats, f16* const* outs, f16* hid_io, hipStream_t s);
+// decode_fused.hip: the executor's two adapter launches behind an op-level fused launch at one row (rank <= 64): outs[i] (+)= (x A_i) B_i
+int dec_op_lora(int device, int nmat, const f16* x, const f16* norm_w, float eps, int K, const f16* const* a3, const f16* const* b3, const int* r3,
+                f16* const* outs, const int* widths, int silu, f16* act, hipStream_t s);
 int launch_rope(f16* x, const f16* sin, const f16* cos, int bsz, int rows_per_batch, int head_dim, int num_heads,
                 int past_len, const int32_t* past_len_dev, hipStream_t s);
 int launch_silu_mul(f16* x, const f16* y, int height, int width, hipStream_t s);

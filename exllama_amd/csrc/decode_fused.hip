@@ -1702,6 +1702,38 @@ int dec_op_gemv(int device, int cls, int pnorm, int emode, const f16* vec, const
     return launch_dec_gemv(&cfg[device], cls, pnorm, emode, vec, nullptr, norm_w, eps, nullptr, nmat, mats, outs, hid_io, s);
 }
 
+// The adapter launches of the executor (dec_lora_down_kernel / dec_lora_up_kernel) behind an op-level fused launch at ONE row: what
+// exl_q4_attn / exl_q4_attn_2 / exl_q4_mlp run when the reference's model.py passes LoRA operands per token (model.py:254-289) --
+// 2 launches per class instead of 3 per projection (x A as partial + finish, then (x A) B).  outs[i] (+)= (x A_i) B_i; silu: outs[0] /
+// outs[1] hold the gate / up products and act receives silu(gate + ..) * (up + ..).  The partial sums live in the device's workspace.
+int dec_op_lora(int device, int nmat, const f16* x, const f16* norm_w, float eps, int K, const f16* const* a3, const f16* const* b3, const int* r3,
+                f16* const* outs, const int* widths, int silu, f16* act, hipStream_t s)
+{
+    DecLoraArgs a = {};
+    a.x = x; a.norm_w = norm_w; a.eps = eps; a.K = K; a.nmat = nmat;
+    int nparts = (K + 255) / 256;
+    if (nparts > DEC_LORA_PARTS) nparts = DEC_LORA_PARTS;
+    a.kslice = ((K + nparts - 1) / nparts + 7) & ~7;
+    nparts = (K + a.kslice - 1) / a.kslice;
+    int total = 0;
+    for (int i = 0; i < nmat; ++i) {
+        EXL_REQUIRE(r3[i] >= 0 && r3[i] <= DEC_LORA_MAXR, EXL_E_UNSUPPORTED, "LoRA rank %d beyond %d", r3[i], DEC_LORA_MAXR);
+        EXL_REQUIRE(widths[i] % 2 == 0, EXL_E_UNSUPPORTED, "LoRA: odd output width %d", widths[i]);
+        a.a[i] = r3[i] > 0 ? a3[i] : nullptr; a.b[i] = r3[i] > 0 ? b3[i] : nullptr; a.r[i] = r3[i];
+        a.out[i] = outs[i]; a.n[i] = widths[i];
+        total += widths[i];
+    }
+    float* ws = nullptr;
+    EXL_TRY(exl_workspace(device, (size_t) 3 * DEC_LORA_PARTS * DEC_LORA_MAXR, &ws));
+    a.part = ws; a.silu = silu; a.act = act;
+    hipLaunchKernelGGL(dec_lora_down_kernel, dim3(nparts, nmat), dim3(256), 0, s, a);
+    EXL_LAUNCH_CHECK();
+    const int cols = silu ? widths[0] : total;
+    hipLaunchKernelGGL(dec_lora_up_kernel, dim3((cols / 2 + 127) / 128), dim3(128), 0, s, a, nparts);
+    EXL_LAUNCH_CHECK();
+    return 0;
+}
+
 // The split merge rides in the o_proj prologue when a thread owns ONE 8-dim vector of the attention output (hidden <= 4096:
 // 16 split loads = 64 registers); wider models keep it as its own kernel (with 2+ vectors per thread hipcc keeps every
 // vector's loads live and o_proj, which needs two blocks per CU from hidden 5120 on, drops to one; a rolled loop under a

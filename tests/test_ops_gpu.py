@@ -775,6 +775,60 @@ def test_q4_attn_2_and_mlp_fused(ce, dim, inter, gs, act):
         _close(xm.cpu().numpy(), refm, ulps=4.0)
 
 
+@pytest.mark.parametrize("dim,heads,inter,ranks", [(4096, 32, 11008, (16, 16, 16, 16, 16, 16, 16)), (4096, 32, 11008, (16, 8, 0, 64, 12, 0, 24)),
+                                                   (5120, 40, 13824, (0, 32, 4, 0, 0, 16, 0))])
+def test_one_row_adapter_launches_equal_the_separate_products(ce, dim, heads, inter, ranks):
+    """q4_attn / q4_attn_2 / q4_mlp with LoRA operands at ONE row (the reference's per-token call, model.py:254-289) run the executor's
+    fused launches + its two adapter kernels (csrc/decode_fused.hip: dec_op_gemv, dec_op_lora); at two rows the same entry points
+    run norm, the two half GEMMs per adapter and the q4 products one after the other (the path test_q4_matmul_lora and the LoRA
+    prefill test pin against the oracle).  Same arithmetic up to the order of the fp32 sums: row 0 of the two-row call is the yardstick.
+    Ranks in the order q k v o gate up down (0 = no adapter on that projection), mixed, not multiples of 8, up to 64."""
+    hd, gs, max_seq, past = dim // heads, 128, 32, 5
+    keep = _prep_buffers(ce, 2, dim, inter)
+    gen = torch.Generator().manual_seed(dim + sum(ranks))
+    std = 0.03 * (512.0 / dim) ** 0.5
+    shapes = [(dim, dim), (dim, dim), (dim, dim), (dim, dim), (dim, inter), (dim, inter), (inter, dim)]
+    hs = [_handle(ce, _lin(K, N, gs, False, seed=300 + i, std=std if i < 6 else 0.02 * (1408.0 / inter) ** 0.5)[0]) for i, (K, N) in enumerate(shapes)]
+    nt = ce.none_tensor
+    ab = []
+    for (K, N), r in zip(shapes, ranks):
+        if r == 0:
+            ab.append((nt, nt))
+        else:
+            ab.append(((torch.randn(K, r, generator=gen) * 0.04 * (16.0 / r) ** 0.5).half().to(DEV), (torch.randn(r, N, generator=gen) * 0.04).half().to(DEV)))
+    sin, cos = (torch.from_numpy(t).to(DEV)[None, None] for t in O.rope_tables(max_seq, hd))
+    w = (1 + 0.1 * torch.randn(dim, generator=gen)).half().to(DEV)
+    x1 = torch.randn(1, 1, dim, generator=gen).half()
+    attn1 = torch.randn(1, 1, dim, generator=gen).half()
+    out = {}
+    for rows in (1, 2):
+        x = x1.repeat(rows, 1, 1).to(DEV)
+        attn = attn1.repeat(rows, 1, 1).to(DEV)
+        lt = torch.zeros((rows, 64), dtype=torch.float16, device=DEV)
+        q = torch.empty((rows, 1, dim), dtype=torch.float16, device=DEV)
+        k, v = torch.empty_like(q), torch.empty_like(q)
+        kc = torch.zeros(rows, heads, max_seq, hd, dtype=torch.float16, device=DEV)
+        vc = torch.zeros_like(kc)
+        ce.exllama_ext.q4_attn(x, w, 1e-6, q, k, v, hs[0][0], hs[1][0], hs[2][0], sin, cos, 1, past, heads, heads, hd, kc, vc, max_seq,
+                               ab[0][0], ab[0][1], ab[1][0], ab[1][1], ab[2][0], ab[2][1], lt)
+        h = x.clone()
+        ce.exllama_ext.q4_attn_2(h, attn, hs[3][0], ab[3][0], ab[3][1], lt)
+        m = x.clone().view(-1, dim)
+        ce.exllama_ext.q4_mlp(m, w, 1e-6, hs[4][0], hs[5][0], hs[6][0], ab[4][0], ab[4][1], ab[5][0], ab[5][1], ab[6][0], ab[6][1], lt)
+        out[rows] = {"q": q[0], "k": k[0], "v": v[0], "kc": kc[0, :, past], "vc": vc[0, :, past], "attn_2": h[0], "mlp": m[0]}
+    for name, ref in out[2].items():
+        _close(out[1][name].float().cpu().numpy(), ref.float().cpu().numpy(), ulps=3.0)
+    # and the adapters are not a no-op on the outputs they touch
+    base = torch.empty((1, 1, dim), dtype=torch.float16, device=DEV)
+    b2, b3 = torch.empty_like(base), torch.empty_like(base)
+    kc = torch.zeros(1, heads, max_seq, hd, dtype=torch.float16, device=DEV)
+    ce.exllama_ext.q4_attn(x1.to(DEV), w, 1e-6, base, b2, b3, hs[0][0], hs[1][0], hs[2][0], sin, cos, 1, past, heads, heads, hd, kc, torch.zeros_like(kc), max_seq,
+                           nt, nt, nt, nt, nt, nt, nt)
+    for name, plain, r in (("q", base, ranks[0]), ("k", b2, ranks[1]), ("v", b3, ranks[2])):
+        same = torch.equal(plain[0], out[1][name])
+        assert same == (r == 0), (name, r)
+
+
 def test_compiled_binding_and_ctypes_path_launch_the_same_work(ce):
     """exllama_amd/_exl_fast.so (the compiled binding of the per-token entry points, csrc/binding/exl_fast.cpp) against the ctypes
     methods it replaces (kept in the class as the A/B reference): the same C-ABI calls with the same arguments, so every output is
