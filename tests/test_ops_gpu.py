@@ -610,7 +610,10 @@ def test_update_cache_bit_exact(ce):
 # ---------------------------------------------------------------------------------------------------------
 # attention
 # ---------------------------------------------------------------------------------------------------------
-def _attn_case(ce, bsz, q_len, heads, kvh, hd, past, max_seq, seed, with_mask=False, dev_pos=False):
+def _attn_case(ce, bsz, q_len, heads, kvh, hd, past, max_seq, seed, with_mask=False, dev_pos=False, poison=False, spikes=()):
+    """poison: the cache rows behind the last visible key hold NaN (they may hold anything: a kernel must not let them in, not even under
+    a zero weight).  spikes: key positions whose K row is a large multiple of a query row -- a row maximum that grows by far more than
+    2^8 LATE in the key loop, the case the lazy reference maximum of the prompt kernels has to rescale for."""
     gen = torch.Generator().manual_seed(seed)
     kv_len = past + q_len
     q = torch.randn(bsz, q_len, heads * hd, generator=gen).half()
@@ -618,6 +621,12 @@ def _attn_case(ce, bsz, q_len, heads, kvh, hd, past, max_seq, seed, with_mask=Fa
     vc = torch.zeros_like(kc)
     kc[:, :, :kv_len] = torch.randn(bsz, kvh, kv_len, hd, generator=gen).half()
     vc[:, :, :kv_len] = torch.randn(bsz, kvh, kv_len, hd, generator=gen).half()
+    for pos_k in spikes:                                                       # scores ~ +-|q|^2 * 3 / sqrt(hd) ~ 30-40 at this key for the rows
+        qrow = min(q_len - 1, max(0, pos_k - past + 7))                        # that see it: e^35 times everything before
+        kc[:, :, pos_k] = 3.0 * q.view(bsz, q_len, heads, hd)[:, qrow, ::heads // kvh]
+    if poison:
+        kc[:, :, kv_len:] = float("nan")
+        vc[:, :, kv_len:] = float("nan")
     mask = None
     if with_mask:
         mask = torch.zeros(bsz, 1, q_len, kv_len, dtype=torch.float16)
@@ -671,6 +680,24 @@ def test_attention_decode_variants(ce):
 @pytest.mark.parametrize("q_len,past,heads,kvh", [(16, 0, 4, 4), (128, 0, 4, 4), (200, 0, 8, 2), (333, 45, 4, 4), (64, 1000, 2, 2)])
 def test_attention_prefill_flash(ce, q_len, past, heads, kvh):
     _attn_case(ce, 1, q_len, heads, kvh, 128, past, 2048, seed=q_len + past)
+
+
+@pytest.mark.parametrize("bsz,q_len,past,heads,kvh", [(1, 129, 0, 4, 4), (2, 257, 63, 4, 2), (1, 192, 0, 8, 8), (1, 320, 1, 4, 1), (1, 64, 193, 4, 4),
+                                                      (2, 128, 129, 2, 2), (1, 1000, 1047, 2, 1)])
+def test_attention_prefill_8wave_kernel_edges(ce, bsz, q_len, past, heads, kvh):
+    """flash_prefill8_kernel (everything beyond one query block of <= 256 keys): one query row in the last block, odd and even numbers of
+    key tiles (the odd-tile waves with and without a last tile of their own), key counts that are no multiple of the 64-key tile with NaN
+    behind the last key (the DMA of the last tile must re-read valid rows instead), batch 2, GQA down to one kv head, a prompt chunk
+    behind a cache, the cache full to its last row."""
+    _attn_case(ce, bsz, q_len, heads, kvh, 128, past, 2048 if past + q_len <= 2048 else past + q_len, seed=1000 + q_len + past, poison=True)
+
+
+@pytest.mark.parametrize("q_len,past,spikes", [(128, 0, (100,)), (512, 0, (70, 300, 301, 500)), (384, 100, (120, 470)), (700, 0, (690,))])
+def test_attention_prefill_reference_point_moves_late(ce, q_len, past, spikes):
+    """Both prompt kernels keep a LAZY reference maximum (it only moves when a row maximum grows by more than 2^8, then O and l are
+    rescaled once).  Random scores never take that branch after the first tiles: here single keys dominate everything before them by
+    e^30 and more, at the start, in the middle and in the last tile, for one and for both of the 8-wave kernel's tile sets."""
+    _attn_case(ce, 1, q_len, 4, 2, 128, past, 1024, seed=77 + q_len, spikes=spikes)
 
 
 def test_attention_prefill_full_size_row_checks(ce):
