@@ -437,7 +437,8 @@ __device__ unsigned long long g_attn_probe[512 * 8];                // [block][p
 // NW = waves per block (EXL_DEC_ATTN_WAVES): 4 -> 16 key rows per step, 10 rows per thread and chunk, 5 in flight;
 //                                            8 -> 32 key rows per step,  5 rows per thread and chunk, all 5 K rows in flight
 // (twice the waves per CU at the same bytes in flight per thread).
-// The one-split bucket (context <= 160; the benchmark's "best case" runs here): round 2's kernel, unchanged.  The chunked form
+// The one-split bucket (context <= 160; the benchmark's "best case" runs here): round 2's kernel with, since round 4, the reductions of the
+// kernel below (DPP row sums instead of 100 ds_bpermute round trips per thread, barriers that do not drain the V loads).  The chunked form
 // below measured 0.3 us slower per launch here and 35 us per token slower inside the graph (same box, A/B of the two libraries:
 // 806 -> 773 tokens/s at context 4), where there is nothing to speculate on and one split to balance.
 template <int NW>
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_short_kernel(const f16* __re
     constexpr bool SHORT = true;
     constexpr int HD = 128, LPK = 16, KPI = NW * 4, UN = DEC_ATT_CHUNK / 16, NT = NW * 64;   // 10 rows per thread and pass: 160 keys with 4 waves, 320 with 8
     __shared__ float sc[DEC_ATT_MAX_KEYS];
-    __shared__ float red[KPI][HD + 1];
+    __shared__ float red[NW][HD + 1];
     __shared__ float stat[2 * NW];
 
     // 1-D grid; block id -> (head, split) such that every split of head h runs on XCD h % 8 (block b runs on XCD b % 8,
@@ -544,8 +545,7 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_short_kernel(const f16* __re
         float dot = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) dot = fmaf(qf[e], (float) kk[e], dot);
-#pragma unroll
-        for (int off = 1; off < LPK; off <<= 1) dot += __shfl_xor(dot, off, 64);
+        dot = dec_row_sum(dot);                                        // 16 lanes of a key row: DPP, no LDS-pipe round trips
         if (j < nkeys) {
             if (d8 == 0) sc[j] = dot;
             mx = fmaxf(mx, dot);
@@ -576,24 +576,22 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_short_kernel(const f16* __re
         score_chunk(j0, kv);
     }
     AP_CLK(3);                                                       // K rows landed, scores done
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    mx = dec_row_max(mx);
+    mx = fmaxf(fmaxf(dec_lane(mx, 0), dec_lane(mx, 16)), fmaxf(dec_lane(mx, 32), dec_lane(mx, 48)));
     if ((tid & 63) == 0) stat[tid >> 6] = mx;
-    __syncthreads();
+    dec_lds_barrier();                                               // LDS hand-off only: the V rows stay in flight across it (__syncthreads drains vmcnt)
     mx = stat[0];
 #pragma unroll
     for (int w = 1; w < NW; ++w) mx = fmaxf(mx, stat[w]);
-    __syncthreads();
     float lsum = 0.f;
     for (int j = tid; j < nkeys; j += NT) {
         const float p = __expf(sc[j] - mx);
         sc[j] = p;
         lsum += p;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off, 64);
+    lsum = dec_wave_sum(lsum);
     if ((tid & 63) == 0) stat[NW + (tid >> 6)] = lsum;
-    __syncthreads();
+    dec_lds_barrier();
     lsum = stat[NW];
 #pragma unroll
     for (int w = 1; w < NW; ++w) lsum += stat[NW + w];
@@ -625,8 +623,13 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_short_kernel(const f16* __re
         pv_chunk(j0, vv);
     }
     AP_CLK(5);                                                       // V rows landed, P V done
+    // the 4 key rows of a wave first (v_permlane16_swap / v_permlane32_swap), then one row per wave through LDS
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[ks][d8 * 8 + e] = o[e];
+    for (int e = 0; e < 8; ++e) o[e] = dec_rows_sum(o[e]);
+    if ((tid & 63) < 16) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid >> 6][d8 * 8 + e] = o[e];
+    }
     __syncthreads();
     // Several splits: each writes its OWN attention output (normalised by its own sum: a convex combination of V rows,
     // safe in fp16) plus (max, sum); the o_proj kernel combines them while it builds its activation image.
@@ -635,7 +638,7 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_short_kernel(const f16* __re
     if (tid < HD) {
         float v = 0.f;
 #pragma unroll
-        for (int s = 0; s < KPI; ++s) v += red[s][tid];
+        for (int s = 0; s < NW; ++s) v += red[s][tid];
         const f16 r = (f16) (nkeys > 0 ? v / lsum : 0.f);
         if (direct_out) direct_out[out_perm ? (int) out_perm[h * HD + tid] : h * HD + tid] = r;   // a single split: this IS the attention output
                                                                         // (stored where an act-order o_proj reads it linearly)
