@@ -473,18 +473,20 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_short_kernel(const f16* __re
     unsigned long long ap_t[7];
     const unsigned long long ap_t0 = __builtin_readcyclecounter();
 #endif
+    const int kvh = h / (heads / kv_heads);
+    f16* kbase = kc + (size_t) kvh * max_seq * HD + d8 * 8;
+    f16* vbase = vc + (size_t) kvh * max_seq * HD + d8 * 8;
     const int past = *pos_dev;
     const int vis = past + 1;
     int L = (vis + nsplit - 1) / nsplit;
     L = (L + 15) & ~15;
     const int s0 = min(vis, split * L), s1 = min(vis, s0 + L);
     const int nkeys = s1 - s0;
-    const int kvh = h / (heads / kv_heads);
-    f16* kbase = kc + (size_t) kvh * max_seq * HD + d8 * 8;
-    f16* vbase = vc + (size_t) kvh * max_seq * HD + d8 * 8;
 
     AP_CLK(0);                                                       // position known
     // ---- every load of the first chunk up front: small ones first, then K rows, then V rows -------------------------
+    // (Round 4, measured and not kept: q, the new k / v and the first K rows of every thread requested BEFORE the position is read --
+    // with one split their addresses do not depend on it -- made no difference to the replay rate at context 4, scripts/gpu_calls/r04r.sh.)
     const f16x8 sn = *(const f16x8*) (sin + (size_t) past * HD + d8 * 8);
     const f16x8 cs = *(const f16x8*) (cos + (size_t) past * HD + d8 * 8);
     const f16x8 qraw = *(const f16x8*) (q + (size_t) h * HD + d8 * 8);

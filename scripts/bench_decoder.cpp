@@ -1,7 +1,7 @@
 // Stand-alone driver of the native decode executor through the C ABI only (no Python, no torch): builds a synthetic
 // Llama-7B-shaped GPTQ model in HBM, then reports per-kernel-class times (exl_decoder_step_timed) and the hipGraph
 // replay rate at two context lengths.  Doubles as a C-caller example of include/exl_amd.h.
-//   hipcc -O2 -std=c++17 scripts/bench_decoder.cpp -Iinclude -Lexllama_amd -lexl_amd -Wl,-rpath,'$ORIGIN/../exllama_amd' -o build/bench_decoder
+//   hipcc -O2 -std=c++17 --offload-arch=gfx950 scripts/bench_decoder.cpp -Iinclude -Lexllama_amd -lexl_amd -Wl,-rpath,'$ORIGIN/../exllama_amd' -o build/bench_decoder
 //   build/bench_decoder [layers=32] [ctx=2048] [groupsize=128] [contexts=2: ctx and 4; 1: ctx only (counter passes)]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
