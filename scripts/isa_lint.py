@@ -15,6 +15,13 @@ outstanding load has not delivered yet, and every `s_endpgm` reached with an LDS
 the same model), so every report is a hand-counting or liveness defect.
 
     python scripts/isa_lint.py [path/to/libexl_amd.so] [--kernel SUBSTR] [-v]
+A second, unrelated rule rides along (round 4): REGISTER COPIES IN MFMA LOOPS.  With a wide accumulator (16 registers per MFMA result,
+64 per wave in the prompt attention kernel) live across a branch, hipcc has kept the accumulators in two places and copied them
+every iteration -- 64-96 `v_mov_b64` beside 32 MFMAs, a third of the loop's issue slots, with nothing in the source to show for it
+("flash_prefill8_kernel").  Every innermost loop with >= 16 MFMAs is checked for the number of registers moved by
+`v_mov_b32` / `v_mov_b64` / `v_accvgpr_*` per MFMA; the library's loops sit at <= 1.4, the defect at 4-6, the limit is 2.
+
+    python scripts/isa_lint.py [path/to/libexl_amd.so] [--kernel SUBSTR] [-v]
 Exit code 1 when a hazard is found.  tests/test_isa_lint.py runs it over the built library.
 """
 import os
@@ -284,6 +291,33 @@ def lint_kernel(name, insns, verbose=False):
     return list(report.values()) + extra + valu_sgpr_hazards(name, insns)
 
 
+COPY_RULE_MIN_MFMA = 16
+COPY_RULE_LIMIT = 2.0
+
+
+def accumulator_copy_hazards(name, insns):
+    """Innermost loops with >= COPY_RULE_MIN_MFMA MFMAs that move >= COPY_RULE_LIMIT registers per MFMA with plain copies."""
+    index = {a: i for i, (a, _, _) in enumerate(insns)}
+    loops = []
+    for i, (addr, mn, ops) in enumerate(insns):
+        t = branch_target(addr, mn, ops)
+        if t is not None and t in index and index[t] <= i:
+            loops.append((index[t], i))
+    out = []
+    for lo, hi in loops:
+        if any(m != (lo, hi) and m[0] >= lo and m[1] <= hi for m in loops):
+            continue                                                   # not innermost
+        body = insns[lo:hi + 1]
+        mfma = sum(1 for _, mn, _ in body if "mfma" in mn)
+        if mfma < COPY_RULE_MIN_MFMA:
+            continue
+        regs = sum(2 if mn.startswith("v_mov_b64") else 1 for _, mn, _ in body if mn.startswith(("v_mov_b32", "v_mov_b64", "v_accvgpr_")))
+        if regs >= COPY_RULE_LIMIT * mfma:
+            out.append((name, insns[lo][0], f"loop of {hi - lo + 1} instructions with {mfma} MFMAs", insns[lo][0],
+                        f"{regs} registers copied per iteration (v_mov / v_accvgpr): accumulators kept in two places?", []))
+    return out
+
+
 def lint_library(so_path, kernel_filter=None, verbose=False):
     """-> (number of kernels checked, [hazard tuples])"""
     hazards, count = [], 0
@@ -295,7 +329,7 @@ def lint_library(so_path, kernel_filter=None, verbose=False):
                 if not insns:
                     continue
                 count += 1
-                hz = lint_kernel(name, insns, verbose)
+                hz = lint_kernel(name, insns, verbose) + accumulator_copy_hazards(name, insns)
                 if verbose:
                     print(f"{name[:100]}: {len(insns)} instructions, {len(hz)} hazards")
                 hazards += hz
@@ -312,7 +346,10 @@ def main(argv):
     so = args[0] if args else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "exllama_amd", "libexl_amd.so")
     count, hazards = lint_library(so, kf, verbose)
     for (name, addr, text, qa, qtext, regs) in hazards:
-        print(f"HAZARD {name[:90]}\n   {addr:#x}: {text}\n   touches v{regs} while the load at {qa:#x} is outstanding: {qtext}")
+        if regs:
+            print(f"HAZARD {name[:90]}\n   {addr:#x}: {text}\n   touches v{regs} while the load at {qa:#x} is outstanding: {qtext}")
+        else:
+            print(f"HAZARD {name[:90]}\n   {addr:#x}: {text}\n   {qtext}")
     print(f"{count} kernels checked, {len(hazards)} hazards")
     return 1 if hazards else 0
 

@@ -83,3 +83,17 @@ def test_built_library_has_no_in_flight_register_hazard():
     count, hazards = isa_lint.lint_library(LIB)
     assert count > 100                                             # every translation unit's kernels were found
     assert hazards == [], "\n".join(f"{h[0][:80]} {h[1]:#x}: {h[2]}  <- {h[4]}" for h in hazards[:10])
+
+
+def test_lint_flags_accumulators_copied_inside_an_mfma_loop():
+    # what hipcc made of the prompt attention kernel while a 64-register accumulator lived across a branch: whole accumulators moved per
+    # iteration.  16 MFMAs with 32 v_mov_b64 (64 registers) in the loop is flagged, the same loop with the handful of moves every loop has is not
+    def loop(nmov):
+        body = [("v_mfma_f32_32x32x16_f16", "v[0:15], v[64:67], v[68:71], v[0:15]")] * 16 + [("v_mov_b64_e32", "v[100:101], v[0:1]")] * nmov
+        return _k([("s_mov_b32", "s0, 0")] + body + [("s_cbranch_scc1", str((0x104 - (0x104 + 4 * len(body) + 4)) // 4 & 0xFFFF)), ("s_endpgm", "")])
+    bad = isa_lint.accumulator_copy_hazards("bad", loop(32))
+    assert len(bad) == 1 and "64 registers copied" in bad[0][4]
+    assert isa_lint.accumulator_copy_hazards("good", loop(4)) == []
+    few = _k([("v_mfma_f32_16x16x32_f16", "v[0:3], v[8:11], v[12:15], v[0:3]")] * 4 + [("v_mov_b64_e32", "v[20:21], v[0:1]")] * 30 +
+             [("s_cbranch_scc1", str((0x100 - (0x100 + 4 * 34 + 4)) // 4 & 0xFFFF)), ("s_endpgm", "")])
+    assert isa_lint.accumulator_copy_hazards("few MFMAs: not a matrix loop", few) == []
