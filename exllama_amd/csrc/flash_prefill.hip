@@ -423,6 +423,11 @@ __global__ __launch_bounds__(512) void flash_prefill8_kernel(const f16* __restri
                          s[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kb_[kb], qf[kb], s[1], 0, 0, 0); if (!(FA8_ABL & 1)) dma(kb)
         FA8_STEPB(7, 0); FA8_STEPB(6, 1); FA8_STEPB(5, 2); FA8_STEPB(4, 3); FA8_STEPB(3, 4); FA8_STEPB(2, 5); FA8_STEPB(1, 6); FA8_STEPB(0, 7);
 #undef FA8_STEPB
+        // The counted waits above hold as long as NOTHING ELSE enters the LDS queue between the first read and the last wait: the V^T reads
+        // of the softmax / P V part below depend on nothing computed here, so neither the compiler (memory clobber) nor the machine
+        // scheduler (sched_barrier) may lift them into this stretch.
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     // ---- causal mask + online softmax of S (this lane: query qrow, keys kv0 + kt*32 + (r&3)+8*(r>>2)+4*g), then O^T += V^T P^T with the V
