@@ -20,6 +20,8 @@ A second, unrelated rule rides along (round 4): REGISTER COPIES IN MFMA LOOPS.  
 every iteration -- 64-96 `v_mov_b64` beside 32 MFMAs, a third of the loop's issue slots, with nothing in the source to show for it
 ("flash_prefill8_kernel").  Every innermost loop with >= 16 MFMAs is checked for the number of registers moved by
 `v_mov_b32` / `v_mov_b64` / `v_accvgpr_*` per MFMA; the library's loops sit at <= 1.4, the defect at 4-6, the limit is 2.
+And a third for the one kernel that counts `lgkmcnt` by hand (flash_prefill8_kernel's K fragment reads): under every partial wait the
+LDS queue may hold one kind of LDS operation only and no scalar memory read (lgkm_count_hazards).
 
     python scripts/isa_lint.py [path/to/libexl_amd.so] [--kernel SUBSTR] [-v]
 Exit code 1 when a hazard is found.  tests/test_isa_lint.py runs it over the built library.
@@ -291,6 +293,40 @@ def lint_kernel(name, insns, verbose=False):
     return list(report.values()) + extra + valu_sgpr_hazards(name, insns)
 
 
+HAND_COUNTED_LGKM_PREFIXES = ("_Z21flash_prefill8_kernel",)   # kernels with hand-issued LDS reads under counted lgkmcnt waits
+
+
+def lgkm_count_hazards(name, insns):
+    """A partial wait `s_waitcnt lgkmcnt(N > 0)` retires the OLDEST LDS operations (they return in order); a scalar memory read in the
+    queue returns out of order and makes the count meaningless, and a hand-counted sequence only holds while nothing else enters the queue
+    between its first read and its last wait.  In the kernels named above every partial wait must therefore see, since the last full
+    drain of its basic block, LDS operations of ONE kind only and no scalar memory operation: an LDS read of another kind that the
+    compiler or the scheduler lifted into a counted stretch shows up as a second kind."""
+    if not name.startswith(HAND_COUNTED_LGKM_PREFIXES):
+        return []
+    out, queue = [], []
+    for addr, mn, ops in insns:
+        if mn.startswith(("s_cbranch", "s_branch", "s_barrier", "s_endpgm")):
+            queue = []                                                 # (every block of these kernels is entered behind a full drain or a barrier)
+            continue
+        if mn.startswith(("ds_", "s_load", "s_buffer_load", "s_memtime", "s_memrealtime")):
+            queue.append((addr, mn))
+            continue
+        if mn == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", ops)
+            if m is None:
+                continue
+            n = int(m.group(1))
+            if n > 0:
+                kinds = sorted({q for _, q in queue})
+                scalar = [q for q in kinds if q.startswith("s_")]
+                if scalar or len(kinds) > 1:
+                    out.append((name, addr, f"s_waitcnt {ops}", queue[0][0] if queue else addr,
+                                "partial LDS wait with " + (", ".join(kinds)) + " in the queue: a counted wait needs one kind of LDS operation and no scalar read", []))
+            queue = queue[len(queue) - n:] if n and n < len(queue) else ([] if n == 0 else queue)
+    return out
+
+
 COPY_RULE_MIN_MFMA = 16
 COPY_RULE_LIMIT = 2.0
 
@@ -329,7 +365,7 @@ def lint_library(so_path, kernel_filter=None, verbose=False):
                 if not insns:
                     continue
                 count += 1
-                hz = lint_kernel(name, insns, verbose) + accumulator_copy_hazards(name, insns)
+                hz = lint_kernel(name, insns, verbose) + accumulator_copy_hazards(name, insns) + lgkm_count_hazards(name, insns)
                 if verbose:
                     print(f"{name[:100]}: {len(insns)} instructions, {len(hz)} hazards")
                 hazards += hz

@@ -97,3 +97,21 @@ def test_lint_flags_accumulators_copied_inside_an_mfma_loop():
     few = _k([("v_mfma_f32_16x16x32_f16", "v[0:3], v[8:11], v[12:15], v[0:3]")] * 4 + [("v_mov_b64_e32", "v[20:21], v[0:1]")] * 30 +
              [("s_cbranch_scc1", str((0x100 - (0x100 + 4 * 34 + 4)) // 4 & 0xFFFF)), ("s_endpgm", "")])
     assert isa_lint.accumulator_copy_hazards("few MFMAs: not a matrix loop", few) == []
+
+
+def test_lint_flags_a_foreign_operation_in_a_hand_counted_lds_queue():
+    # flash_prefill8_kernel issues its K fragment reads by hand and waits with counted lgkmcnt: another kind of LDS read lifted into the
+    # stretch, or a scalar memory read (returns out of order), breaks the count
+    name = "_Z21flash_prefill8_kernelPKDF16_"
+    reads = [("ds_read_b128", f"v[{8 * i}:{8 * i + 3}], v100") for i in range(4)]
+    ok = _k(reads + [("s_waitcnt", "lgkmcnt(3)"), ("v_mfma_f32_32x32x16_f16", "v[64:79], v[0:3], v[40:43], v[64:79]"), ("s_waitcnt", "lgkmcnt(0)"), ("s_endpgm", "")])
+    assert isa_lint.lgkm_count_hazards(name, ok) == []
+    lifted = _k(reads[:2] + [("ds_read_b64_tr_b16", "v[50:51], v101")] + reads[2:] + [("s_waitcnt", "lgkmcnt(3)"), ("s_endpgm", "")])
+    hz = isa_lint.lgkm_count_hazards(name, lifted)
+    assert len(hz) == 1 and "ds_read_b64_tr_b16" in hz[0][4]
+    scalar = _k([("s_memtime", "s[4:5]")] + reads + [("s_waitcnt", "lgkmcnt(3)"), ("s_endpgm", "")])
+    assert len(isa_lint.lgkm_count_hazards(name, scalar)) == 1
+    assert isa_lint.lgkm_count_hazards("some_other_kernel", lifted) == []               # compiler-counted kernels are correct by construction
+    # behind a full drain the queue starts again
+    again = _k([("ds_bpermute_b32", "v1, v2, v3"), ("s_waitcnt", "lgkmcnt(0)")] + reads + [("s_waitcnt", "lgkmcnt(2)"), ("s_endpgm", "")])
+    assert isa_lint.lgkm_count_hazards(name, again) == []
