@@ -330,7 +330,6 @@ __global__ __launch_bounds__(512) void flash_prefill8_kernel(const f16* __restri
     const int last_q = min(q0 + FA_BQ, q_len) - 1;
     const int ntiles = (min(kv_len, past_len + last_q + 1) + FA_BKV - 1) / FA_BKV;
     const int niter = (ntiles + 1) >> 1;
-    const int wave_last_key = past_len + min(q0 + wq * 32 + 31, q_len - 1);
 
     const f16* kbase = kc + ((size_t) b * kv_heads + kvh) * max_seq * FA_HD;
     const f16* vbase = vc + ((size_t) b * kv_heads + kvh) * max_seq * FA_HD;
