@@ -502,7 +502,8 @@ __global__ __launch_bounds__(512) void flash_prefill8_kernel(const f16* __restri
     // Measured on the way and not kept (scripts/bench_flash.hip, S = 2048, 32 heads; this form: 51.9 us): P V of the tile before issued in
     // one basic block with this tile's exponentials (the matrix and the vector pipe fed by ONE wave): 55.3 us; the two sets a third of a
     // step apart (one instruction stream, the odd set at the barrier between softmax / P V and S): 55.4 us; the odd set started late by
-    // s_sleep: 52.7-59 us.  Phase probe of the second (cycles per step, 2 wave-tiles per SIMD): 3950 = 2 x ~1000 in S, 2 x ~1800 in softmax
+    // s_sleep: 52.7-59 us; the DMA pieces issued in the vector stretch behind S instead of between its MFMAs: 52.4 against 53.1 us, within
+    // what the validated form is worth keeping for.  Phase probe of the second (cycles per step, 2 wave-tiles per SIMD): 3950 = 2 x ~1000 in S, 2 x ~1800 in softmax
     // + P V, the rest at the barrier; the matrix pipe is busy 2048 of them.  At 56 us per launch those 17 x 3950 cycles mean a shader clock
     // of ~1.3-1.4 GHz: like the GEMMs of the prompt pass this kernel runs into the power limit, and what is left is energy per tile
     // rather than an idle pipe.
