@@ -21,6 +21,7 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+os.environ.setdefault("EXL_REQUIRE_FAST_BINDING", "1")         # a benchmark never runs on the ctypes path by accident (cuda_ext.py)
 
 import torch
 
@@ -52,6 +53,15 @@ def parse_args():
     p.add_argument("--no-graph", action="store_true", help="decode eagerly instead of replaying the captured hipGraph")
     p.add_argument("--host-argmax", action="store_true", help="greedy argmax by torch between graph replays (the reference's loop) instead of inside the graph")
     p.add_argument("--no-roofline-probe", action="store_true")
+    p.add_argument("--brief", action="store_true",
+                   help="the timed protocol, path_roofline and the kernel probes only: no other prompt lengths, host-loop tiers, CPU baseline, "
+                        "drop-in run or other configs (what the sub-runs of the default invocation use)")
+    p.add_argument("--no-other-configs", action="store_true",
+                   help="default 7B run on one GPU: do not run BASELINE configs[2..4] (13B act-order, 33B g32 act-order, 65B) and the drop-in "
+                        "path as sub-runs after the headline")
+    p.add_argument("--no-sharded", action="store_true",
+                   help="--gpus N > 1: do not run the sharded sub-runs (--layer-split / --tensor-parallel over the same N GPUs) after the "
+                        "replica headline")
     p.add_argument("--layer-split", action="store_true",
                    help="ONE model split by layers across the ranks (hidden states handed off by RCCL send/recv, exllama_amd/pipeline.py) "
                         "instead of one replica per rank; capacity mode: the stages run one after the other at batch 1")
@@ -445,6 +455,7 @@ def main():
             "layers": L, "prompt_tokens": S, "gen_tokens": G, "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
             "decode_mode": ("hipGraph replay, greedy argmax inside the graph" if device_greedy else
                             "hipGraph replay, torch.argmax between replays" if use_graph else "eager launches"),
+            "decode_path_report": model.decode_path_report(cache),     # which tier a token step takes on this model / cache, and why
         },
         "prefill_tokens_per_s": round(prefill_tps, 1),
         "decode_worst_tokens_per_s": round(decode_tps, 2),
@@ -460,7 +471,7 @@ def main():
     # ---- further protocol points, measured after the timed region (not part of `value`) -----------------------------
     # the reference's own `-p` lengths (test_benchmark_inference.py:157-180: S = max_seq_len - 128 = 1920 with -l 2048) and
     # the 128-token prompt of BASELINE configs[0]; each: 2 warm-up passes, then the mean of 3
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.brief:
         def timed_prefill(n_tok, reps=3):
             for _ in range(2):
                 cache.current_seq_len = 0
@@ -545,24 +556,158 @@ def main():
         except Exception as exc:                                  # measurement aid only: never fail the benchmark line
             result["prefill_roofline"] = {"error": str(exc)}
     # ---- CPU baseline: the oracle ("port") on a bounded sample of the same workload ----------------------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.brief:
         result["cpu_baseline"] = cpu_baseline(dims, args.groupsize, ctx=S,
                                               sample_layers=dims.num_hidden_layers if args.cpu_baseline_full else 2)
-    # ---- the drop-in path (the reference's unmodified model.py on the cuda_ext shim, its own -p loop): measured offline by
-    # scripts/bench_dropin.py (it executes reference code, which exists only where the archive was staged) and quoted here
-    if rank == 0 and args.model == "7b" and args.groupsize == 128:
-        try:
-            with open(os.path.join(ROOT, "profiles", "r04_dropin_reference_model_py_compiled_binding.json")) as f:
-                result["dropin_reference_model_py"] = dict(json.load(f), source="offline: scripts/bench_dropin.py (round 4, compiled binding; same box on the ctypes path: "
-                                                           "profiles/r04_dropin_reference_model_py_ctypes_same_box.json), committed under profiles/; not re-measured in this run")
-        except Exception:
-            pass
+    # ---- everything below runs AFTER the timed region as sub-runs of this same file / of scripts/, each in its own process
+    # (own HIP context, memory released when it ends), on the GPU(s) this job was given, and lands in the ONE JSON line: every
+    # number in the line is measured in THIS invocation.  A sub-run that fails or times out leaves an {"error": ...} record.
+    extras_ok = rank == 0 and not args.brief and args.model == "7b" and args.groupsize == 128 and not args.act_order and args.layers is None
+    if extras_ok and world == 1:
+        del model, cache
+        torch.cuda.empty_cache()
+        if not args.no_other_configs:
+            # BASELINE configs[2..4] on this one GPU (every model fits 288 GB): same protocol, fewer steps
+            result["other_configs"] = {
+                "13b_g128_actorder": sub_bench(["--model", "13b", "--act-order", "--steps", "2", "--warmup", "1"], "BASELINE configs[2]"),
+                "33b_g32_actorder": sub_bench(["--model", "33b", "--groupsize", "32", "--act-order", "--steps", "2", "--warmup", "1"],
+                                              "BASELINE configs[3] on ONE device (its 2-GPU layer split: --gpus 2)"),
+                "65b_g128": sub_bench(["--model", "65b", "--steps", "1", "--warmup", "1"],
+                                      "BASELINE configs[4] on ONE device (its 8-GPU layer split: --gpus 8)"),
+            }
+            # the drop-in path: the reference's UNMODIFIED model.py on the cuda_ext shim, its own -p loop (scripts/bench_dropin.py;
+            # the reference's three .py files travel in the git-ignored oracle/_ref/refpy.tgz -- absent: the key is omitted)
+            dropin = dropin_run()
+            if dropin is not None:
+                result["dropin_reference_model_py"] = dropin
 
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if extras_ok and world > 1 and not args.no_sharded:
+        # the replicas are done and every other rank is exiting (its GPU is free): rank 0 launches ONE model sharded over the same N GPUs
+        # -- the reference's layer split (model.py:636-668; P2P hidden-state hand-off over RCCL) and the tensor-parallel mode -- each as
+        # its own torch.distributed.run job with a time limit, so a hang or crash there cannot take the replica headline with it
+        del model, cache
+        torch.cuda.empty_cache()
+        time.sleep(3.0)
+        result["sharded"] = sharded_runs(world)
     if rank == 0:                                                  # the ONE JSON line last (after RCCL's teardown output, if any)
         print(json.dumps(result), flush=True)
+
+
+def _last_json_line(text):
+    for line in reversed(text.strip().splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                continue
+    return None
+
+
+def _run_sub(cmd, limit_s, env=None):
+    """One sub-run with a wall-clock limit; returns (parsed JSON line or None, seconds, error text or None)."""
+    import subprocess
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s, cwd=ROOT, env=env)
+    except subprocess.TimeoutExpired:
+        return None, time.perf_counter() - t0, f"timed out after {limit_s} s"
+    except Exception as e:                                            # noqa: BLE001
+        return None, time.perf_counter() - t0, str(e)[:300]
+    d = _last_json_line(r.stdout)
+    if r.returncode != 0 or d is None:
+        return None, time.perf_counter() - t0, f"rc {r.returncode}: {(r.stderr or r.stdout)[-400:]}"
+    return d, time.perf_counter() - t0, None
+
+
+_SUB_KEEP = ("value", "unit", "ms_per_step", "steps", "warmup", "prefill_tokens_per_s", "decode_worst_tokens_per_s", "decode_best_tokens_per_s",
+             "prefill_ms", "decode_worst_ms_per_token", "decode_best_ms_per_token", "path_roofline", "scaling", "n_gpus", "rccl_ranks", "backend",
+             "per_rank")
+
+
+def _sub_record(d, secs, err, what):
+    if err is not None:
+        return {"what": what, "error": err, "seconds": round(secs, 1)}
+    rec = {"what": what, "workload": d["config"]["workload"], "decode_mode": d["config"].get("decode_mode") or d["config"].get("parallelism"),
+           "measured": "this run (sub-run of the same bench.py after the timed region)", "seconds": round(secs, 1)}
+    rec.update({k: d[k] for k in _SUB_KEEP if k in d})
+    for k in ("roofline", "prefill_roofline"):
+        if isinstance(d.get(k), dict) and "frac" in d[k]:
+            rec[k] = {kk: d[k][kk] for kk in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_us") if kk in d[k]}
+    return rec
+
+
+def sub_bench(flags, what, limit_s=900):
+    d, secs, err = _run_sub([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--brief"] + flags, limit_s)
+    return _sub_record(d, secs, err, what)
+
+
+def dropin_run(limit_s=600):
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "refpy.tgz")):
+        return None
+    import tempfile
+    out = os.path.join(tempfile.mkdtemp(prefix="exl_dropin_"), "dropin.json")
+    _, secs, err = _run_sub([sys.executable, os.path.join(ROOT, "scripts", "bench_dropin.py"), "--out", out], limit_s)
+    try:
+        with open(out) as f:
+            d = json.load(f)
+    except Exception:                                                 # noqa: BLE001
+        return {"error": err or "no output", "seconds": round(secs, 1)}
+    d["measured"] = "this run (scripts/bench_dropin.py as a sub-run after the timed region)"
+    d["seconds"] = round(secs, 1)
+    return d
+
+
+def sharded_runs(world, limit_s=900):
+    """ONE model over the N GPUs of this job, launched by rank 0 after the replica run: `python -m torch.distributed.run ... bench.py
+    --layer-split / --tensor-parallel` on a fresh rendezvous port."""
+    import socket
+    out = {}
+
+    def launch(flags, what):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                                                                  "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--brief"] + flags
+        d, secs, err = _run_sub(cmd, limit_s, env=env)
+        return _sub_record(d, secs, err, what)
+    out["layer_split_65b"] = launch(["--layer-split", "--model", "65b", "--steps", "1", "--warmup", "1"],
+                                    f"BASELINE configs[4]: Llama-65B g128 split by layers over {world} GPUs (reference: model.py:636-668)")
+    if world == 2:
+        out["layer_split_33b_g32_actorder"] = launch(["--layer-split", "--model", "33b", "--groupsize", "32", "--act-order", "--steps", "2", "--warmup", "1"],
+                                                     "BASELINE configs[3]: Llama-33B g32 act-order split by layers over 2 GPUs")
+    out["layer_split_7b"] = launch(["--layer-split", "--steps", "2", "--warmup", "1"], f"Llama-7B g128 split by layers over {world} GPUs")
+    out["tensor_parallel_7b"] = launch(["--tensor-parallel", "--steps", "2", "--warmup", "1"],
+                                       f"Llama-7B g128 tensor parallel over {world} GPUs (not in the reference; SURVEY.md 8 row N4)")
+    return out
+
+
+def newest_pmc_profile():
+    """profiles/rNN_pmc_traffic.json of the highest round present (collected by scripts/gpu_rNN_profiles.sh in separate rocprofv3 --pmc
+    passes: counters cannot be read inside this process).  Returns (dict, provenance string) or (None, None)."""
+    import glob
+    import re
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")):
+        m = re.match(r"r(\d+)_pmc_traffic\.json$", os.path.basename(path))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), path)
+    if best is None:
+        return None, None
+    try:
+        with open(best[1]) as f:
+            d = json.load(f)
+    except Exception:                                                 # noqa: BLE001
+        return None, None
+    stamp = ", ".join(f"{k} {d[k]}" for k in ("git_head", "collected") if k in d) or "no git / date stamp in the file"
+    return d, (f"offline PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs; FETCH_SIZE doubled per MI355X_MICROARCH.md): "
+               f"profiles/{os.path.basename(best[1])} [{stamp}]; counters cannot be collected inside this process")
 
 
 def decoder_roofline_probe(model, cache, dims, g, ctx, steps=6):
@@ -593,21 +738,18 @@ def decoder_roofline_probe(model, cache, dims, g, ctx, steps=6):
         classes[k] = {"us_per_launch": round(us, 3), "GBps": round(per_launch[k] / us / 1e3, 1) if per_launch[k] else None}
     dom = "gate_up"
     achieved = per_launch[dom] / (ms[dom] / L / 1e3) / 1e9
-    # HBM traffic of the same kernel from the PMC counters: collected OFFLINE in separate rocprofv3 --pmc passes
-    # (scripts/gpu_r04_profiles.sh -> profiles/r04_pmc_traffic.json); only valid for the shapes it was measured on
+    # HBM traffic of the same kernel from the PMC counters (newest round's file; only valid for the shapes it was measured on)
     traffic = None
+    pmc, pmc_src = newest_pmc_profile()
     try:
-        with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) as f:
-            pmc = json.load(f)
-        if (h, I, g) == (4096, 11008, 128):
+        if pmc is not None and (h, I, g) == (4096, 11008, 128):
             traffic = pmc["decode_classes"][dom]["hbm_bytes_per_launch"]
     except Exception:
         traffic = None
     return {"bound": "hbm", "kernel": "dec_ring_kernel<PNORM=1, EMODE=2> (fused RMSNorm + gate/up projections + SiLU*mul, one launch per layer)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
-            "traffic_source": ("offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (scripts/gpu_r04_profiles.sh), FETCH_SIZE doubled per "
-                               "MI355X_MICROARCH.md, committed as profiles/r04_pmc_traffic.json; not re-measured in this run") if traffic else None,
+            "traffic_source": pmc_src if traffic else None,
             "launches": L * steps, "avg_launch_us": round(ms[dom] * 1e3 / L, 3),
             "algorithmic_bytes_per_launch": int(per_launch[dom]), "classes": classes,
             "token_ms_sum_of_classes": round(sum(ms.values()), 4),
@@ -640,18 +782,17 @@ def prefill_gemm_probe(model, dims, S, dev, reps=2):
     flops = 2 * 2.0 * S * h * I
     tf = flops / us / 1e6
     traffic = None
-    try:                                                          # L2 <-> fabric bytes of the same kernel at the 7B shape (offline PMC passes)
-        with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) as f:
-            pre = json.load(f)["prefill"]
-        if (h, I, S) == (4096, 11008, 2048):
-            traffic = [v["hbm_bytes_per_launch"] for k, v in pre.items() if "q4_gemm_t16d2" in k][0]
+    pmc, pmc_src = newest_pmc_profile()                           # L2 <-> fabric bytes of the same kernel at the 7B shape
+    try:
+        if pmc is not None and (h, I, S) == (4096, 11008, 2048):
+            traffic = [v["hbm_bytes_per_launch"] for k, v in pmc["prefill"].items() if "q4_gemm_t16d2" in k][0]
     except Exception:
         traffic = None
     return {"bound": "mfma", "kernel": "q4_gemm_t16d2_kernel (fused int4 dequant + gate/up MFMA GEMMs + SiLU*mul, one launch per layer)",
             "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4),
             "launches": reps * len(mlps), "avg_launch_us": round(us, 2), "flops_per_launch": int(flops), "rows": S,
             "traffic": traffic, "algorithmic_bytes_per_launch": int(h * I + 2.5 * 2 * (h // 128) * I + 2 * S * (h + I)),
-            "traffic_source": "offline: profiles/r04_pmc_traffic.json (scripts/gpu_r04_profiles.sh)" if traffic else None}
+            "traffic_source": pmc_src if traffic else None}
 
 
 def gemv_roofline_probe(model, groupsize, dev, tokens=3):

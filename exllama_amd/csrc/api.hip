@@ -93,9 +93,14 @@ int exl_sampler_workspace(int device, size_t bytes, void** out)
 int exl_gemm_workspace(int device, size_t floats, float** out)
 {
     EXL_REQUIRE(device >= 0 && device < EXL_MAX_DEVICES, EXL_E_INVALID, "invalid device index %d", device);
+    // growth is serialised: two host threads running prompt passes on one device must not both free / allocate the buffer.
+    // Callers treat a non-zero return as "run the variant that needs no workspace" (launch_q4_gemm, plan_gemm_tail, half GEMM).
+    static std::mutex grow_lock;
+    std::lock_guard<std::mutex> hold(grow_lock);
     DeviceBuffers* b = &g_buffers[device];
     if (b->gemm_ws_floats < floats) {
-        if (floats > ((size_t) 512 << 20) / sizeof(float)) return EXL_E_TOO_SMALL;
+        if (floats > ((size_t) 512 << 20) / sizeof(float))
+            EXL_FAIL(EXL_E_TOO_SMALL, "GEMM workspace: %zu floats requested, the cap is 512 MiB", floats);
         int prev = 0;
         EXL_HIP(hipGetDevice(&prev));
         EXL_HIP(hipSetDevice(device));
@@ -104,7 +109,10 @@ int exl_gemm_workspace(int device, size_t floats, float** out)
         const size_t want = floats + floats / 4;             // head room: the next shape rarely needs a new allocation
         const hipError_t e = hipMalloc((void**) &b->gemm_ws, want * sizeof(float));
         (void) hipSetDevice(prev);
-        if (e != hipSuccess) { (void) hipGetLastError(); return EXL_E_TOO_SMALL; }
+        if (e != hipSuccess) {
+            (void) hipGetLastError();
+            EXL_FAIL(EXL_E_TOO_SMALL, "GEMM workspace: hipMalloc of %zu bytes failed (%s)", want * sizeof(float), hipGetErrorString(e));
+        }
         b->gemm_ws_floats = want;
     }
     *out = b->gemm_ws;
@@ -278,6 +286,7 @@ extern "C" int exl_make_q4(int device, int height, int width, int groups, uint32
         uint64_t hsh = 1469598103934665603ull;                        // FNV-1a over the map: equal maps <=> (with overwhelming odds) equal hashes
         for (int row = 0; row < height; ++row) { hsh ^= x_map[row]; hsh *= 1099511628211ull; }
         m->xmap_hash = hsh ? hsh : 1;
+        m->xmap_host = x_map;
         int prev = 0;
         hipError_t e = hipGetDevice(&prev);
         if (e == hipSuccess) e = hipSetDevice(device);

@@ -1,6 +1,7 @@
 // Internal declarations shared by the HIP translation units of libexl_amd.so (gfx950 only).
 #pragma once
 
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
@@ -66,6 +67,8 @@ struct Q4Matrix {
     uint32_t* x_map;   // owned   [K] or NULL (act-order)
     uint64_t xmap_hash;// FNV-1a of the map's K entries (0 without a map): matrices quantised against the same input (q / k / v, gate / up)
                        // carry the SAME map in GPTQ checkpoints; equal (height, hash) lets the fused prompt kernels gather once
+    std::vector<uint32_t> xmap_host;   // the map's entries on the host: equal hashes are CONFIRMED entry by entry (q4_same_map) before a
+                       // fused launch gathers k / v / up through q's / gate's map -- a hash collision must not pick a wrong permutation
     int layout;        // EXL_LAYOUT_GPTQ or EXL_LAYOUT_T16
     uint32_t fp[8];    // first and last 16 bytes of qweight AFTER the in-place rewrite (make_q4's double-call guard); fp_valid: rewritten
     bool fp_valid;

@@ -21,6 +21,7 @@
 // (prompt_prologue).  A 2-byte gather cannot ride in the 16-byte LDS-DMA pieces of the A tile.
 #include "gemv_t16.h"
 #include <stdlib.h>
+#include <string.h>
 
 #define MAGIC_1024 0x64006400u
 #define BM 128
@@ -1052,7 +1053,10 @@ static int plan_gemm_tail(int device, int mtiles, int ntiles, int K, int slices_
 bool q4_same_map(const Q4Matrix* a, const Q4Matrix* b)
 {
     if (!a->x_map || !b->x_map) return !a->x_map && !b->x_map;
-    return a->height == b->height && a->xmap_hash == b->xmap_hash;
+    if (a->height != b->height || a->xmap_hash != b->xmap_hash) return false;
+    // equal hashes are a hint, not a proof: the entries themselves decide (host copies kept by make_q4; ~K * 4 bytes per call)
+    return a->xmap_host.size() == b->xmap_host.size() &&
+           memcmp(a->xmap_host.data(), b->xmap_host.data(), a->xmap_host.size() * sizeof(uint32_t)) == 0;
 }
 
 // Runs the prologue of a fused prompt-pass launch (common.h: PromptPrologue) and points *x at the kernel's input.
@@ -1512,8 +1516,13 @@ int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
         // 0.397 / 0.405 / 0.423 ms without, 0.318 / 0.327 / 0.355 ms with (profiles/r03_tile128_validation.txt); validated by the
         // GEMM op tests and the cold-launch case t16m128k.  EXL_GEMM_NO_SPLITK=1 is the A/B switch.
         static const bool splitk = getenv("EXL_GEMM_NO_SPLITK") == nullptr;
-        if (splitk && rows > 256 && K % 256 == 0 && N % 4 == 0)
-            return launch_gemm_t16m<2, 2, 4, 4, 2>(w, xin, rows, out, no_zero, gshift, s);
+        if (splitk && rows > 256 && K % 256 == 0 && N % 4 == 0) {
+            // the slices live in the per-device workspace, grown on demand: when it cannot be had (a device packed to the weights),
+            // the unsplit kernel below computes the same product (its error message stays in exl_last_error for the curious)
+            float* probe = nullptr;
+            if (exl_gemm_workspace(w->device, (size_t) 2 * rows * N, &probe) == 0)
+                return launch_gemm_t16m<2, 2, 4, 4, 2>(w, xin, rows, out, no_zero, gshift, s);
+        }
         return launch_gemm_t16m<2, 2, 4, 4>(w, xin, rows, out, no_zero, gshift, s);                // 128 x 128, 4 waves
     }
     if (w->layout == EXL_LAYOUT_T16)

@@ -242,6 +242,10 @@ def _fold_act_order_down_proj(tensors, key):
             for j in range(8):
                 packed |= z[:, :, j].to(torch.int32) << (4 * j)
             qz.copy_(packed)
+    for proj in ("gate_proj", "up_proj"):                                # an output bias of a producer follows its columns
+        bk = f"{key}.{proj}.bias"
+        if bk in tensors and tensors[bk] is not None:
+            tensors[bk] = tensors[bk][x_map.to(tensors[bk].device)].contiguous()
     del tensors[gk]
     return x_map
 
@@ -698,7 +702,10 @@ class ExLlama:
         st = self._decoder
         if (st is not None and cache is st["cache"] and bsz == 1 and seq_len == 1 and lora is st.get("lora")
                 and input_mask is None and not preprocess_only and st["has_embed"] and st["has_head"]):
+            self._count_path(self._executor_tier(st))
             return self._decode_step(input_ids, cache, str(output_device))
+        if seq_len == 1:
+            self._count_path(self._op_tier(bsz))
         devs = cfg.device_map.get_layers_devs()
 
         buffer = ExLlamaBuffer(cfg)
@@ -779,6 +786,94 @@ class ExLlama:
         if cfg.tp is not None and self.lm_head_weight.shape[0] != cfg.vocab_size:      # this rank's vocabulary rows (tp.py): gather the rest
             logits = cfg.tp.all_gather_last(logits, cfg.tp.plan.vocab_sizes)
         return logits
+
+    # ---- which decode tier runs (and why not a faster one) --------------------------------------------------
+    DECODE_TIERS = {
+        "executor_graph": "native decode executor, one hipGraph replay per token and device (5 launches per layer + head; greedy argmax / "
+                          "sampler inside the graph through generate_greedy / generate_sample)",
+        "executor_eager": "native decode executor, eager launches (5 per layer + head)",
+        "executor_pieces_tp": "native decode executor in half-layer pieces, the residual stream all-reduced between them (tensor parallel)",
+        "ops_fused": "op by op: q4_attn -> attention -> q4_attn_2 -> q4_mlp per layer (the reference's fused decode ops, model.py:524-552)",
+        "ops_general": "op by op, general path: norm, q/k/v projections, RoPE, cache update, attention, o_proj, norm, gate/up, SiLU, down "
+                       "(batched generation, fused_attn off, or a tensor-parallel shard outside the executor)",
+    }
+
+    def _count_path(self, tier):
+        c = self.__dict__.setdefault("_path_counts", {})
+        c[tier] = c.get(tier, 0) + 1
+        self._last_path = tier
+
+    def _executor_tier(self, st):
+        if self.config.tp is not None:
+            return "executor_pieces_tp"
+        return "executor_graph" if st["graph"] is not None else "executor_eager"
+
+    def _op_tier(self, bsz):
+        cfg = self.config
+        if cfg.tp is None and cfg.fused_attn and bsz == 1:
+            return "ops_fused"
+        return "ops_general"
+
+    def executor_obstacles(self, batch_size=1, lora=None):
+        """Why enable_decode_graph() would refuse this model (empty list: it takes it).  The conditions are the executor's own
+        (csrc/decode_fused.hip: exl_decoder_create / exl_decoder_set_layer / exl_decoder_set_lora) and enable_decode_graph's."""
+        cfg, why = self.config, []
+        if batch_size != 1:
+            why.append(f"batch size {batch_size}: the executor handles batch 1 (batched generation runs op by op)")
+        if cfg.head_dim != 128:
+            why.append(f"head_dim {cfg.head_dim}: the executor's attention / RoPE kernels are written for 128")
+        if cfg.hidden_size % 128 or cfg.intermediate_size % 128:
+            why.append("hidden / intermediate size is not a multiple of 128")
+        if cfg.hidden_size > 8192 or cfg.intermediate_size > 32768:
+            why.append("hidden > 8192 or intermediate > 32768")
+        if any(not str(d).startswith("cuda") for d in cfg.device_map.layers):
+            why.append("a layer is not on a HIP device")
+        if cfg.tp is not None and any(l.self_attn.o_gather or l.mlp.down_gather for l in self.layers):
+            why.append("tensor parallel: act-order o_proj / down_proj shards (gather mode) run on the op-by-op path")
+        if lora is not None:
+            if cfg.tp is not None:
+                why.append("LoRA on a tensor-parallel shard")
+            for i, l in enumerate(self.layers):
+                if (l.self_attn.o_proj.lora_applies(lora) or l.mlp.down_proj.lora_applies(lora)) and \
+                        (l.self_attn.o_proj.g_idx is not None or l.mlp.down_proj.g_idx is not None):
+                    why.append(f"layer {i}: adapter on an act-order o_proj / unfolded act-order down_proj (their inputs are stored permuted)")
+                    break
+        return why
+
+    def decode_path_report(self, cache=None, batch_size=None, lora=None):
+        """Which tier a [batch_size, 1] forward on `cache` takes RIGHT NOW, what the tiers are, why a faster one is not in use,
+        and how many single-token forwards each tier has served since the model was built (reset_decode_path_counts()).  The
+        reference has one decode path per branch of model.py:524-552; this model has those plus the executor, and picks
+        silently -- this is where it says which."""
+        st = self._decoder
+        bsz = batch_size if batch_size is not None else (cache.batch_size if cache is not None else 1)
+        on_executor = (st is not None and (cache is None or cache is st["cache"]) and bsz == 1 and lora is st.get("lora")
+                       and st["has_embed"] and st["has_head"])
+        tier = self._executor_tier(st) if on_executor else self._op_tier(bsz)
+        why = []
+        if not on_executor:
+            obstacles = self.executor_obstacles(bsz, lora)
+            if obstacles:
+                why = obstacles
+            elif st is None:
+                why = ["enable_decode_graph(cache) has not been called"]
+            elif cache is not None and cache is not st["cache"]:
+                why = ["the executor was enabled for another cache"]
+            elif lora is not st.get("lora"):
+                why = ["the executor was enabled " + ("without this adapter" if lora is not None else "with an adapter")
+                       + ": enable_decode_graph(cache, lora=...)"]
+            elif not (st["has_embed"] and st["has_head"]):
+                why = ["this model is one link of a layer split: decode_stage_step() / pipeline.LayerSplitRunner"]
+        elif tier == "executor_eager":
+            why = ["enable_decode_graph(use_graph=False), or the token step could not be captured (process-group calls)"]
+        rep = {"tier": tier, "what": self.DECODE_TIERS[tier], "why_not_faster": why,
+               "executor_enabled": st is not None, "executor_stages": len(st["stages"]) if st is not None else 0,
+               "hop_captured": bool(st.get("hop_captured")) if st is not None else False,
+               "forwards_by_tier": dict(self.__dict__.get("_path_counts", {})), "last_forward_tier": self.__dict__.get("_last_path")}
+        return rep
+
+    def reset_decode_path_counts(self):
+        self._path_counts, self._last_path = {}, None
 
     # ---- native decode executor + hipGraph ---------------------------------------------------------------
     def _decode_stages(self):

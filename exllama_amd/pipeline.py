@@ -46,6 +46,50 @@ def stage_tensors(tensors, first, last):
     return out
 
 
+class HostStagedGroup:
+    """A `torch.distributed`-shaped object for process groups whose backend cannot move DEVICE tensors point to point (gloo:
+    only broadcast / all_reduce take them): every call stages through pinned-size host copies -- device -> host (which drains
+    the stream the kernels ran on), the backend's own call on the host tensor, host -> device.  StageHop, LayerSplitRunner and
+    exllama_amd.tp.TensorParallel take it wherever they take `torch.distributed`; results are the backend's (gloo adds fp16
+    all-reduce operands pairwise in fp16, like RCCL's ring).  With backend "nccl" (= RCCL) use `torch.distributed` itself: the
+    transfers then are stream-ordered device kernels and can be captured into the rank's hipGraph -- these calls cannot
+    (capture_hop=False / eager token steps).  This is what lets N processes share ONE GPU in tests/test_multiproc_gpu.py
+    (RCCL refuses two ranks on one device) and what a box without a working RCCL falls back to."""
+
+    def __init__(self, dist, group=None):
+        self.dist, self.group = dist, group
+        self.ReduceOp = dist.ReduceOp
+
+    def get_rank(self): return self.dist.get_rank(self.group)
+    def get_world_size(self): return self.dist.get_world_size(self.group)
+    def get_backend(self): return self.dist.get_backend(self.group) + " (host-staged)"
+    def barrier(self): return self.dist.barrier(group=self.group)
+
+    def send(self, t, dst):
+        self.dist.send(t.detach().to("cpu"), dst=dst, group=self.group)
+
+    def recv(self, t, src):
+        h = torch.empty(t.shape, dtype=t.dtype, device="cpu")
+        self.dist.recv(h, src=src, group=self.group)
+        t.copy_(h)
+
+    def broadcast(self, t, src):
+        h = t.detach().to("cpu")
+        self.dist.broadcast(h, src=src, group=self.group)
+        t.copy_(h)
+
+    def all_reduce(self, t, op=None, group=None):
+        h = t.detach().to("cpu")
+        self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM if op is None else op, group=self.group)
+        t.copy_(h)
+
+    def all_gather(self, parts, t, group=None):
+        hs = [torch.empty(p.shape, dtype=p.dtype, device="cpu") for p in parts]
+        self.dist.all_gather(hs, t.detach().to("cpu").contiguous(), group=self.group)
+        for p, h in zip(parts, hs):
+            p.copy_(h)
+
+
 class StageHop:
     """This rank's point-to-point exchanges of ONE token step of a layer split, issued on the executor's own device buffers
     (ExLlama.decode_hop_buffers): before() ahead of the first stage's kernels, after() behind the last stage's.

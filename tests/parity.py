@@ -114,3 +114,69 @@ def _model_close(got, ref, tol, tag=""):
     assert err <= tol * scale, (tag, err, scale)
     assert rel <= tol / 2, (tag, "rms(diff) / rms(ref)", rel)
     assert worst_block <= 4 * tol, (tag, "16-element block", worst_block)
+
+
+def perplexity_three_ways(dims, layers, groupsize, act_order, tokens=1536, seed=17, head_scale=4.6, ckpt_seed=23, device="cuda:0", log=None):
+    """north_star: "perplexity equal to 2 dp" (the reference prints 4 decimals, perplexity.py:121-138; README.md:139-148 quotes 2).
+    One synthetic checkpoint of `layers` layers of `dims`, its head sharpened by `head_scale` so that the model's own text scores in
+    the README's range; `tokens` tokens SAMPLED from the model's next-token distribution (HIP decode path); then the perplexity of
+    that text three ways: HIP whole-chunk path (MFMA GEMMs + flash attention), HIP token-by-token path (decode kernels), CPU oracle
+    (oracle/model_oracle.py, all `layers` layers).  Returns a record with the three values, their 2-dp strings, the per-token
+    negative log-likelihood spread of the oracle and the standard error of its perplexity estimate (the yardstick for |delta|)."""
+    import time
+    import torch
+    from exllama_amd import synth
+    from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
+    from exllama_amd.perplexity import Perplexity
+    from oracle.model_oracle import OracleLlama
+    say = log or (lambda *a: None)
+    t0 = time.time()
+    tensors = synth.make_checkpoint(dims, groupsize=groupsize, act_order=act_order, seed=ckpt_seed, device="cpu", zeros="rand", num_layers=layers)
+    tensors["lm_head.weight"] = (tensors["lm_head.weight"].float() * head_scale).half()
+    cfg = ExLlamaConfig(synth.config_dict(dims, layers))
+    cfg.max_seq_len = tokens + 64
+    cfg.max_input_len = 2048
+    model = ExLlama(cfg, tensors={k: v.clone() for k, v in tensors.items()})
+    say(f"checkpoint + model: {time.time() - t0:.1f} s")
+    gen = torch.Generator().manual_seed(seed)
+    cache = ExLlamaCache(model)
+    seq = torch.randint(1, dims.vocab_size, (4,), generator=gen).tolist()
+    lg = model.forward(torch.tensor([seq], device=device), cache)
+    if dims.head_dim == 128:
+        model.enable_decode_graph(cache)                              # the sampling loop on the executor's graph
+    while len(seq) < tokens:
+        nxt = int(torch.multinomial(torch.softmax(lg[0, -1].float().cpu(), -1), 1, generator=gen))
+        seq.append(nxt)
+        lg = model.forward(torch.tensor([[nxt]], device=device), cache)
+    sampled_on = model.decode_path_report(cache)["tier"]
+    model.disable_decode_graph()
+    ids = torch.tensor([seq])
+    p = Perplexity(model=model, cache=ExLlamaCache(model))
+    p.add_tokens(ids.to(device), chunk_size=tokens, overlap=0)
+    whole = p.test(quiet=True)
+    token = p.test(quiet=True, ppl_token=True)
+    say(f"HIP whole {whole:.4f} token {token:.4f}: {time.time() - t0:.1f} s")
+    model.free_unmanaged()
+    del model, cache, p
+    torch.cuda.empty_cache()
+    t1 = time.time()
+    orc = OracleLlama(synth.config_dict(dims, layers), tensors, max_seq_len=cfg.max_seq_len)
+    orc.prepare()
+    lgo = torch.from_numpy(np.asarray(orc.forward(ids[:, :-1].numpy(), last_id_only=False), dtype=np.float32))
+    nll = -torch.log_softmax(lgo, dim=-1).gather(-1, ids[:, 1:].unsqueeze(-1)).view(-1).double()
+    n = int(nll.numel())
+    ref = math.exp(float(nll.mean()))
+    se = ref * float(nll.std()) / math.sqrt(n)                        # delta method: d exp(m) = exp(m) dm
+    say(f"oracle {ref:.4f} ({time.time() - t1:.1f} s)")
+    nearest_boundary = abs((ref * 100) % 1.0 - 0.5) / 100             # distance of the oracle's value from a x.xx5 rounding boundary
+    rec = {"tag": "perplexity whole / token / oracle, full depth", "layers": layers, "hidden": dims.hidden_size, "groupsize": groupsize,
+           "act_order": act_order, "tokens": n, "seed": seed, "head_scale": head_scale, "text_sampled_on": sampled_on,
+           "values": [whole, token, ref], "two_dp": [f"{whole:.2f}", f"{token:.2f}", f"{ref:.2f}"],
+           "delta_whole": whole - ref, "delta_token": token - ref,
+           "oracle_nll_std": float(nll.std()), "oracle_standard_error": se,
+           "delta_whole_over_standard_error": abs(whole - ref) / se,
+           "oracle_distance_to_rounding_boundary": nearest_boundary,
+           "equal_to_2dp": f"{whole:.2f}" == f"{ref:.2f}",
+           "boundary_straddled": f"{whole:.2f}" != f"{ref:.2f}" and abs(whole - ref) < 0.005,
+           "oracle_seconds": round(time.time() - t1, 1)}
+    return rec

@@ -414,3 +414,55 @@ def test_bench_per_rank_report_single_process():
     assert info["rccl_ranks"] == 0 and info["backend"] is None
     assert info["per_rank"] == [{"rank": 0, "a_ms": 1.5, "b_ms": 2.25}]
     assert bench.reduce_over_ranks([3.0, 4.0], None, "cpu") == [3.0, 4.0]
+
+
+# ---- bench.py: the sub-runs that put every quoted number into the one JSON line (other configs, drop-in, sharded modes) ------
+def test_bench_sub_run_plumbing(tmp_path, monkeypatch):
+    import json
+    import sys
+    import bench
+    assert bench._last_json_line('noise\n{"a": 1}\n{"value": 2, "config": {}}\nRCCL banner') == {"value": 2, "config": {}}
+    assert bench._last_json_line("nothing here") is None
+    line = {"value": 402.5, "unit": "tokens/s", "prefill_tokens_per_s": 40125.1, "config": {"workload": "Llama-13B ...", "decode_mode": "hipGraph replay"},
+            "path_roofline": {"decode_worst": {"frac_of_8TBps": 0.43}}, "roofline": {"kernel": "k", "frac": 0.5, "achieved": 4000.0, "classes": {}},
+            "device_state": {"x": 1}}
+    rec = bench._sub_record(line, 12.34, None, "BASELINE configs[2]")
+    assert rec["value"] == 402.5 and rec["workload"] == "Llama-13B ..." and rec["measured"].startswith("this run")
+    assert rec["roofline"] == {"kernel": "k", "achieved": 4000.0, "frac": 0.5} and "device_state" not in rec
+    assert bench._sub_record(None, 900.0, "timed out after 900 s", "x") == {"what": "x", "error": "timed out after 900 s", "seconds": 900.0}
+    # a sub-run that prints no JSON line, exits non-zero or outlives its limit is an error record, never an exception
+    d, secs, err = bench._run_sub([sys.executable, "-c", "print('no json')"], 30)
+    assert d is None and "rc 0" in err
+    d, secs, err = bench._run_sub([sys.executable, "-c", "import sys; print('{\"value\": 1}'); sys.exit(3)"], 30)
+    assert d is None and "rc 3" in err
+    d, secs, err = bench._run_sub([sys.executable, "-c", "import time; time.sleep(30)"], 1)
+    assert d is None and "timed out" in err
+    d, secs, err = bench._run_sub([sys.executable, "-c", "print('{\"value\": 7, \"config\": {}}')"], 30)
+    assert d == {"value": 7, "config": {}} and err is None
+    # the sharded sub-runs: one torch.distributed.run job per mode over the same N GPUs, fresh port, the parent's rank variables dropped
+    seen = []
+
+    def fake(cmd, limit_s, env=None):
+        seen.append((cmd, env))
+        return {"value": 1.0, "config": {"workload": "w", "parallelism": "p"}, "n_gpus": 2, "rccl_ranks": 2}, 1.0, None
+    monkeypatch.setattr(bench, "_run_sub", fake)
+    monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("LOCAL_RANK", "0"); monkeypatch.setenv("MASTER_PORT", "1")
+    out = bench.sharded_runs(2)
+    assert set(out) == {"layer_split_65b", "layer_split_33b_g32_actorder", "layer_split_7b", "tensor_parallel_7b"}
+    assert set(bench.sharded_runs(8)) == {"layer_split_65b", "layer_split_7b", "tensor_parallel_7b"}
+    ports = set()
+    for cmd, env in seen[:4]:
+        assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "--brief" in cmd
+        assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+        ports.add(cmd[cmd.index("--master-port") + 1])
+        assert not ({"RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"} & set(env))
+        assert ("--layer-split" in cmd) != ("--tensor-parallel" in cmd)
+    assert out["layer_split_65b"]["rccl_ranks"] == 2 and out["tensor_parallel_7b"]["decode_mode"] == "p"
+    # the PMC traffic file: newest round wins, its own stamp is quoted
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (tmp_path / "profiles").mkdir()
+    assert bench.newest_pmc_profile() == (None, None)
+    (tmp_path / "profiles" / "r04_pmc_traffic.json").write_text(json.dumps({"decode_classes": {}, "round": 4}))
+    (tmp_path / "profiles" / "r11_pmc_traffic.json").write_text(json.dumps({"decode_classes": {}, "round": 11, "git_head": "abc1234", "collected": "2026-09-23"}))
+    d, src = bench.newest_pmc_profile()
+    assert d["round"] == 11 and "r11_pmc_traffic.json" in src and "abc1234" in src and "2026-09-23" in src

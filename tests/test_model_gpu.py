@@ -863,3 +863,134 @@ def test_executor_refuses_an_adapter_on_an_act_order_o_proj():
     model.disable_decode_graph()
     assert torch.isfinite(model.forward(ids, cache, lora=lora)).all()       # the op path takes it
     model.free_unmanaged()
+
+
+# ---- which decode tier ran (ExLlama.decode_path_report): one test per tier and per fallback, each with oracle parity ---------
+def test_decode_path_report_follows_the_executor_on_and_off():
+    """forward() picks its single-token path silently (graph replay / eager executor / fused ops): the report names the tier a
+    forward would take now, why a faster one is not in use, and counts the forwards each tier served."""
+    from exllama_amd.model import ExLlamaCache
+    model, cache, tensors, dims = _build("tiny_hd128", 128, False, seed=9, max_seq_len=96)
+    ids = torch.randint(1, dims.vocab_size, (1, 12), generator=torch.Generator().manual_seed(3)).to("cuda:0")
+    tok = torch.tensor([[5]], device="cuda:0")
+    assert model.executor_obstacles() == []
+    rep = model.decode_path_report(cache)
+    assert rep["tier"] == "ops_fused" and rep["why_not_faster"] == ["enable_decode_graph(cache) has not been called"], rep
+    model.forward(ids, cache)                                          # a prompt is not a decode step: not counted
+    assert model.decode_path_report(cache)["forwards_by_tier"] == {}
+    model.forward(tok, cache)
+    model.enable_decode_graph(cache)
+    rep = model.decode_path_report(cache)
+    assert rep["tier"] == "executor_graph" and rep["why_not_faster"] == [] and rep["executor_stages"] == 1, rep
+    model.forward(tok, cache); model.forward(tok, cache)
+    other = ExLlamaCache(model)
+    assert model.decode_path_report(other)["why_not_faster"] == ["the executor was enabled for another cache"]
+    model.forward(ids, other); model.forward(tok, other)               # ... and really runs op by op
+    model.enable_decode_graph(cache, use_graph=False)
+    assert model.decode_path_report(cache)["tier"] == "executor_eager"
+    model.forward(tok, cache)
+    rep = model.decode_path_report(cache)
+    assert rep["forwards_by_tier"] == {"ops_fused": 2, "executor_graph": 2, "executor_eager": 1} and rep["last_forward_tier"] == "executor_eager", rep
+    model.reset_decode_path_counts()
+    assert model.decode_path_report(cache)["forwards_by_tier"] == {}
+    assert set(model.DECODE_TIERS) >= {rep["tier"], "ops_general", "executor_pieces_tp"}
+    model.free_unmanaged()
+
+
+def test_head_dim_100_falls_to_the_fused_ops_and_says_so():
+    """OpenLLaMA-3B's geometry (hidden 3200, 32 heads of 100, intermediate 8640: the reference benchmarks it, README.md:33-41): the
+    executor's kernels are written for head_dim 128, so enable_decode_graph refuses and decode runs the reference's op sequence
+    (q4_attn -> attention -> q4_attn_2 -> q4_mlp).  The report says which tier and why; the tier is held to the oracle."""
+    from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
+    dims = synth.LlamaDims(3200, 8640, 2, 32, vocab_size=640)
+    assert dims.head_dim == 100
+    tensors = synth.make_checkpoint(dims, groupsize=64, act_order=False, seed=13, device="cpu", zeros="rand")
+    cfg = ExLlamaConfig(synth.config_dict(dims))
+    cfg.max_seq_len = cfg.max_input_len = 64
+    model = ExLlama(cfg, tensors={k: v.clone() for k, v in tensors.items()})
+    cache = ExLlamaCache(model)
+    why = model.executor_obstacles()
+    assert any("head_dim 100" in w for w in why) and any("multiple of 128" in w for w in why), why
+    with pytest.raises(RuntimeError):
+        model.enable_decode_graph(cache)
+    rep = model.decode_path_report(cache)
+    assert rep["tier"] == "ops_fused" and rep["why_not_faster"] == why and not rep["executor_enabled"], rep
+    S, n = 23, 5
+    ids = torch.randint(1, dims.vocab_size, (1, S), generator=torch.Generator().manual_seed(8))
+    lg = model.forward(ids.to("cuda:0"), cache, last_id_only=False).float().cpu().numpy()
+    ref = OracleLlama(synth.config_dict(dims), tensors, max_seq_len=64)
+    _model_close(lg, np.asarray(ref.forward(ids.numpy(), last_id_only=False), dtype=np.float32), ORACLE_TOL, "hd 100 prompt vs oracle")
+    toks, got = [int(lg[0, -1].argmax())], []
+    for i in range(n):
+        step = model.forward(torch.tensor([[toks[-1]]], device="cuda:0"), cache).float().cpu().numpy()[0, 0]
+        got.append(step)
+        toks.append(int(step.argmax()))
+    assert model.decode_path_report(cache)["forwards_by_tier"] == {"ops_fused": n}
+    for l in range(dims.num_hidden_layers):                           # the steps in isolation, from the rows the GPU's prompt pass wrote
+        ref.kc[l][0, :, :S] = cache.key_states[l][0, :, :S].cpu().numpy()
+        ref.vc[l][0, :, :S] = cache.value_states[l][0, :, :S].cpu().numpy()
+    _, runs, truth = _oracle_steps(ref, toks[:n], S)
+    for i in range(n):
+        _truth_close(got[i], runs, truth, i, f"hd 100 fused ops vs truth, step {i}")
+    model.free_unmanaged()
+
+
+def test_batched_decode_runs_the_general_ops_and_says_so():
+    """Batch 2, one token per row (what the reference's generator does with a batched cache, generator.py:344-381 on
+    ExLlamaCache(batch_size=2)): the executor handles batch 1, the fused ops need rows == 1, so this runs the general op
+    sequence.  Reported as such, and equal to the oracle's batched forward."""
+    from exllama_amd.model import ExLlamaCache
+    model, cache1, tensors, dims = _build("tiny_hd128", 128, "gptq", seed=15, max_seq_len=96)
+    model.enable_decode_graph(cache1)                                 # an executor on ANOTHER cache does not catch the batched one
+    cache = ExLlamaCache(model, batch_size=2)
+    rep = model.decode_path_report(cache)
+    assert rep["tier"] == "ops_general" and any("batch size 2" in w for w in rep["why_not_faster"]), rep
+    with pytest.raises(RuntimeError):
+        model.enable_decode_graph(cache)
+    model.enable_decode_graph(cache1)
+    S, n = 19, 4
+    ids = torch.randint(1, dims.vocab_size, (2, S), generator=torch.Generator().manual_seed(6))
+    lg = model.forward(ids.to("cuda:0"), cache, last_id_only=False).float().cpu().numpy()
+    ref = OracleLlama(synth.config_dict(dims), tensors, max_seq_len=96)
+    ref.reset(bsz=2)
+    _model_close(lg, np.asarray(ref.forward(ids.numpy(), last_id_only=False), dtype=np.float32), ORACLE_TOL, "batch 2 prompt vs oracle")
+    tok = lg[:, -1].argmax(-1).reshape(2, 1)
+    for i in range(n):
+        step = model.forward(torch.from_numpy(tok).to("cuda:0"), cache).float().cpu().numpy()
+        want = np.asarray(ref.forward(tok), dtype=np.float32)
+        _model_close(step, want, PATHS_TOL, f"batch 2 decode step {i} vs oracle")
+        tok = want[:, -1].argmax(-1).reshape(2, 1)                    # the oracle's choice drives both
+    assert model.decode_path_report(cache)["forwards_by_tier"] == {"ops_general": n}
+    assert cache.current_seq_len == S + n
+    model.free_unmanaged()
+
+
+def test_perplexity_full_depth_7b():
+    """north_star's accuracy bar at the depth it is stated for: ALL 32 layers of BASELINE configs[1] (7B g128), 1535 scored tokens of
+    the model's own sampled text, HIP whole-chunk path vs the CPU oracle over the same 32 layers (reference: perplexity.py:92-138;
+    README.md:139-148 quotes two decimals).  Asserted the way it is stated: the two numbers PRINT the same to 2 dp, and
+    |delta| < 0.005.  Should the oracle's value sit within |delta| of a x.xx5 rounding boundary, the strings can differ although
+    the values agree to 3 dp: that case is reported with both values (warning + stats record) and held to |delta| < 0.005 and
+    |delta| < 5 % of the standard error of the perplexity estimate itself (what 1535 tokens can resolve) -- the bound is not widened.
+    More texts and the 13B act-order model: scripts/ppl_full_depth.py -> profiles/r05_model_tolerance_stats.jsonl.
+    ~4 minutes (the oracle's prompt pass); EXL_SKIP_SLOW=1 skips it in quick local runs."""
+    if os.environ.get("EXL_SKIP_SLOW"):
+        pytest.skip("EXL_SKIP_SLOW set")
+    import warnings
+    from parity import perplexity_three_ways
+    rec = perplexity_three_ways(synth.PRESETS["7b"], 32, 128, False, tokens=1536, seed=17)
+    stats = os.environ.get("EXL_TOL_STATS")
+    if stats:
+        with open(stats, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    whole, token, ref = rec["values"]
+    assert rec["layers"] == 32 and rec["tokens"] == 1535
+    assert 3.0 < ref < 12.0, rec                                      # the README's range (5.68 .. 3.53) or just above it
+    assert abs(whole - ref) < 0.005, rec
+    if not rec["equal_to_2dp"]:
+        assert rec["oracle_distance_to_rounding_boundary"] <= abs(whole - ref), rec        # only a straddled boundary can do this
+        assert rec["delta_whole_over_standard_error"] < 0.05, rec
+        warnings.warn(f"perplexity straddles a rounding boundary: HIP {whole:.4f} vs oracle {ref:.4f} (standard error {rec['oracle_standard_error']:.3f})")
+    else:
+        assert f"{whole:.2f}" == f"{ref:.2f}"
+    assert abs(token - ref) < 0.02 and token < whole + 0.005, rec      # the path that sampled the text scores lowest (see the 2-layer test)

@@ -326,3 +326,57 @@ def test_layer_split_token_ring_generates_the_unsplit_models_tokens(world):
         assert steps == 1                                          # (the second executor was stepped once)
         if rank == world - 1:                                      # the chain step after the ring continues the same sequence
             assert int(lg[0, -1].argmax()) == want[5]
+
+
+# ---- pipeline.HostStagedGroup: the torch.distributed-shaped adapter the one-GPU multi-process tests (tests/test_multiproc_gpu.py)
+# and RCCL-less boxes use; here with host tensors on three ranks: every call it forwards, and the toy pipeline through it.
+def _staged_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from exllama_amd.pipeline import HostStagedGroup, LayerSplitRunner, split_layers
+    g = HostStagedGroup(dist)
+    assert g.get_rank() == rank and g.get_world_size() == world and g.get_backend().startswith("gloo")
+    t = torch.full((5,), float(rank + 1), dtype=torch.float16)
+    g.all_reduce(t)
+    parts = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+    g.all_gather(parts, torch.arange(3) + 10 * rank)
+    b = torch.tensor([[rank]], dtype=torch.int64)
+    g.broadcast(b, src=world - 1)
+    ring = torch.zeros(4, dtype=torch.float16)
+    if rank == 0:
+        g.send(torch.arange(4, dtype=torch.float16), dst=1)
+        g.recv(ring, src=world - 1)
+    else:
+        g.recv(ring, src=rank - 1)
+        g.send(ring + 1, dst=(rank + 1) % world)
+    m = torch.tensor([float(rank)], dtype=torch.float64)
+    g.all_reduce(m, op=g.ReduceOp.MAX)
+    first, last = split_layers(8, world)[rank]
+    runner = LayerSplitRunner(_ToyStage(first, last), None, g, 32, "cpu")
+    logits = runner.forward(torch.tensor([[3, 7, 11, 13]]))
+    tok = runner.next_token(logits)
+    g.barrier()
+    out.put((rank, t.tolist(), [p.tolist() for p in parts], int(b), ring.tolist(), float(m), int(tok)))
+    dist.destroy_process_group()
+
+
+def test_host_staged_group_forwards_every_call():
+    world = 3
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_staged_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(out.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full = _ToyStage(0, 8)
+    want_tok = int(full.head(full.forward_layers(full.embed(torch.tensor([[3, 7, 11, 13]])), None))[0, -1].argmax())
+    for rank, red, parts, b, ring, m, tok in got:
+        assert red == [6.0] * 5
+        assert parts == [[0, 1, 2], [10, 11, 12], [20, 21, 22]]
+        assert b == world - 1 and m == float(world - 1) and tok == want_tok
+        assert ring == [float(v + (world - 1 if rank == 0 else rank - 1)) for v in range(4)]
