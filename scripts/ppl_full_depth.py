@@ -28,15 +28,38 @@ def main():
     ap.add_argument("--seeds", default="17")
     ap.add_argument("--head-scale", type=float, default=4.6)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "ppl_full_depth.jsonl"))
+    ap.add_argument("--hip-only", metavar="DIR", default=None,
+                    help="GPU box: sample + score on the HIP paths only and leave <DIR>/ppl_<model>_<seed>.pt (record + token ids) for --oracle-from")
+    ap.add_argument("--oracle-from", metavar="DIR", default=None,
+                    help="any host, no GPU needed: finish the records a --hip-only run left in DIR with the CPU oracle's perplexity of the same texts")
     args = ap.parse_args()
     from exllama_amd import synth
-    from parity import perplexity_three_ways
+    import torch
+    from parity import perplexity_hip, perplexity_oracle, perplexity_three_ways
+    say = lambda *a: print(*a, flush=True)
+    os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+    if args.oracle_from:
+        import glob
+        for path in sorted(glob.glob(os.path.join(args.oracle_from, "ppl_*.pt"))):
+            blob = torch.load(path)
+            rec = perplexity_oracle(blob["rec"], blob["ids"], synth.PRESETS[blob["rec"]["model"]], log=say)
+            rec["oracle_host"] = "container CPU (the HIP half ran on the MI355X box: scripts/ppl_full_depth.py --hip-only)"
+            print(json.dumps(rec), flush=True)
+            with open(args.out, "a") as f:
+                f.write(json.dumps(rec) + "\n")
+        return
     dims = synth.PRESETS[args.model]
     L = dims.num_hidden_layers if args.layers is None else args.layers
-    os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+    act = "gptq" if args.act_order else False
     for seed in [int(s) for s in args.seeds.split(",")]:
-        rec = perplexity_three_ways(dims, L, args.groupsize, "gptq" if args.act_order else False, tokens=args.tokens, seed=seed,
-                                    head_scale=args.head_scale, log=lambda *a: print(*a, flush=True))
+        if args.hip_only:
+            os.makedirs(args.hip_only, exist_ok=True)
+            rec, ids = perplexity_hip(dims, L, args.groupsize, act, tokens=args.tokens, seed=seed, head_scale=args.head_scale, log=say)
+            rec["model"] = args.model
+            torch.save({"rec": rec, "ids": ids}, os.path.join(args.hip_only, f"ppl_{args.model}{'_act' if act else ''}_{seed}.pt"))
+            print(json.dumps(rec), flush=True)
+            continue
+        rec = perplexity_three_ways(dims, L, args.groupsize, act, tokens=args.tokens, seed=seed, head_scale=args.head_scale, log=say)
         rec["model"] = args.model
         print(json.dumps(rec), flush=True)
         with open(args.out, "a") as f:

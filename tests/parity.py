@@ -116,23 +116,25 @@ def _model_close(got, ref, tol, tag=""):
     assert worst_block <= 4 * tol, (tag, "16-element block", worst_block)
 
 
-def perplexity_three_ways(dims, layers, groupsize, act_order, tokens=1536, seed=17, head_scale=4.6, ckpt_seed=23, device="cuda:0", log=None):
-    """north_star: "perplexity equal to 2 dp" (the reference prints 4 decimals, perplexity.py:121-138; README.md:139-148 quotes 2).
-    One synthetic checkpoint of `layers` layers of `dims`, its head sharpened by `head_scale` so that the model's own text scores in
-    the README's range; `tokens` tokens SAMPLED from the model's next-token distribution (HIP decode path); then the perplexity of
-    that text three ways: HIP whole-chunk path (MFMA GEMMs + flash attention), HIP token-by-token path (decode kernels), CPU oracle
-    (oracle/model_oracle.py, all `layers` layers).  Returns a record with the three values, their 2-dp strings, the per-token
-    negative log-likelihood spread of the oracle and the standard error of its perplexity estimate (the yardstick for |delta|)."""
+def _ppl_checkpoint(dims, layers, groupsize, act_order, head_scale, ckpt_seed):
+    from exllama_amd import synth
+    tensors = synth.make_checkpoint(dims, groupsize=groupsize, act_order=act_order, seed=ckpt_seed, device="cpu", zeros="rand", num_layers=layers)
+    tensors["lm_head.weight"] = (tensors["lm_head.weight"].float() * head_scale).half()
+    return tensors
+
+
+def perplexity_hip(dims, layers, groupsize, act_order, tokens=1536, seed=17, head_scale=4.6, ckpt_seed=23, device="cuda:0", log=None, tensors=None):
+    """The HIP half of perplexity_three_ways: samples the text on the decode path and scores it on the whole-chunk and the
+    token-by-token path.  Returns (record, ids [1, tokens] LongTensor on the host)."""
     import time
     import torch
     from exllama_amd import synth
     from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
     from exllama_amd.perplexity import Perplexity
-    from oracle.model_oracle import OracleLlama
     say = log or (lambda *a: None)
     t0 = time.time()
-    tensors = synth.make_checkpoint(dims, groupsize=groupsize, act_order=act_order, seed=ckpt_seed, device="cpu", zeros="rand", num_layers=layers)
-    tensors["lm_head.weight"] = (tensors["lm_head.weight"].float() * head_scale).half()
+    if tensors is None:
+        tensors = _ppl_checkpoint(dims, layers, groupsize, act_order, head_scale, ckpt_seed)
     cfg = ExLlamaConfig(synth.config_dict(dims, layers))
     cfg.max_seq_len = tokens + 64
     cfg.max_input_len = 2048
@@ -159,24 +161,65 @@ def perplexity_three_ways(dims, layers, groupsize, act_order, tokens=1536, seed=
     model.free_unmanaged()
     del model, cache, p
     torch.cuda.empty_cache()
+    rec = {"tag": "perplexity whole / token / oracle, full depth", "layers": layers, "hidden": dims.hidden_size, "groupsize": groupsize,
+           "act_order": act_order, "tokens": tokens - 1, "seed": seed, "head_scale": head_scale, "ckpt_seed": ckpt_seed,
+           "text_sampled_on": sampled_on, "hip_whole": whole, "hip_token": token}
+    return rec, ids
+
+
+def perplexity_oracle(rec, ids, dims, log=None, tensors=None):
+    """The oracle half: the CPU oracle's perplexity of the same text over ALL layers (weights dequantised one layer at a time, so a
+    13B model needs a few GB of host memory, not 4 bytes per weight); completes and returns the record."""
+    import time
+    import torch
+    from exllama_amd import synth
+    from oracle import exl_oracle as O
+    from oracle.model_oracle import OracleLlama
+    say = log or (lambda *a: None)
+    layers = rec["layers"]
+    if tensors is None:
+        tensors = _ppl_checkpoint(dims, layers, rec["groupsize"], rec["act_order"], rec["head_scale"], rec["ckpt_seed"])
     t1 = time.time()
-    orc = OracleLlama(synth.config_dict(dims, layers), tensors, max_seq_len=cfg.max_seq_len)
-    orc.prepare()
-    lgo = torch.from_numpy(np.asarray(orc.forward(ids[:, :-1].numpy(), last_id_only=False), dtype=np.float32))
-    nll = -torch.log_softmax(lgo, dim=-1).gather(-1, ids[:, 1:].unsqueeze(-1)).view(-1).double()
+    orc = OracleLlama(synth.config_dict(dims, layers), tensors, max_seq_len=ids.shape[1] + 64)
+    x = ids[:, :-1].numpy()
+    hidden = orc.embed[x]
+    for i in range(orc.L):
+        lin = [orc.layers[i][k] for k in ("q", "k", "v", "o", "gate", "up", "down")]
+        for l in lin:
+            l.prepare()
+        hidden = orc.layer_forward(i, hidden)
+        for l in lin:
+            l.w32 = None
+        orc.kc[i] = orc.vc[i] = None                                   # (one pass: the rows are not needed again)
+        say(f"  oracle layer {i + 1}/{orc.L}: {time.time() - t1:.0f} s")
+    bsz, q, h = hidden.shape
+    hn = O.rms_norm(hidden.reshape(-1, h), orc.norm_w, orc.eps)        # the tail of OracleLlama.forward
+    lgo = (hn.astype(np.float32) @ orc.lm_head.astype(np.float32).T).astype(np.float16).astype(np.float32).reshape(bsz, q, -1)
+    nll = -torch.log_softmax(torch.from_numpy(lgo), dim=-1).gather(-1, ids[:, 1:].unsqueeze(-1)).view(-1).double()
     n = int(nll.numel())
     ref = math.exp(float(nll.mean()))
     se = ref * float(nll.std()) / math.sqrt(n)                        # delta method: d exp(m) = exp(m) dm
+    whole, token = rec["hip_whole"], rec["hip_token"]
     say(f"oracle {ref:.4f} ({time.time() - t1:.1f} s)")
-    nearest_boundary = abs((ref * 100) % 1.0 - 0.5) / 100             # distance of the oracle's value from a x.xx5 rounding boundary
-    rec = {"tag": "perplexity whole / token / oracle, full depth", "layers": layers, "hidden": dims.hidden_size, "groupsize": groupsize,
-           "act_order": act_order, "tokens": n, "seed": seed, "head_scale": head_scale, "text_sampled_on": sampled_on,
-           "values": [whole, token, ref], "two_dp": [f"{whole:.2f}", f"{token:.2f}", f"{ref:.2f}"],
-           "delta_whole": whole - ref, "delta_token": token - ref,
-           "oracle_nll_std": float(nll.std()), "oracle_standard_error": se,
-           "delta_whole_over_standard_error": abs(whole - ref) / se,
-           "oracle_distance_to_rounding_boundary": nearest_boundary,
-           "equal_to_2dp": f"{whole:.2f}" == f"{ref:.2f}",
-           "boundary_straddled": f"{whole:.2f}" != f"{ref:.2f}" and abs(whole - ref) < 0.005,
-           "oracle_seconds": round(time.time() - t1, 1)}
+    rec = dict(rec)
+    rec.update({"tokens": n, "values": [whole, token, ref], "two_dp": [f"{whole:.2f}", f"{token:.2f}", f"{ref:.2f}"],
+                "delta_whole": whole - ref, "delta_token": token - ref,
+                "oracle_nll_std": float(nll.std()), "oracle_standard_error": se,
+                "delta_whole_over_standard_error": abs(whole - ref) / se,
+                "oracle_distance_to_rounding_boundary": abs((ref * 100) % 1.0 - 0.5) / 100,   # from the nearest x.xx5
+                "equal_to_2dp": f"{whole:.2f}" == f"{ref:.2f}",
+                "boundary_straddled": f"{whole:.2f}" != f"{ref:.2f}" and abs(whole - ref) < 0.005,
+                "oracle_seconds": round(time.time() - t1, 1)})
     return rec
+
+
+def perplexity_three_ways(dims, layers, groupsize, act_order, tokens=1536, seed=17, head_scale=4.6, ckpt_seed=23, device="cuda:0", log=None):
+    """north_star: "perplexity equal to 2 dp" (the reference prints 4 decimals, perplexity.py:121-138; README.md:139-148 quotes 2).
+    One synthetic checkpoint of `layers` layers of `dims`, its head sharpened by `head_scale` so that the model's own text scores in
+    the README's range; `tokens` tokens SAMPLED from the model's next-token distribution (HIP decode path); then the perplexity of
+    that text three ways: HIP whole-chunk path (MFMA GEMMs + flash attention), HIP token-by-token path (decode kernels), CPU oracle
+    (oracle/model_oracle.py, all `layers` layers).  Returns a record with the three values, their 2-dp strings, the per-token
+    negative log-likelihood spread of the oracle and the standard error of its perplexity estimate (the yardstick for |delta|)."""
+    tensors = _ppl_checkpoint(dims, layers, groupsize, act_order, head_scale, ckpt_seed)
+    rec, ids = perplexity_hip(dims, layers, groupsize, act_order, tokens, seed, head_scale, ckpt_seed, device, log, tensors=tensors)
+    return perplexity_oracle(rec, ids, dims, log, tensors=tensors)

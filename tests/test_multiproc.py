@@ -104,7 +104,7 @@ def _pipe_worker(rank, world, port, out):
         toks.append(int(tok))
         logits = runner.forward(tok)
     if rank == world - 1:
-        out.put((toks, logits))
+        out.put((toks, logits.numpy()))              # by value: a torch tensor travels as a file descriptor the exiting worker may close first
     dist.barrier()
     dist.destroy_process_group()
 
@@ -136,7 +136,7 @@ def test_layer_split_matches_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got_toks == toks
-    assert torch.equal(got_logits, logits)
+    assert torch.equal(torch.from_numpy(got_logits), logits)
 
 
 # ---- the same split with CHECKPOINT-shaped stages: every rank builds its link from pipeline.stage_tensors() of a real GPTQ
@@ -197,7 +197,7 @@ def _oracle_pipe_worker(rank, world, port, out):
         toks.append(int(tok))
         logits = runner.forward(tok)
     if rank == world - 1:
-        out.put((toks, logits))
+        out.put((toks, logits.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -226,7 +226,7 @@ def test_layer_split_of_a_real_checkpoint_layout_matches_the_unsplit_model():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got_toks == toks
-    assert np.array_equal(got_logits.numpy(), logits)
+    assert np.array_equal(got_logits, logits)
 
 
 # ---- the executor-side hand-off (pipeline.StageHop) and the token ring of LayerSplitRunner.generate_greedy: every rank's single-token
@@ -292,7 +292,7 @@ def _ring_worker(rank, world, port, out):
     # the plain chain through the executor stages (no ring): the hidden state arrives through the hop, the token from the host
     runner.enable_decode_executor(use_graph=False, token_ring=False)
     lg = runner.forward(toks[-1].view(1, 1))
-    out.put((rank, int(tok), toks.tolist(), again, stage.steps, None if lg is None else lg.clone()))
+    out.put((rank, int(tok), toks.tolist(), again, stage.steps, None if lg is None else lg.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
