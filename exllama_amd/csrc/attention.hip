@@ -13,7 +13,12 @@
 #define ATT_THREADS 256
 #define ATT_MAX_SPLIT_KEYS 1024
 
-template <int LPK>   // lanes per key row = head_dim / 8 rounded up to a power of two (8, 16, 32)
+// VW: halves per lane and access -- 8 (16-byte loads) where head_dim % 8 == 0, else 4 (head_dim % 4 == 0: OpenLLaMA-3B's 100, whose
+// rows are only 8-byte aligned)
+template <int VW> struct AttVec;
+template <> struct AttVec<8> { typedef f16x8 T; };
+template <> struct AttVec<4> { typedef f16x4 T; };
+template <int LPK, int VW = 8>   // lanes per key row = head_dim / VW rounded up to a power of two (8, 16, 32, 64)
 __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(
     const f16* __restrict__ q, const f16* __restrict__ kc, const f16* __restrict__ vc, const f16* __restrict__ mask,
     float* __restrict__ partial, f16* __restrict__ out, int q_len, int heads, int kv_heads, int hd, int max_seq,
@@ -21,7 +26,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(
 {
     constexpr int KPI = ATT_THREADS / LPK;                    // keys per block iteration
     __shared__ float sc[ATT_MAX_SPLIT_KEYS];
-    __shared__ float red[KPI][8 * LPK + 1];
+    __shared__ float red[KPI][VW * LPK + 1];
+    typedef typename AttVec<VW>::T vec_t;
     __shared__ float stat[8];
 
     const int split = blockIdx.x;
@@ -41,18 +47,18 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(
     const int tid = threadIdx.x;
     const int d8 = tid % LPK;
     const int ks = tid / LPK;
-    const bool d_ok = d8 * 8 < hd;
+    const bool d_ok = d8 * VW < hd;
     const int kvh = h / (heads / kv_heads);
-    const f16* kbase = kc + (((size_t) b * kv_heads + kvh) * max_seq) * hd + d8 * 8;
-    const f16* vbase = vc + (((size_t) b * kv_heads + kvh) * max_seq) * hd + d8 * 8;
+    const f16* kbase = kc + (((size_t) b * kv_heads + kvh) * max_seq) * hd + d8 * VW;
+    const f16* vbase = vc + (((size_t) b * kv_heads + kvh) * max_seq) * hd + d8 * VW;
     const f16* mrow = mask ? mask + ((size_t) b * q_len + qi) * kv_len : nullptr;
 
-    float qf[8];
+    float qf[VW];
     {
-        f16x8 qv = {};
-        if (d_ok) qv = *(const f16x8*) (q + ((size_t) bq * heads + h) * hd + d8 * 8);
+        vec_t qv = {};
+        if (d_ok) qv = *(const vec_t*) (q + ((size_t) bq * heads + h) * hd + d8 * VW);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[j] = (float) qv[j] * scale;
+        for (int j = 0; j < VW; ++j) qf[j] = (float) qv[j] * scale;
     }
 
     // ---- pass 1: scores -> LDS, block max ---------------------------------------------------------
@@ -61,9 +67,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(
         const int j = j0 + ks;
         float dot = 0.f;
         if (j < nkeys && d_ok) {
-            const f16x8 kv = *(const f16x8*) (kbase + (size_t) (s0 + j) * hd);
+            const vec_t kv = *(const vec_t*) (kbase + (size_t) (s0 + j) * hd);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) dot = fmaf(qf[e], (float) kv[e], dot);
+            for (int e = 0; e < VW; ++e) dot = fmaf(qf[e], (float) kv[e], dot);
         }
 #pragma unroll
         for (int off = 1; off < LPK; off <<= 1) dot += __shfl_xor(dot, off, 64);
@@ -94,19 +100,19 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_kernel(
     lsum = stat[4] + stat[5] + stat[6] + stat[7];
 
     // ---- pass 3: o[d] = sum_j p_j * v[j][d] -------------------------------------------------------------
-    float o[8];
+    float o[VW];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    for (int e = 0; e < VW; ++e) o[e] = 0.f;
     if (d_ok) {
         for (int j = ks; j < nkeys; j += KPI) {
-            const f16x8 vv = *(const f16x8*) (vbase + (size_t) (s0 + j) * hd);
+            const vec_t vv = *(const vec_t*) (vbase + (size_t) (s0 + j) * hd);
             const float p = sc[j];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = fmaf(p, (float) vv[e], o[e]);
+            for (int e = 0; e < VW; ++e) o[e] = fmaf(p, (float) vv[e], o[e]);
         }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[ks][d8 * 8 + e] = o[e];
+    for (int e = 0; e < VW; ++e) red[ks][d8 * VW + e] = o[e];
     __syncthreads();
     for (int d = tid; d < hd; d += ATT_THREADS) {
         float v = 0.f;
@@ -155,7 +161,7 @@ int launch_attention(const f16* q, const f16* kc, const f16* vc, f16* out, const
                      float* ws, size_t ws_floats, hipStream_t s)
 {
     if (bsz <= 0 || q_len <= 0) return 0;
-    EXL_REQUIRE(hd % 8 == 0 && hd <= 256, EXL_E_UNSUPPORTED, "attention: head_dim (%d) must be a multiple of 8, <= 256", hd);
+    EXL_REQUIRE(hd % 4 == 0 && hd > 0 && hd <= 256, EXL_E_UNSUPPORTED, "attention: head_dim (%d) must be a multiple of 4, <= 256", hd);
     EXL_REQUIRE(kv_heads > 0 && heads % kv_heads == 0, EXL_E_INVALID, "attention: heads (%d) %% kv_heads (%d) != 0", heads, kv_heads);
     EXL_REQUIRE(past_len + q_len <= max_seq, EXL_E_INVALID, "attention: past_len + q_len (%d) exceeds max_seq_len (%d)",
                 past_len + q_len, max_seq);
@@ -188,12 +194,19 @@ int launch_attention(const f16* q, const f16* kc, const f16* vc, f16* out, const
     }
     if (chunk > 65535) chunk = 65535;                             // gridDim.z limit
     const float scale = 1.0f / sqrtf((float) hd);
-    const int lpk = hd <= 64 ? 8 : hd <= 128 ? 16 : 32;
+    const bool narrow = hd % 8 != 0;                                 // 8-byte accesses (VW = 4)
+    const int lanes = narrow ? hd / 4 : hd / 8;
+    const int lpk = lanes <= 8 ? 8 : lanes <= 16 ? 16 : lanes <= 32 ? 32 : 64;
     for (int r0 = 0; r0 < total_rows; r0 += chunk) {
         const int nr = total_rows - r0 < chunk ? total_rows - r0 : chunk;
         dim3 grid(nsplit, heads, nr);
 #define ATT_ARGS q, kc, vc, mask, partial, out, q_len, heads, kv_heads, hd, max_seq, past_len, past_len_dev, nsplit, scale, r0
-        if (lpk == 8)       hipLaunchKernelGGL(attn_decode_kernel<8>,  grid, dim3(ATT_THREADS), 0, s, ATT_ARGS);
+        if (narrow) {
+            if (lpk <= 16)      hipLaunchKernelGGL((attn_decode_kernel<16, 4>), grid, dim3(ATT_THREADS), 0, s, ATT_ARGS);
+            else if (lpk == 32) hipLaunchKernelGGL((attn_decode_kernel<32, 4>), grid, dim3(ATT_THREADS), 0, s, ATT_ARGS);
+            else                hipLaunchKernelGGL((attn_decode_kernel<64, 4>), grid, dim3(ATT_THREADS), 0, s, ATT_ARGS);
+        }
+        else if (lpk == 8)  hipLaunchKernelGGL(attn_decode_kernel<8>,  grid, dim3(ATT_THREADS), 0, s, ATT_ARGS);
         else if (lpk == 16) hipLaunchKernelGGL(attn_decode_kernel<16>, grid, dim3(ATT_THREADS), 0, s, ATT_ARGS);
         else                hipLaunchKernelGGL(attn_decode_kernel<32>, grid, dim3(ATT_THREADS), 0, s, ATT_ARGS);
 #undef ATT_ARGS

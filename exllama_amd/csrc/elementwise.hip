@@ -195,13 +195,44 @@ __global__ __launch_bounds__(256) void rope_kernel(f16* __restrict__ x, const f1
     *(f16x8*) (xp + hd2) = nr;
 }
 
+// Any even head_dim (OpenLLaMA-3B: 100 -- the reference's rope.cu:27-87 takes any even width): one thread = ONE pair (l, r), the same
+// arithmetic; 2-byte accesses, used only where the 16-byte form above cannot be (head_dim % 16 != 0).
+__global__ __launch_bounds__(256) void rope_pair_kernel(f16* __restrict__ x, const f16* __restrict__ sin, const f16* __restrict__ cos,
+                                                        int rows_per_batch, int head_dim, int num_heads, int past_len,
+                                                        const int32_t* __restrict__ past_len_dev, long total)
+{
+    const long gid = (long) blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int hd2 = head_dim >> 1;
+    const long grow = gid / hd2;
+    const int i = (int) (gid - grow * hd2);
+    const int row = (int) (grow % rows_per_batch);
+    const int past = past_len_dev ? *past_len_dev : past_len;
+    const int pos = past + row / num_heads;
+    f16* xp = x + (size_t) grow * head_dim;
+    const f16* sp = sin + (size_t) pos * head_dim;
+    const f16* cp = cos + (size_t) pos * head_dim;
+    const f16 l = xp[i], r = xp[i + hd2];
+    const f16 ls = r * (-sp[i]);
+    const f16 rs = l * sp[i + hd2];
+    xp[i] = __builtin_fmaf16(l, cp[i], ls);
+    xp[i + hd2] = __builtin_fmaf16(r, cp[i + hd2], rs);
+}
+
 int launch_rope(f16* x, const f16* sin, const f16* cos, int bsz, int rows_per_batch, int head_dim, int num_heads,
                 int past_len, const int32_t* past_len_dev, hipStream_t s)
 {
     const int total_rows = bsz * rows_per_batch;
     if (total_rows <= 0) return 0;
-    EXL_REQUIRE(head_dim % 16 == 0, EXL_E_UNSUPPORTED, "rope: head_dim (%d) must be a multiple of 16", head_dim);
+    EXL_REQUIRE(head_dim > 0 && head_dim % 2 == 0, EXL_E_UNSUPPORTED, "rope: head_dim (%d) must be even", head_dim);
     EXL_REQUIRE(num_heads > 0, EXL_E_INVALID, "rope: num_heads must be > 0");
+    if (head_dim % 16 != 0) {
+        const long pairs = (long) total_rows * (head_dim / 2);
+        hipLaunchKernelGGL(rope_pair_kernel, dim3((unsigned) ((pairs + 255) / 256)), dim3(256), 0, s, x, sin, cos, rows_per_batch,
+                           head_dim, num_heads, past_len, past_len_dev, pairs);
+        EXL_LAUNCH_CHECK();
+        return 0;
+    }
     const long total = (long) total_rows * (head_dim / 16);
     hipLaunchKernelGGL(rope_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, s, x, sin, cos, rows_per_batch,
                        head_dim, num_heads, past_len, past_len_dev, total_rows);
@@ -320,11 +351,19 @@ __global__ __launch_bounds__(256) void rope_qk_cache_kernel(f16* __restrict__ q,
     }
 }
 
+int launch_update_cache(const f16* k, const f16* v, f16* kc, f16* vc, int bsz, int q_len, int kvh, int hd,
+                        int max_seq, int past_len, const int32_t* past_len_dev, hipStream_t s);
+
 int launch_rope_qk_cache(f16* q, f16* k, const f16* v, f16* kc, f16* vc, const f16* sin, const f16* cos, int bsz, int q_len,
                          int heads, int kvh, int hd, int max_seq, int past_len, const int32_t* past_len_dev, hipStream_t s)
 {
-    EXL_REQUIRE(hd % 16 == 0, EXL_E_UNSUPPORTED, "rope: head_dim (%d) must be a multiple of 16", hd);
+    EXL_REQUIRE(hd > 0 && hd % 2 == 0, EXL_E_UNSUPPORTED, "rope: head_dim (%d) must be even", hd);
     EXL_REQUIRE(heads > 0 && kvh > 0, EXL_E_INVALID, "rope: num_heads must be > 0");
+    if (hd % 16 != 0) {                                               // the three reference steps (q4_attn.cu:160-204) with the any-width kernels
+        EXL_TRY(launch_rope(q, sin, cos, bsz, q_len * heads, hd, heads, past_len, past_len_dev, s));
+        EXL_TRY(launch_rope(k, sin, cos, bsz, q_len * kvh, hd, kvh, past_len, past_len_dev, s));
+        return launch_update_cache(k, v, kc, vc, bsz, q_len, kvh, hd, max_seq, past_len, past_len_dev, s);
+    }
     const long total = (long) bsz * q_len * (heads + kvh) * (hd / 16);
     if (total <= 0) return 0;
     hipLaunchKernelGGL(rope_qk_cache_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, s, q, k, v, kc, vc, sin, cos,
@@ -333,10 +372,37 @@ int launch_rope_qk_cache(f16* q, f16* k, const f16* v, f16* kc, f16* vc, const f
     return 0;
 }
 
+__global__ __launch_bounds__(256) void update_cache_pair_kernel(const f16* __restrict__ k, const f16* __restrict__ v, f16* __restrict__ kc,
+                                                                f16* __restrict__ vc, int q_len, int kvh, int hd, int max_seq, int past_len,
+                                                                const int32_t* __restrict__ past_len_dev, long total)
+{
+    const long gid = (long) blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int per_head = hd >> 1;
+    const int d2 = (int) (gid % per_head);
+    long rest = gid / per_head;
+    const int h = (int) (rest % kvh); rest /= kvh;
+    const int t = (int) (rest % q_len);
+    const int b = (int) (rest / q_len);
+    const int past = past_len_dev ? *past_len_dev : past_len;
+    const size_t src = (((size_t) b * q_len + t) * kvh + h) * hd + d2 * 2;
+    const size_t dst = (((size_t) b * kvh + h) * max_seq + (past + t)) * hd + d2 * 2;
+    *(uint32_t*) (kc + dst) = *(const uint32_t*) (k + src);
+    *(uint32_t*) (vc + dst) = *(const uint32_t*) (v + src);
+}
+
 int launch_update_cache(const f16* k, const f16* v, f16* kc, f16* vc, int bsz, int q_len, int kvh, int hd,
                         int max_seq, int past_len, const int32_t* past_len_dev, hipStream_t s)
 {
-    EXL_REQUIRE(hd % 8 == 0, EXL_E_UNSUPPORTED, "update_cache: head_dim (%d) must be a multiple of 8", hd);
+    EXL_REQUIRE(hd > 0 && hd % 2 == 0, EXL_E_UNSUPPORTED, "update_cache: head_dim (%d) must be even", hd);
+    if (hd % 8 != 0) {                                                // 4-byte copies (q4_attn.cu:19-72 copies element pairs too)
+        const long pairs = (long) bsz * q_len * kvh * (hd / 2);
+        if (pairs <= 0) return 0;
+        hipLaunchKernelGGL(update_cache_pair_kernel, dim3((unsigned) ((pairs + 255) / 256)), dim3(256), 0, s, k, v, kc, vc, q_len,
+                           kvh, hd, max_seq, past_len, past_len_dev, pairs);
+        EXL_LAUNCH_CHECK();
+        return 0;
+    }
     const long total = (long) bsz * q_len * kvh * (hd / 8);
     if (total <= 0) return 0;
     hipLaunchKernelGGL(update_cache_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, s, k, v, kc, vc, q_len,

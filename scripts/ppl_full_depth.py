@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=1536)
     ap.add_argument("--seeds", default="17")
     ap.add_argument("--head-scale", type=float, default=4.6)
+    ap.add_argument("--zeros", default="sym", choices=["sym", "rand"], help="stored zero points: symmetric (bench.py's models) or random per group and column")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "ppl_full_depth.jsonl"))
     ap.add_argument("--hip-only", metavar="DIR", default=None,
                     help="GPU box: sample + score on the HIP paths only and leave <DIR>/ppl_<model>_<seed>.pt (record + token ids) for --oracle-from")
@@ -54,12 +55,12 @@ def main():
     for seed in [int(s) for s in args.seeds.split(",")]:
         if args.hip_only:
             os.makedirs(args.hip_only, exist_ok=True)
-            rec, ids = perplexity_hip(dims, L, args.groupsize, act, tokens=args.tokens, seed=seed, head_scale=args.head_scale, log=say)
+            rec, ids = perplexity_hip(dims, L, args.groupsize, act, tokens=args.tokens, seed=seed, head_scale=args.head_scale, log=say, zeros=args.zeros)
             rec["model"] = args.model
             torch.save({"rec": rec, "ids": ids}, os.path.join(args.hip_only, f"ppl_{args.model}{'_act' if act else ''}_{seed}.pt"))
             print(json.dumps(rec), flush=True)
             continue
-        rec = perplexity_three_ways(dims, L, args.groupsize, act, tokens=args.tokens, seed=seed, head_scale=args.head_scale, log=say)
+        rec = perplexity_three_ways(dims, L, args.groupsize, act, tokens=args.tokens, seed=seed, head_scale=args.head_scale, log=say, zeros=args.zeros)
         rec["model"] = args.model
         print(json.dumps(rec), flush=True)
         with open(args.out, "a") as f:

@@ -116,14 +116,17 @@ def _model_close(got, ref, tol, tag=""):
     assert worst_block <= 4 * tol, (tag, "16-element block", worst_block)
 
 
-def _ppl_checkpoint(dims, layers, groupsize, act_order, head_scale, ckpt_seed):
+def _ppl_checkpoint(dims, layers, groupsize, act_order, head_scale, ckpt_seed, zeros="sym"):
+    """zeros: "sym" = every stored zero nibble 7, the symmetric-GPTQ norm and what bench.py's models carry (the
+    statistics that keep activations finite through all layers); "rand" = the stress variant of the short-model tests."""
     from exllama_amd import synth
-    tensors = synth.make_checkpoint(dims, groupsize=groupsize, act_order=act_order, seed=ckpt_seed, device="cpu", zeros="rand", num_layers=layers)
+    tensors = synth.make_checkpoint(dims, groupsize=groupsize, act_order=act_order, seed=ckpt_seed, device="cpu", zeros=zeros, num_layers=layers)
     tensors["lm_head.weight"] = (tensors["lm_head.weight"].float() * head_scale).half()
     return tensors
 
 
-def perplexity_hip(dims, layers, groupsize, act_order, tokens=1536, seed=17, head_scale=4.6, ckpt_seed=23, device="cuda:0", log=None, tensors=None):
+def perplexity_hip(dims, layers, groupsize, act_order, tokens=1536, seed=17, head_scale=4.6, ckpt_seed=23, device="cuda:0", log=None, tensors=None,
+                   zeros="sym"):
     """The HIP half of perplexity_three_ways: samples the text on the decode path and scores it on the whole-chunk and the
     token-by-token path.  Returns (record, ids [1, tokens] LongTensor on the host)."""
     import time
@@ -134,7 +137,7 @@ def perplexity_hip(dims, layers, groupsize, act_order, tokens=1536, seed=17, hea
     say = log or (lambda *a: None)
     t0 = time.time()
     if tensors is None:
-        tensors = _ppl_checkpoint(dims, layers, groupsize, act_order, head_scale, ckpt_seed)
+        tensors = _ppl_checkpoint(dims, layers, groupsize, act_order, head_scale, ckpt_seed, zeros)
     cfg = ExLlamaConfig(synth.config_dict(dims, layers))
     cfg.max_seq_len = tokens + 64
     cfg.max_input_len = 2048
@@ -144,6 +147,9 @@ def perplexity_hip(dims, layers, groupsize, act_order, tokens=1536, seed=17, hea
     cache = ExLlamaCache(model)
     seq = torch.randint(1, dims.vocab_size, (4,), generator=gen).tolist()
     lg = model.forward(torch.tensor([seq], device=device), cache)
+    if not bool(torch.isfinite(lg).all()):
+        raise RuntimeError(f"the synthetic model's logits are not finite after {len(seq)} tokens (zeros={zeros!r}, {layers} layers): "
+                           "its activations left the fp16 range -- not a checkpoint to measure perplexity on")
     if dims.head_dim == 128:
         model.enable_decode_graph(cache)                              # the sampling loop on the executor's graph
     while len(seq) < tokens:
@@ -162,7 +168,7 @@ def perplexity_hip(dims, layers, groupsize, act_order, tokens=1536, seed=17, hea
     del model, cache, p
     torch.cuda.empty_cache()
     rec = {"tag": "perplexity whole / token / oracle, full depth", "layers": layers, "hidden": dims.hidden_size, "groupsize": groupsize,
-           "act_order": act_order, "tokens": tokens - 1, "seed": seed, "head_scale": head_scale, "ckpt_seed": ckpt_seed,
+           "act_order": act_order, "tokens": tokens - 1, "seed": seed, "head_scale": head_scale, "ckpt_seed": ckpt_seed, "zeros": zeros,
            "text_sampled_on": sampled_on, "hip_whole": whole, "hip_token": token}
     return rec, ids
 
@@ -178,7 +184,7 @@ def perplexity_oracle(rec, ids, dims, log=None, tensors=None):
     say = log or (lambda *a: None)
     layers = rec["layers"]
     if tensors is None:
-        tensors = _ppl_checkpoint(dims, layers, rec["groupsize"], rec["act_order"], rec["head_scale"], rec["ckpt_seed"])
+        tensors = _ppl_checkpoint(dims, layers, rec["groupsize"], rec["act_order"], rec["head_scale"], rec["ckpt_seed"], rec.get("zeros", "sym"))
     t1 = time.time()
     orc = OracleLlama(synth.config_dict(dims, layers), tensors, max_seq_len=ids.shape[1] + 64)
     x = ids[:, :-1].numpy()
@@ -213,13 +219,14 @@ def perplexity_oracle(rec, ids, dims, log=None, tensors=None):
     return rec
 
 
-def perplexity_three_ways(dims, layers, groupsize, act_order, tokens=1536, seed=17, head_scale=4.6, ckpt_seed=23, device="cuda:0", log=None):
+def perplexity_three_ways(dims, layers, groupsize, act_order, tokens=1536, seed=17, head_scale=4.6, ckpt_seed=23, device="cuda:0", log=None,
+                          zeros="sym"):
     """north_star: "perplexity equal to 2 dp" (the reference prints 4 decimals, perplexity.py:121-138; README.md:139-148 quotes 2).
     One synthetic checkpoint of `layers` layers of `dims`, its head sharpened by `head_scale` so that the model's own text scores in
     the README's range; `tokens` tokens SAMPLED from the model's next-token distribution (HIP decode path); then the perplexity of
     that text three ways: HIP whole-chunk path (MFMA GEMMs + flash attention), HIP token-by-token path (decode kernels), CPU oracle
     (oracle/model_oracle.py, all `layers` layers).  Returns a record with the three values, their 2-dp strings, the per-token
     negative log-likelihood spread of the oracle and the standard error of its perplexity estimate (the yardstick for |delta|)."""
-    tensors = _ppl_checkpoint(dims, layers, groupsize, act_order, head_scale, ckpt_seed)
-    rec, ids = perplexity_hip(dims, layers, groupsize, act_order, tokens, seed, head_scale, ckpt_seed, device, log, tensors=tensors)
+    tensors = _ppl_checkpoint(dims, layers, groupsize, act_order, head_scale, ckpt_seed, zeros)
+    rec, ids = perplexity_hip(dims, layers, groupsize, act_order, tokens, seed, head_scale, ckpt_seed, device, log, tensors=tensors, zeros=zeros)
     return perplexity_oracle(rec, ids, dims, log, tensors=tensors)
