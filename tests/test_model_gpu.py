@@ -511,9 +511,9 @@ def test_native_decode_executor_at_real_layer_shapes(key):
     model.free_unmanaged()
 
 
-@pytest.mark.parametrize("name,gs,act,L", [("7b", 128, False, 2), ("13b", 128, True, 1), ("33b", 32, True, 1)])
+@pytest.mark.parametrize("name,gs,act,L", [("7b", 128, False, 2), ("13b", 128, True, 1), ("33b", 32, True, 1), ("65b", 128, False, 1)])
 def test_real_shape_prefill_end_to_end_vs_oracle(name, gs, act, L):
-    """BASELINE configs[1] / [2] / [3] shapes (7B g128; 13B g128 act-order; 33B g32 act-order), the whole 2048-token prompt through
+    """BASELINE configs[1] / [2] / [3] / [4] shapes (7B g128; 13B g128 act-order; 33B g32 act-order; 65B g128), the whole 2048-token prompt through
     the product's prefill path (act-order: the gather folded into the GEMM's activation staging; fused q/k/v + RoPE + cache GEMM
     -> flash attention -> o_proj GEMM -> dual gate/up GEMM + SiLU -> down GEMM), compared END TO END with the CPU oracle model
     that ran the same prompt itself: last-token logits, K / V cache rows at sampled positions of every layer, and the next

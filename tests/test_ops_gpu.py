@@ -234,7 +234,9 @@ GEMM_SHAPES = [(256, 128, 64, True, 16), (512, 96, 128, False, 33), (704, 256, 6
                (4096, 4096, 128, False, 600), (1408, 512, 64, True, 530), (512, 11008, 32, False, 777),
                # more tiles than CUs with a partly filled last round: its tiles are cut along K (plan_gemm_tail): 13B o_proj (320 tiles,
                # act-order: the LDS-staged gather), 7B gate_proj with a ragged last m-tile (430 tiles)
-               (5120, 5120, 128, True, 2048), (4096, 11008, 128, False, 1100)]
+               (5120, 5120, 128, True, 2048), (4096, 11008, 128, False, 1100),
+               # BASELINE configs[4] (65B) at the full prompt length: gate / up (172 column tiles) and down_proj (K = 22016)
+               (8192, 22016, 128, False, 2048), (22016, 8192, 128, False, 2048)]
 
 
 @pytest.mark.parametrize("K,N,gs,act,rows", GEMM_SHAPES)
