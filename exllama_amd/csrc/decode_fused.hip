@@ -1245,156 +1245,13 @@ __global__ __launch_bounds__(128) void dec_lora_up_kernel(const DecLoraArgs a, i
     *(f16x2*) (out + n0) = prev0;
 }
 
-// Round 5: BOTH halves in one launch (dec_lora_fused_kernel; the two kernels above stay as the A/B reference, EXL_DEC_LORA_SPLIT=1).
-// A launch is a boundary (~1.6 us) plus a latency chain; the pair above costs two of each per GEMV launch, eight per layer -- decoding
-// with a rank-16 adapter ran at 0.47 of the plain rate (profiles/r04_lora.json).  The down half is tiny in FLOPs but its result t (r
-// numbers) is needed by every column of the up half, which is what forced the second launch.  Here every block computes t ITSELF, in
-// full: x (RMSNormed as the GEMV launch norms it) goes to LDS once, A (K x r fp16, 128 KiB at K = 4096 / r = 16) streams from the L2
-// with 16 rows in flight per thread, the block sums in a fixed order (thread -> lanes -> waves), so every block holds the same
-// bits.  A block covers 1024 columns (2 per thread), a launch is 4 .. 12 blocks: the redundant A reads are <= 12 x 128 KiB of L2
-// traffic.  The up half is dec_lora_up_kernel's, with its B rows and the GEMV's products requested BEFORE the down half runs.
-#define DEC_LF_THREADS 512
-__global__ __launch_bounds__(DEC_LF_THREADS) void dec_lora_fused_kernel(const DecLoraArgs a)
-{
-    extern __shared__ f16 lf_x[];                                      // [K] the launch's input row, normalised
-    __shared__ float red[DEC_LF_THREADS / 64][8][8];
-    __shared__ float t[3][DEC_LORA_MAXR];
-    __shared__ float ssq[DEC_LF_THREADS / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NWV = DEC_LF_THREADS / 64;
-    // ---- this thread's two columns (as dec_lora_up_kernel) and everything it will add to, requested first
-    const int n2 = (blockIdx.x * DEC_LF_THREADS + tid) * 2;
-    int mi = 0, n0 = n2;
-    if (!a.silu) {
-        if (n0 >= a.n[0]) { n0 -= a.n[0]; mi = 1; if (a.nmat > 1 && n0 >= a.n[1]) { n0 -= a.n[1]; mi = 2; } }
-    }
-    const int N = mi == 0 ? a.n[0] : mi == 1 ? a.n[1] : a.n[2];
-    const int r = mi == 0 ? a.r[0] : mi == 1 ? a.r[1] : a.r[2];
-    const f16* B = mi == 0 ? a.b[0] : mi == 1 ? a.b[1] : a.b[2];
-    f16* out = mi == 0 ? a.out[0] : mi == 1 ? a.out[1] : a.out[2];
-    const bool live = mi < a.nmat && n0 < N;
-    LoraRows R0, R1;
-    f16x2 prev0 = {(f16) 0.f, (f16) 0.f}, prev1 = prev0;
-    const int r1 = a.silu ? a.r[1] : 0;
-    if (live) {
-        lora_rows_load(R0, B, N, n0, r, 0);
-        prev0 = *(const f16x2*) (out + n0);
-        if (a.silu) { lora_rows_load(R1, a.b[1], a.n[1], n0, r1, 0); prev1 = *(const f16x2*) (a.out[1] + n0); }
-    }
-    // ---- the matrices this block's columns belong to (silu: gate and up; else the range first column .. last column)
-    int m_lo = 0, m_hi = a.silu ? 1 : 0;
-    if (!a.silu) {
-        const int c_first = blockIdx.x * DEC_LF_THREADS * 2, c_last = c_first + DEC_LF_THREADS * 2 - 1;
-        const int e0 = a.n[0], e1 = e0 + (a.nmat > 1 ? a.n[1] : 0);
-        m_lo = c_first < e0 ? 0 : c_first < e1 ? 1 : 2;
-        m_hi = c_last < e0 ? 0 : c_last < e1 ? 1 : 2;
-        if (m_hi > a.nmat - 1) m_hi = a.nmat - 1;
-        if (m_lo > m_hi) return;                                       // (a block beyond the last column: nothing to do)
-    }
-    // ---- x -> LDS (rms_norm.cu: fp32 sum of squares, r rounded to fp16, two fp16 multiplies; plain inputs are copied)
-    float sq = 0.f;
-    for (int k = tid * 8; k < a.K; k += DEC_LF_THREADS * 8) {
-        const f16x8 v = *(const f16x8*) (a.x + k);
-        *(f16x8*) (lf_x + k) = v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float f = (float) v[j]; sq = fmaf(f, f, sq); }
-    }
-    if (a.norm_w) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
-        if (lane == 0) ssq[wave] = sq;
-        __syncthreads();
-        float tot = 0.f;
-#pragma unroll
-        for (int w = 0; w < NWV; ++w) tot += ssq[w];
-        const f16 rmh = (f16) (1.0f / sqrtf(tot * (1.0f / (float) a.K) + a.eps));
-        for (int k = tid * 8; k < a.K; k += DEC_LF_THREADS * 8) {      // (each thread re-reads what it wrote itself)
-            f16x8 v = *(const f16x8*) (lf_x + k);
-            const f16x8 w8 = *(const f16x8*) (a.norm_w + k);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const f16 m = v[j] * rmh; v[j] = m * w8[j]; }
-            *(f16x8*) (lf_x + k) = v;
-        }
-    }
-    __syncthreads();
-    // ---- t_m = x A_m, whole K, in this block
-    for (int m = m_lo; m <= m_hi; ++m) {
-        const int rm_ = m == 0 ? a.r[0] : m == 1 ? a.r[1] : a.r[2];
-        if (rm_ <= 0) continue;
-        const f16* A = m == 0 ? a.a[0] : m == 1 ? a.a[1] : a.a[2];
-        int nc = (rm_ + 7) >> 3;                                       // column chunks of 8, padded to a power of two <= 8
-        nc = nc <= 1 ? 1 : nc <= 2 ? 2 : nc <= 4 ? 4 : 8;
-        const int c = lane % nc, kl = lane / nc, rpw = 64 / nc;
-        const bool vec = (rm_ & 7) == 0;
-        const int stride = NWV * rpw;                                  // rows the block covers per step
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int kb = wave * rpw + kl; kb < a.K; kb += 16 * stride) {
-            f16x8 wv[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {                             // 16 rows in flight per thread
-                const int k = kb + u * stride;
-                wv[u] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                if (k < a.K && c * 8 < rm_) {
-                    if (vec) wv[u] = *(const f16x8*) (A + (size_t) k * rm_ + c * 8);
-                    else for (int j = 0; j < 8 && c * 8 + j < rm_; ++j) wv[u][j] = A[(size_t) k * rm_ + c * 8 + j];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int k = kb + u * stride;
-                const float xf = k < a.K ? (float) lf_x[k] : 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fmaf(xf, (float) wv[u][j], acc[j]);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float v = acc[j];
-            for (int off = nc; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
-            if (kl == 0) red[wave][c][j] = v;
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const int cc = tid >> 3, j = tid & 7;
-            float v = 0.f;
-            if (cc < nc && cc * 8 + j < rm_) {
-#pragma unroll
-                for (int w = 0; w < NWV; ++w) v += red[w][cc][j];
-            }
-            if (cc * 8 + j < DEC_LORA_MAXR) t[m][cc * 8 + j] = (float) (f16) v;     // the reference's fp16 temporary
-        }
-        __syncthreads();
-    }
-    if (!live) return;
-    // ---- the up half (dec_lora_up_kernel's arithmetic)
-    const float* tm = mi == 0 ? t[0] : mi == 1 ? t[1] : t[2];
-    float c0 = 0.f, c1 = 0.f, d0 = 0.f, d1 = 0.f;
-    lora_rows_fma(R0, tm, r, 0, c0, c1);
-    if (r > 32) { lora_rows_load(R0, B, N, n0, r, 32); lora_rows_fma(R0, tm, r, 32, c0, c1); }
-    if (a.silu) {
-        lora_rows_fma(R1, t[1], r1, 0, d0, d1);
-        if (r1 > 32) { lora_rows_load(R1, a.b[1], a.n[1], n0, r1, 32); lora_rows_fma(R1, t[1], r1, 32, d0, d1); }
-        const f16 gh0 = r > 0 ? (f16) ((float) prev0[0] + (float) (f16) c0) : prev0[0], gh1 = r > 0 ? (f16) ((float) prev0[1] + (float) (f16) c1) : prev0[1];
-        const f16 uh0 = r1 > 0 ? (f16) ((float) prev1[0] + (float) (f16) d0) : prev1[0], uh1 = r1 > 0 ? (f16) ((float) prev1[1] + (float) (f16) d1) : prev1[1];
-        *(f16x2*) (a.act + n0) = (f16x2){silu_mul_f16(gh0, uh0), silu_mul_f16(gh1, uh1)};
-        return;
-    }
-    if (r <= 0) return;
-    prev0[0] = (f16) ((float) prev0[0] + (float) (f16) c0);
-    prev0[1] = (f16) ((float) prev0[1] + (float) (f16) c1);
-    *(f16x2*) (out + n0) = prev0;
-}
-
-// One launch (the default) or the down / up pair behind a GEMV launch; `a` is complete except for the pair's partial-sum buffer.
+// The down / up pair behind a GEMV launch; `a` is complete except for the partial-sum buffer.
+// (Round 5 measured the two halves as ONE launch -- every block computing t = x A itself, in full, from an LDS copy of x, 1024
+// columns per block: 305 instead of 336 tokens/s at rank 16, 135 instead of 189 at rank 64, profiles/r05_lora.json.  One CU keeps
+// ~32 KiB of requests in flight, so a block streams its 128-352 KiB of A in 4-10 round trips; cutting K over 32 blocks, as here,
+// is what keeps the down half at one round trip.  The kernel was removed again.)
 static int dec_lora_launch(DecLoraArgs& a, int cols, float* part, hipStream_t s)
 {
-    static const bool split = getenv("EXL_DEC_LORA_SPLIT") != nullptr;
-    const size_t smem = (size_t) ((a.K + 7) & ~7) * sizeof(f16);
-    if (!split && a.K % 8 == 0 && smem <= 60 * 1024) {
-        hipLaunchKernelGGL(dec_lora_fused_kernel, dim3((cols / 2 + DEC_LF_THREADS - 1) / DEC_LF_THREADS), dim3(DEC_LF_THREADS), smem, s, a);
-        EXL_LAUNCH_CHECK();
-        return 0;
-    }
     int nparts = (a.K + 255) / 256;
     if (nparts > DEC_LORA_PARTS) nparts = DEC_LORA_PARTS;
     a.kslice = ((a.K + nparts - 1) / nparts + 7) & ~7;
