@@ -112,7 +112,7 @@ def layer_split_main(args, dims, L, S, G, rank, world, dev, dist):
     first, last = split_layers(L, world)[rank]
     n_local = last - first
     tensors = synth.make_checkpoint(dims, groupsize=args.groupsize, act_order=args.act_order, seed=100 + rank, device=dev,
-                                    zeros="sym", num_layers=n_local)
+                                    zeros="sym", num_layers=n_local, nibbles="centered")
     cfg = ExLlamaConfig(synth.config_dict(dims, n_local))
     cfg.max_seq_len = S + G
     cfg.max_input_len = S
@@ -142,11 +142,12 @@ def layer_split_main(args, dims, L, S, G, rank, world, dev, dist):
             runner.generate_greedy(tok, G)                        # G tokens: the token travels last rank -> rank 0 on the device
         else:
             for _ in range(G):
-                logits = runner.forward(tok)
-                tok = runner.next_token(logits)
+                lg = runner.forward(tok)
+                tok = runner.next_token(lg)
         e[2].record()
         if record is not None:
             record.append(e)
+        return logits
 
     def barrier():
         torch.cuda.synchronize()
@@ -160,9 +161,11 @@ def layer_split_main(args, dims, L, S, G, rank, world, dev, dist):
     events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(events)
+        last_logits = step(events)
     barrier()
     elapsed = time.perf_counter() - t0
+    bad = 0.0 if last_logits is None or bool(torch.isfinite(last_logits).all()) else 1.0     # (the prompt's logits, on the last rank)
+    bad = reduce_over_ranks([bad], dist, dev)[0]
     mean = lambda v: sum(v) / len(v)
     pre = mean([e[0].elapsed_time(e[1]) for e in events])
     dec = mean([e[1].elapsed_time(e[2]) for e in events])
@@ -175,6 +178,7 @@ def layer_split_main(args, dims, L, S, G, rank, world, dev, dist):
             "metric": "single-token decode tokens/s at full context (prefill tokens/s alongside), Llama GPTQ 4-bit",
             "value": round(G / (dec / 1e3), 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "logits_finite": bad == 0.0,
             "dtype": "int4 weights (GPTQ) x fp16 activations, fp32 accumulate",
             "data": "synthetic (seeded random GPTQ weights of the named architecture, random token ids)",
             "config": {"workload": f"Llama-{args.model.upper()} 4-bit GPTQ g{args.groupsize}, {S}-token prefill + {G}-token greedy decode, "
@@ -199,7 +203,7 @@ def tensor_parallel_main(args, dims, L, S, G, rank, world, dev, dist):
     from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
 
     cfg_dict = synth.config_dict(dims, L)
-    full = synth.make_checkpoint(dims, groupsize=args.groupsize, act_order=args.act_order, seed=100, device=dev, zeros="sym", num_layers=L)
+    full = synth.make_checkpoint(dims, groupsize=args.groupsize, act_order=args.act_order, seed=100, device=dev, zeros="sym", num_layers=L, nibbles="centered")
     local, plan = tp.shard_tensors(full, cfg_dict, rank, world)
     del full
     cfg = ExLlamaConfig(tp.shard_config_dict(cfg_dict, plan))
@@ -223,7 +227,7 @@ def tensor_parallel_main(args, dims, L, S, G, rank, world, dev, dist):
         e = [ev() for _ in range(3)]
         cache.current_seq_len = 0
         e[0].record()
-        logits = model.forward(ids, cache)
+        logits = first_logits = model.forward(ids, cache)
         e[1].record()
         tok = logits[0, -1].argmax().view(1, 1)                   # identical logits on every rank: no token broadcast needed
         if model._decoder is not None:
@@ -235,6 +239,7 @@ def tensor_parallel_main(args, dims, L, S, G, rank, world, dev, dist):
         e[2].record()
         if record is not None:
             record.append(e)
+        return first_logits
 
     def barrier():
         torch.cuda.synchronize()
@@ -248,9 +253,10 @@ def tensor_parallel_main(args, dims, L, S, G, rank, world, dev, dist):
     events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(events)
+        last_logits = step(events)
     barrier()
     elapsed = time.perf_counter() - t0
+    logits_finite = bool(torch.isfinite(last_logits).all())
     mean = lambda v: sum(v) / len(v)
     pre = mean([e[0].elapsed_time(e[1]) for e in events])
     dec = mean([e[1].elapsed_time(e[2]) for e in events])
@@ -266,6 +272,7 @@ def tensor_parallel_main(args, dims, L, S, G, rank, world, dev, dist):
             "metric": "single-token decode tokens/s at full context (prefill tokens/s alongside), Llama GPTQ 4-bit",
             "value": round(G / (dec / 1e3), 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "logits_finite": logits_finite,
             "dtype": "int4 weights (GPTQ) x fp16 activations, fp32 accumulate",
             "data": "synthetic (seeded random GPTQ weights of the named architecture, random token ids)",
             "config": {"workload": f"Llama-{args.model.upper()} 4-bit GPTQ g{args.groupsize}, {S}-token prefill + {G}-token greedy decode, "
@@ -362,8 +369,10 @@ def main():
         return layer_split_main(args, dims, L, S, G, rank, world, dev, dist)
     if args.tensor_parallel:
         return tensor_parallel_main(args, dims, L, S, G, rank, world, dev, dist)
+    # nibbles="centered": weights symmetric about the zero point, as GPTQ writes them -- uniform nibbles carry a -0.5-step bias per weight
+    # that pushes a deep model's residual stream out of the fp16 range around layer 37 (synth.make_checkpoint)
     tensors = synth.make_checkpoint(dims, groupsize=args.groupsize, act_order=args.act_order, seed=0, device=dev,
-                                    zeros="sym", num_layers=L)
+                                    zeros="sym", num_layers=L, nibbles="centered")
     cfg = ExLlamaConfig(synth.config_dict(dims, L))
     cfg.max_seq_len = S + G
     cfg.max_input_len = S
@@ -422,9 +431,12 @@ def main():
     events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(events)
+        last_logits = step(events)
     barrier()
     elapsed = time.perf_counter() - t0
+    # the timed steps ran on real numbers: a synthetic model whose residual stream has left the fp16 range executes the same
+    # instructions on inf / NaN (and draws less power doing so) -- such a line is marked invalid (checked after the clock stopped)
+    logits_finite = bool(torch.isfinite(last_logits).all()) and bool(torch.isfinite(model.forward(ids[:, :8], ExLlamaCache(model), last_id_only=False)).all())
     for e in events:
         phase_ms["prefill"].append(e[0].elapsed_time(e[1]))
         phase_ms["worst"].append(e[1].elapsed_time(e[2]))
@@ -463,6 +475,9 @@ def main():
         "prefill_ms": round(prefill_ms, 3), "decode_worst_ms_per_token": round(worst_ms / G, 4),
         "decode_best_ms_per_token": round(best_ms / G, 4),
     }
+    result["logits_finite"] = logits_finite
+    if not logits_finite:
+        result["config"]["INVALID"] = "the model's activations left the fp16 range (inf / NaN logits): timings are not those of a real model"
     if args.layers is not None:
         result["config"]["INVALID"] = "truncated model (--layers): not a benchmark result"
     if rank == 0:
@@ -623,7 +638,7 @@ def _run_sub(cmd, limit_s, env=None):
     return d, time.perf_counter() - t0, None
 
 
-_SUB_KEEP = ("value", "unit", "ms_per_step", "steps", "warmup", "prefill_tokens_per_s", "decode_worst_tokens_per_s", "decode_best_tokens_per_s",
+_SUB_KEEP = ("value", "unit", "logits_finite", "ms_per_step", "steps", "warmup", "prefill_tokens_per_s", "decode_worst_tokens_per_s", "decode_best_tokens_per_s",
              "prefill_ms", "decode_worst_ms_per_token", "decode_best_ms_per_token", "path_roofline", "scaling", "n_gpus", "rccl_ranks", "backend",
              "per_rank")
 
@@ -850,7 +865,7 @@ def cpu_baseline(dims, groupsize, sample_layers=2, prompt=128, gen=4, ctx=2048):
     except Exception:
         threads = os.cpu_count() or 1
     tensors = synth.make_checkpoint(dims, groupsize=groupsize, act_order=False, seed=0, device="cpu", zeros="sym",
-                                    num_layers=sample_layers)
+                                    num_layers=sample_layers, nibbles="centered")
     m = OracleLlama(synth.config_dict(dims, sample_layers), tensors, max_seq_len=max(prompt, ctx) + gen)
     m.prepare()
     ids = np.random.RandomState(0).randint(0, min(31999, dims.vocab_size - 1), size=(1, prompt))

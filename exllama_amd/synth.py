@@ -61,10 +61,18 @@ PRESETS = {"7b": LLAMA_7B, "13b": LLAMA_13B, "33b": LLAMA_33B, "65b": LLAMA_65B,
            "tiny_hd128_gqa": LLAMA_TINY_HD128_GQA}
 
 
-def make_q4_linear(K, N, groupsize, act_order, gen, device, zeros="sym", std=None, g_idx=None):
-    """One GPTQ linear. Returns dict(qweight, qzeros, scales[, g_idx]).  `g_idx`: reuse this group index instead of drawing one."""
+def make_q4_linear(K, N, groupsize, act_order, gen, device, zeros="sym", std=None, g_idx=None, nibbles="uniform"):
+    """One GPTQ linear. Returns dict(qweight, qzeros, scales[, g_idx]).  `g_idx`: reuse this group index instead of drawing one.
+    nibbles: "uniform" = every 4-bit value 0..15 equally likely (random bits); "centered" = the same bits with every 0 nibble
+    replaced by 8, i.e. a distribution symmetric about the symmetric zero point 8 (see make_checkpoint)."""
     G = K // groupsize
     qweight = torch.randint(-2**31, 2**31 - 1, (K // 8, N), dtype=torch.int64, generator=gen, device=device).to(torch.int32)
+    if nibbles == "centered":
+        # bit 0 of every nibble of `none` is set where the nibble is 0 (the arithmetic right shifts only disturb bits that the mask drops)
+        none = ~(qweight | (qweight >> 1) | (qweight >> 2) | (qweight >> 3)) & 0x11111111
+        qweight = qweight | (none << 3)
+    elif nibbles != "uniform":
+        raise ValueError(f"nibbles: {nibbles!r}")
     if zeros == "sym":
         qzeros = torch.full((G, N // 8), 0x77777777, dtype=torch.int32, device=device)
     else:
@@ -83,8 +91,17 @@ def make_q4_linear(K, N, groupsize, act_order, gen, device, zeros="sym", std=Non
     return out
 
 
-def make_checkpoint(dims, groupsize=128, act_order=False, seed=0, device="cpu", zeros="sym", num_layers=None):
+def make_checkpoint(dims, groupsize=128, act_order=False, seed=0, device="cpu", zeros="sym", num_layers=None, nibbles="uniform"):
     """Full tensor dict for a Llama of shape `dims` (optionally truncated to `num_layers`).
+
+    nibbles: with zeros="sym" (effective zero point 8) uniform nibbles 0..15 have mean 7.5: every weight carries a bias of -0.5
+    scale steps.  One layer does not notice; a DEEP model does -- RMSNorm does not centre, SiLU(g) * u has a positive mean, and the
+    common-mode shift the down projection adds to ALL channels grows linearly with depth: measured ~1.8e3 per layer in max |hidden|
+    at 13B shapes, the fp16 range is left at layer 36-37 (gpurun_out/r05c), i.e. the 13B / 33B / 65B benchmark models of rounds 1-4
+    computed on inf / NaN from there on (same instructions, but not the data -- or the power draw -- of a real model).
+    "centered" (what bench.py and the full-depth perplexity runs use) replaces every 0 nibble by 8: values 1..15, symmetric about the
+    zero point like the weights GPTQ writes for a real model, and the residual stream stays O(10) through 80 layers.  The default stays
+    "uniform" because the committed golden vectors were generated with it (few layers: no difference that matters there).
 
     act_order: False; True = every matrix draws its own row permutation (the general case the reference's per-matrix x_map allows);
     "gptq" = what GPTQ with desc_act actually writes: the permutation is argsort(diag(H)) of the layer INPUT's Hessian, and the
@@ -109,7 +126,7 @@ def make_checkpoint(dims, groupsize=128, act_order=False, seed=0, device="cpu", 
             share = None
             if act_order == "gptq" and name in ("self_attn.k_proj", "self_attn.v_proj", "mlp.up_proj"):
                 share = t[f"{p}.{'self_attn.q_proj' if name.startswith('self_attn') else 'mlp.gate_proj'}.g_idx"]
-            lin = make_q4_linear(K, N, groupsize, bool(act_order), gen, device, zeros=zeros, g_idx=share)
+            lin = make_q4_linear(K, N, groupsize, bool(act_order), gen, device, zeros=zeros, g_idx=share, nibbles=nibbles)
             for k, v in lin.items():
                 t[f"{p}.{name}.{k}"] = v
     return t
@@ -129,11 +146,11 @@ def config_dict(dims, num_layers=None):
     }
 
 
-def save_checkpoint(directory, dims, groupsize=128, act_order=False, seed=0, zeros="sym", num_layers=None):
+def save_checkpoint(directory, dims, groupsize=128, act_order=False, seed=0, zeros="sym", num_layers=None, nibbles="uniform"):
     """Write config.json + model.safetensors into `directory`; returns (config_path, model_path)."""
     from safetensors.torch import save_file
     os.makedirs(directory, exist_ok=True)
-    tensors = make_checkpoint(dims, groupsize, act_order, seed, "cpu", zeros, num_layers)
+    tensors = make_checkpoint(dims, groupsize, act_order, seed, "cpu", zeros, num_layers, nibbles)
     cfg = os.path.join(directory, "config.json")
     with open(cfg, "w") as f:
         json.dump(config_dict(dims, num_layers), f)

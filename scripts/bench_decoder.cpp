@@ -26,7 +26,8 @@ __global__ void fill_u32(uint32_t* p, size_t n, uint32_t seed)
     for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
         uint32_t x = (uint32_t) i * 2654435761u + seed;
         x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
-        p[i] = x;
+        x |= (~(x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u) << 3;   // every 0 nibble -> 8: weights symmetric about the zero point 8
+        p[i] = x;                                                          // (uniform nibbles bias every weight by -0.5 steps: a deep model overflows fp16)
     }
 }
 __global__ void fill_f16(_Float16* p, size_t n, float lo, float hi, uint32_t seed)

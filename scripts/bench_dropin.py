@@ -46,7 +46,7 @@ def main():
 
     dims = synth.PRESETS["7b"]
     t0 = time.time()
-    cfg_path, st_path = synth.save_checkpoint(os.path.join(work, "ckpt"), dims, groupsize=128, act_order=False, seed=0, zeros="sym",
+    cfg_path, st_path = synth.save_checkpoint(os.path.join(work, "ckpt"), dims, groupsize=128, act_order=False, seed=0, zeros="sym", nibbles="centered",
                                               num_layers=args.layers)
     t_ckpt = time.time() - t0
     cfg = ref.ExLlamaConfig(cfg_path)

@@ -39,7 +39,7 @@ def main():
     a = ap.parse_args()
     dims, L, S, G = synth.PRESETS["7b"], a.layers, 2048, 64
     dev = "cuda:0"
-    tensors = synth.make_checkpoint(dims, groupsize=128, act_order=False, seed=0, device=dev, zeros="sym", num_layers=L)
+    tensors = synth.make_checkpoint(dims, groupsize=128, act_order=False, seed=0, device=dev, zeros="sym", num_layers=L, nibbles="centered")
     cfg = ExLlamaConfig(synth.config_dict(dims, L))
     cfg.max_seq_len, cfg.max_input_len = S + G + 8, S
     model = ExLlama(cfg, tensors=tensors)

@@ -22,10 +22,11 @@ def main():
     ap.add_argument("--rows", default="4,64,600")
     ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--head-scales", default="")
+    ap.add_argument("--nibbles", default="centered")
     a = ap.parse_args()
     dims = synth.PRESETS[a.model]
     L = a.layers or dims.num_hidden_layers
-    t = synth.make_checkpoint(dims, groupsize=a.groupsize, act_order="gptq" if a.act_order else False, seed=a.seed, device="cuda:0", zeros=a.zeros, num_layers=L)
+    t = synth.make_checkpoint(dims, groupsize=a.groupsize, act_order="gptq" if a.act_order else False, seed=a.seed, device="cuda:0", zeros=a.zeros, num_layers=L, nibbles=a.nibbles)
     cfg = ExLlamaConfig(synth.config_dict(dims, L))
     cfg.max_seq_len = cfg.max_input_len = 2048
     model = ExLlama(cfg, tensors=t)

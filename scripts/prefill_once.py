@@ -18,7 +18,7 @@ ap.add_argument("--reps", type=int, default=2)
 a = ap.parse_args()
 dims = synth.PRESETS[a.model]
 act = {"": False, "gptq": "gptq", "independent": True}[a.act_order]
-t = synth.make_checkpoint(dims, groupsize=128, act_order=act, seed=0, device="cuda:0", zeros="sym", num_layers=a.layers)
+t = synth.make_checkpoint(dims, groupsize=128, act_order=act, seed=0, device="cuda:0", zeros="sym", num_layers=a.layers, nibbles="centered")
 cfg = ExLlamaConfig(synth.config_dict(dims, a.layers))
 cfg.max_seq_len = 2048 + 8
 cfg.max_input_len = 2048

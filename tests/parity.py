@@ -120,7 +120,8 @@ def _ppl_checkpoint(dims, layers, groupsize, act_order, head_scale, ckpt_seed, z
     """zeros: "sym" = every stored zero nibble 7, the symmetric-GPTQ norm and what bench.py's models carry (the
     statistics that keep activations finite through all layers); "rand" = the stress variant of the short-model tests."""
     from exllama_amd import synth
-    tensors = synth.make_checkpoint(dims, groupsize=groupsize, act_order=act_order, seed=ckpt_seed, device="cpu", zeros=zeros, num_layers=layers)
+    tensors = synth.make_checkpoint(dims, groupsize=groupsize, act_order=act_order, seed=ckpt_seed, device="cpu", zeros=zeros, num_layers=layers,
+                                    nibbles="centered")
     tensors["lm_head.weight"] = (tensors["lm_head.weight"].float() * head_scale).half()
     return tensors
 

@@ -210,3 +210,34 @@ def test_truth_model_and_the_decode_step_criterion():
     broken.past = 21
     with pytest.raises(AssertionError):
         _truth_close(broken.forward(np.array([[toks[1]]]))[0, 0], runs, truth, 1)
+
+
+def test_centered_nibbles_keep_a_deep_synthetic_model_in_the_fp16_range():
+    """synth.make_checkpoint(nibbles=...): uniform nibbles 0..15 against the symmetric zero point 8 bias every weight by -0.5 steps; through
+    a deep model that bias becomes a common-mode drift of the residual stream, linear in the depth (measured on the GPU at 13B shapes:
+    ~1.8e3 per layer, inf at layer 36-37 of 40) -- the benchmark models of rounds 1-4 beyond 7B computed on inf / NaN from there on.
+    "centered" (every 0 nibble -> 8: symmetric about the zero point, as the weights GPTQ writes are) keeps it bounded."""
+    import torch
+    from exllama_amd import synth
+    from oracle.model_oracle import OracleLlama
+    dims, L = synth.LLAMA_TINY_HD128, 40
+    growth = {}
+    for nib in ("uniform", "centered"):
+        t = synth.make_checkpoint(dims, groupsize=128, seed=3, num_layers=L, nibbles=nib)
+        q = t["model.layers.7.mlp.down_proj.qweight"]
+        vals = torch.stack([(q >> (4 * j)) & 0xF for j in range(8)]).flatten().float()
+        assert abs(float(vals.mean()) - (8.0 if nib == "centered" else 7.5)) < 0.02
+        assert (int((vals == 0).sum()) == 0) == (nib == "centered")
+        o = OracleLlama(synth.config_dict(dims, L), t, max_seq_len=16)
+        h = o.embed[np.array([[5, 9, 11, 200, 17, 3]])]
+        peaks = []
+        for i in range(L):
+            h = o.layer_forward(i, h)
+            peaks.append(float(np.abs(h.astype(np.float32)).max()))
+        growth[nib] = peaks
+    assert growth["uniform"][-1] > 2000 and growth["uniform"][-1] > 1.8 * growth["uniform"][L // 2 - 1]      # linear in the depth
+    assert growth["centered"][-1] < 100
+    # the default stays "uniform": the committed golden vectors were generated with it
+    a = synth.make_checkpoint(synth.LLAMA_TINY, seed=1, num_layers=1)
+    b = synth.make_checkpoint(synth.LLAMA_TINY, seed=1, num_layers=1, nibbles="uniform")
+    assert all(torch.equal(a[k], b[k]) for k in a)
