@@ -53,6 +53,9 @@ def parse_args():
     p.add_argument("--no-graph", action="store_true", help="decode eagerly instead of replaying the captured hipGraph")
     p.add_argument("--host-argmax", action="store_true", help="greedy argmax by torch between graph replays (the reference's loop) instead of inside the graph")
     p.add_argument("--no-roofline-probe", action="store_true")
+    p.add_argument("--nibbles", default="centered", choices=["centered", "uniform"],
+                   help="synthetic weight nibbles: 'centered' (default: symmetric about the zero point, finite activations at any depth) or "
+                        "'uniform' (rounds 1-4: every weight biased by -0.5 steps; models deeper than ~36 layers compute on inf / NaN) -- A/B aid")
     p.add_argument("--brief", action="store_true",
                    help="the timed protocol, path_roofline and the kernel probes only: no other prompt lengths, host-loop tiers, CPU baseline, "
                         "drop-in run or other configs (what the sub-runs of the default invocation use)")
@@ -112,7 +115,7 @@ def layer_split_main(args, dims, L, S, G, rank, world, dev, dist):
     first, last = split_layers(L, world)[rank]
     n_local = last - first
     tensors = synth.make_checkpoint(dims, groupsize=args.groupsize, act_order=args.act_order, seed=100 + rank, device=dev,
-                                    zeros="sym", num_layers=n_local, nibbles="centered")
+                                    zeros="sym", num_layers=n_local, nibbles=args.nibbles)
     cfg = ExLlamaConfig(synth.config_dict(dims, n_local))
     cfg.max_seq_len = S + G
     cfg.max_input_len = S
@@ -203,7 +206,7 @@ def tensor_parallel_main(args, dims, L, S, G, rank, world, dev, dist):
     from exllama_amd.model import ExLlama, ExLlamaCache, ExLlamaConfig
 
     cfg_dict = synth.config_dict(dims, L)
-    full = synth.make_checkpoint(dims, groupsize=args.groupsize, act_order=args.act_order, seed=100, device=dev, zeros="sym", num_layers=L, nibbles="centered")
+    full = synth.make_checkpoint(dims, groupsize=args.groupsize, act_order=args.act_order, seed=100, device=dev, zeros="sym", num_layers=L, nibbles=args.nibbles)
     local, plan = tp.shard_tensors(full, cfg_dict, rank, world)
     del full
     cfg = ExLlamaConfig(tp.shard_config_dict(cfg_dict, plan))
@@ -372,7 +375,7 @@ def main():
     # nibbles="centered": weights symmetric about the zero point, as GPTQ writes them -- uniform nibbles carry a -0.5-step bias per weight
     # that pushes a deep model's residual stream out of the fp16 range around layer 37 (synth.make_checkpoint)
     tensors = synth.make_checkpoint(dims, groupsize=args.groupsize, act_order=args.act_order, seed=0, device=dev,
-                                    zeros="sym", num_layers=L, nibbles="centered")
+                                    zeros="sym", num_layers=L, nibbles=args.nibbles)
     cfg = ExLlamaConfig(synth.config_dict(dims, L))
     cfg.max_seq_len = S + G
     cfg.max_input_len = S
@@ -459,7 +462,9 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "int4 weights (GPTQ) x fp16 activations, fp32 accumulate",
-        "data": "synthetic (seeded random GPTQ weights of the named architecture, random token ids)",
+        "data": "synthetic (seeded random GPTQ weights of the named architecture -- random nibbles, " + (
+            "every 0 nibble replaced by 8 so that the weights are symmetric about the zero point and the activations stay finite at any depth"
+            if args.nibbles == "centered" else "uniform 0..15 as in rounds 1-4: biased by -0.5 steps, deep models overflow fp16") + "; random token ids)",
         "config": {
             "workload": f"Llama-{args.model.upper()} 4-bit GPTQ g{args.groupsize}{(' act-order (shared q/k/v and gate/up maps)' if args.act_order == 'gptq' else ' act-order (one map per matrix)') if args.act_order else ''}, "
                         f"{S}-token prefill + {G}-token greedy decode at context {S}..{S + G} (BASELINE configs[1]); "
