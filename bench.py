@@ -628,18 +628,30 @@ def _last_json_line(text):
 
 
 def _run_sub(cmd, limit_s, env=None):
-    """One sub-run with a wall-clock limit; returns (parsed JSON line or None, seconds, error text or None)."""
+    """One sub-run with a wall-clock limit; returns (parsed JSON line or None, seconds, error text or None).  The sub-run is its own
+    process group: at the limit the WHOLE group (a torch.distributed.run launcher and its workers) is killed, nothing is left holding a GPU."""
+    import signal
     import subprocess
     t0 = time.perf_counter()
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s, cwd=ROOT, env=env)
-    except subprocess.TimeoutExpired:
-        return None, time.perf_counter() - t0, f"timed out after {limit_s} s"
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env, start_new_session=True)
     except Exception as e:                                            # noqa: BLE001
         return None, time.perf_counter() - t0, str(e)[:300]
-    d = _last_json_line(r.stdout)
-    if r.returncode != 0 or d is None:
-        return None, time.perf_counter() - t0, f"rc {r.returncode}: {(r.stderr or r.stdout)[-400:]}"
+    try:
+        out, err = p.communicate(timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)                          # the group this call created (start_new_session), nothing else
+        except OSError:
+            pass
+        try:
+            p.communicate(timeout=30)
+        except Exception:                                             # noqa: BLE001
+            pass
+        return None, time.perf_counter() - t0, f"timed out after {limit_s} s"
+    d = _last_json_line(out)
+    if p.returncode != 0 or d is None:
+        return None, time.perf_counter() - t0, f"rc {p.returncode}: {(err or out)[-400:]}"
     return d, time.perf_counter() - t0, None
 
 
@@ -660,7 +672,7 @@ def _sub_record(d, secs, err, what):
     return rec
 
 
-def sub_bench(flags, what, limit_s=900):
+def sub_bench(flags, what, limit_s=420):
     d, secs, err = _run_sub([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--brief"] + flags, limit_s)
     return _sub_record(d, secs, err, what)
 
@@ -681,13 +693,18 @@ def dropin_run(limit_s=600):
     return d
 
 
-def sharded_runs(world, limit_s=900):
+def sharded_runs(world, limit_s=240, budget_s=600):
     """ONE model over the N GPUs of this job, launched by rank 0 after the replica run: `python -m torch.distributed.run ... bench.py
-    --layer-split / --tensor-parallel` on a fresh rendezvous port."""
+    --layer-split / --tensor-parallel` on a fresh rendezvous port.  Every job has its own time limit and all of them share a budget:
+    these modes have never run on more than one GPU (no such box was available to any round), and a hang in one of them must not
+    cost the replica headline its place in the driver's time limit."""
     import socket
     out = {}
+    t_start = time.perf_counter()
 
     def launch(flags, what):
+        if time.perf_counter() - t_start > budget_s:
+            return {"what": what, "error": f"skipped: the sharded sub-runs' time budget ({budget_s} s) was used up"}
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
@@ -697,12 +714,12 @@ def sharded_runs(world, limit_s=900):
                "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--brief"] + flags
         d, secs, err = _run_sub(cmd, limit_s, env=env)
         return _sub_record(d, secs, err, what)
+    out["layer_split_7b"] = launch(["--layer-split", "--steps", "2", "--warmup", "1"], f"Llama-7B g128 split by layers over {world} GPUs")
     out["layer_split_65b"] = launch(["--layer-split", "--model", "65b", "--steps", "1", "--warmup", "1"],
                                     f"BASELINE configs[4]: Llama-65B g128 split by layers over {world} GPUs (reference: model.py:636-668)")
     if world == 2:
         out["layer_split_33b_g32_actorder"] = launch(["--layer-split", "--model", "33b", "--groupsize", "32", "--act-order", "--steps", "2", "--warmup", "1"],
                                                      "BASELINE configs[3]: Llama-33B g32 act-order split by layers over 2 GPUs")
-    out["layer_split_7b"] = launch(["--layer-split", "--steps", "2", "--warmup", "1"], f"Llama-7B g128 split by layers over {world} GPUs")
     out["tensor_parallel_7b"] = launch(["--tensor-parallel", "--steps", "2", "--warmup", "1"],
                                        f"Llama-7B g128 tensor parallel over {world} GPUs (not in the reference; SURVEY.md 8 row N4)")
     return out

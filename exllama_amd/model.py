@@ -795,12 +795,13 @@ class ExLlama:
         "executor_pieces_tp": "native decode executor in half-layer pieces, the residual stream all-reduced between them (tensor parallel)",
         "ops_fused": "op by op: q4_attn -> attention -> q4_attn_2 -> q4_mlp per layer (the reference's fused decode ops, model.py:524-552)",
         "ops_general": "op by op, general path: norm, q/k/v projections, RoPE, cache update, attention, o_proj, norm, gate/up, SiLU, down "
-                       "(batched generation, fused_attn off, or a tensor-parallel shard outside the executor)",
+                       "(batched generation, fused_attn off, or a tensor-parallel shard outside the executor; <= fused_mlp_thd rows still "
+                       "take q4_mlp for the MLP half, as in the reference)",
     }
 
-    def _count_path(self, tier):
+    def _count_path(self, tier, n=1):
         c = self.__dict__.setdefault("_path_counts", {})
-        c[tier] = c.get(tier, 0) + 1
+        c[tier] = c.get(tier, 0) + n
         self._last_path = tier
 
     def _executor_tier(self, st):
@@ -1196,6 +1197,7 @@ class ExLlama:
         st["tok"].copy_(first_token.view(1, 1), non_blocking=True)
         if st["dev_pos"] != start:
             self._set_positions(st, start)
+        self._count_path("executor_graph", num_tokens)                # (decode_path_report: tokens generated inside the graph count too)
         for i in range(num_tokens):
             p = start + i
             for limit, g in st["ggraphs"]:
@@ -1257,6 +1259,7 @@ class ExLlama:
         st["tok"].copy_(seq[-1:].view(1, 1), non_blocking=True)
         if st["dev_pos"] != start:
             self._set_positions(st, start)
+        self._count_path("executor_graph", num_tokens)
         for i in range(num_tokens):
             p = start + i
             for limit, g in st["sgraphs"]:
@@ -1281,6 +1284,7 @@ class ExLlama:
         if settings is not None and "probs" not in st:
             st["probs"] = torch.empty((self.config.vocab_size,), dtype=torch.float32, device=st["dev"])
         hist = st["history"]
+        self._count_path("executor_pieces_tp", num_tokens)
         for i in range(num_tokens):
             self._run_token(st, cache)                               # advances cache.current_seq_len and the device-side position
             p = start + i + 1                                         # position of the token chosen now

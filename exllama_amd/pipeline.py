@@ -145,9 +145,30 @@ class LayerSplitRunner:
         token_ring = True prepares generate_greedy() (the token travels from the last rank to rank 0 inside the graphs too);
         single-token forward() calls then need token_ring = False (they bring their token from the host)."""
         self.hop = StageHop(self.dist, self.rank, self.world, token_ring)
+        if self.world > 1 and use_graph and capture_hop:
+            self._warm_up_links(token_ring)
         self.stage.enable_decode_graph(self.cache, use_graph=use_graph, first_stage=self.rank == 0, last_stage=self.rank == self.world - 1,
                                        hop=self.hop, hop_capture=capture_hop)
         self._executor = True
+
+    def _warm_up_links(self, token_ring):
+        """One eager exchange over every point-to-point pair the captured token step will use (hidden state r -> r + 1, token last -> 0)
+        BEFORE anything is captured: RCCL sets a pair's connection up at its first use (allocations, IPC handles), which has no place
+        inside a stream capture.  Same order as a token step, so it cannot deadlock; the payloads are scratch."""
+        last = self.world - 1
+        hid = torch.zeros((1, 1, self.hidden_size), dtype=self.dtype, device=self.device)
+        tok = torch.zeros((1, 1), dtype=torch.int64, device=self.device)
+        if self.rank > 0:
+            self.dist.recv(hid, src=self.rank - 1)
+        if self.rank < last:
+            self.dist.send(hid, dst=self.rank + 1)
+        if token_ring:
+            if self.rank == last:
+                self.dist.send(tok, dst=0)
+            elif self.rank == 0:
+                self.dist.recv(tok, src=last)
+        if torch.cuda.is_available() and str(self.device).startswith("cuda"):
+            torch.cuda.synchronize(self.device)
 
     def _decode_token(self, input_ids):
         if self.hop.token_ring:
