@@ -13,7 +13,7 @@
 //     slot l % U, consumes it (dequantise + 4 MFMA) and immediately re-requests that slot with the row-block U steps ahead -- of
 //     this unit, or of the block's NEXT unit, whose scale / zero words travel just ahead of the weight load that first needs them
 //     (one pair of small loads per 4 row-blocks);
-//   * the ring is SHALLOW (U <= 4): a CU accepts about 2 KiB of outstanding requests per wave (measured, DESIGN.md section 3: with 8
+//   * the ring is SHALLOW (U <= 4): a CU accepts about 2 KiB of outstanding requests per wave (measured, profiles/HISTORY.md section 3: with 8
 //     loads per wave the last wave of a block is still queueing its start-up requests when the first 120 KiB have arrived, and the
 //     block-wide activation barrier -- hence all arithmetic -- waits for it); deeper rings only move the waiting from `s_waitcnt` to
 //     the issue stage, where it also blocks the barrier;

@@ -488,7 +488,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void q4_gemm_t16m_kernel(co
     // dead after the loop, and without the tie it shuffled accumulators through the very registers a dwordx4 was still on its way
     // to (v_accvgpr_read v4..v7 / v_accvgpr_write between the loop and this wait): whole accumulator registers of a wave came out
     // as weight bits whenever the last fetch was slow (first launch after an idle period, two blocks per CU): the round-2 "400 rows
-    // x 11008 columns" defect, DESIGN.md 9.5.
+    // x 11008 columns" defect, profiles/HISTORY.md 9.5.
     GM_WAIT("0", rX); GM_WAIT("0", rY);
 #ifdef EXL_GEMM_PROBE
     if (lane == 0 && b < 1024) {
@@ -582,7 +582,7 @@ struct GemmTail { int b_split, parts; float* ws; int mr; };      // see plan_gem
 // and packed weights of about equal size, the rectangle with the fewest bytes from outside the L2 per tile -- 283 MB for the same
 // launch.  MEASURED AND NOT MADE THE DEFAULT: 13B act-order prompt 38.5 / 38.7 k tokens/s with the rectangles against 39.8 / 39.6 k
 // with the old order (alternating runs on one box), 7B 78.5 vs 78.0 k: the traffic is not what bounds these kernels (the loader
-// waves wait 111 of 1473 cycles per K step), and a weight tile shared by 2 blocks instead of 8 makes the
+// waves wait 111 of 1473 cycles per K step, profiles/HISTORY.md 9.3), and a weight tile shared by 2 blocks instead of 8 makes the
 // latency-critical register loads of B miss the L2 more often than the deep activation DMA ring ever stalled.
 __host__ __device__ __forceinline__ bool gemm_tile_of(int b, int mtiles, int ntiles, int mr, int* mt, int* nt)
 {
@@ -1503,7 +1503,7 @@ int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
     if (w->layout == EXL_LAYOUT_T16 && (uint64_t) rows * (uint64_t) K < (1ull << 31)) {    // 32-bit activation byte offsets
         // 257 .. 512 rows: the 128 x 128 tile (about 10 % faster than the 256-row kernels at 300 - 384 rows).  Round 2 found it
         // corrupting accumulators at 400 rows x 11008 columns on cold launches (in-flight "redundant" fetches landing in registers the
-        // compiler had reused; fixed by tying the final wait to those registers) and routed around it; round 3
+        // compiler had reused; fixed by tying the final wait to those registers, profiles/HISTORY.md 9.5) and routed around it; round 3
         // validated the fix with the cold-launch stress test (tests/test_cold_launch_gpu.py: every hand-counted kernel as the first
         // GEMM of a fresh process on poisoned memory) and scripts/isa_lint.py.  EXL_GEMM_NO_TILE128=1 restores the detour.
         static const bool tile128 = getenv("EXL_GEMM_NO_TILE128") == nullptr;

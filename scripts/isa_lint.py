@@ -4,7 +4,7 @@
 Why: the hand-scheduled GEMM kernels issue their global loads from inline asm and count `s_waitcnt vmcnt(N)` by hand.  The
 compiler does not know that such a load is still WRITING its destination registers after the asm statement: if the value is
 dead in the source (the "redundant" last fetches of a straight-line loop) it may hand those registers to something else before
-the wait that covers the load -- round 2's 400 x 11008 garbage was exactly that: accumulators shuffled through
+the wait that covers the load -- round 2's 400 x 11008 garbage (profiles/HISTORY.md 9.5) was exactly that: accumulators shuffled through
 v4..v7 while a dwordx4 was still landing there.
 
 What: disassembles every kernel, replays the vector-memory queue the way the hardware counts it on gfx9-family parts (loads,
@@ -18,7 +18,7 @@ the same model), so every report is a hand-counting or liveness defect.
 A second, unrelated rule rides along (round 4): REGISTER COPIES IN MFMA LOOPS.  With a wide accumulator (16 registers per MFMA result,
 64 per wave in the prompt attention kernel) live across a branch, hipcc has kept the accumulators in two places and copied them
 every iteration -- 64-96 `v_mov_b64` beside 32 MFMAs, a third of the loop's issue slots, with nothing in the source to show for it
-("flash_prefill8_kernel").  Every innermost loop with >= 16 MFMAs is checked for the number of registers moved by
+(profiles/HISTORY.md 3, "flash_prefill8_kernel").  Every innermost loop with >= 16 MFMAs is checked for the number of registers moved by
 `v_mov_b32` / `v_mov_b64` / `v_accvgpr_*` per MFMA; the library's loops sit at <= 1.4, the defect at 4-6, the limit is 2.
 And a third for the one kernel that counts `lgkmcnt` by hand (flash_prefill8_kernel's K fragment reads): under every partial wait the
 LDS queue may hold one kind of LDS operation only and no scalar memory read (lgkm_count_hazards).

@@ -1,7 +1,7 @@
 """Dynamic guard for the hand-counted prefill kernels (reference path replaced: the reconstruct + cuBLAS matmul of
 /root/reference/exllama_ext/cuda_func/q4_matmul.cu:301-344).
 
-Round 2's defect: q4_gemm_t16m_kernel<2,2,4,4> wrote garbage into whole accumulator tiles ONLY on the first launch
+Round 2's defect (profiles/HISTORY.md 9.5): q4_gemm_t16m_kernel<2,2,4,4> wrote garbage into whole accumulator tiles ONLY on the first launch
 after an idle period, with a freshly copied activation tensor -- the compiler had recycled registers an inline-asm load was still
 writing.  The whole GPU suite was green with the bug present.  The static guard is scripts/isa_lint.py; this is the dynamic one:
 every kernel whose vector-memory waits are counted by hand is launched COLD -- in a fresh process, as the first GEMM after a 512 MB

@@ -1,5 +1,5 @@
 """The in-flight-register lint (scripts/isa_lint.py) over the built gfx950 code objects: no instruction may touch a VGPR that an
-outstanding (inline-asm, hand-counted) global load has not delivered yet.  Guards the defect class of DESIGN.md 9.5."""
+outstanding (inline-asm, hand-counted) global load has not delivered yet.  Guards the defect class of profiles/HISTORY.md 9.5."""
 import os
 import sys
 
