@@ -993,4 +993,6 @@ def test_perplexity_full_depth_7b():
         warnings.warn(f"perplexity straddles a rounding boundary: HIP {whole:.4f} vs oracle {ref:.4f} (standard error {rec['oracle_standard_error']:.3f})")
     else:
         assert f"{whole:.2f}" == f"{ref:.2f}"
-    assert abs(token - ref) < 0.02 and token < whole + 0.005, rec      # the path that sampled the text scores lowest (see the 2-layer test)
+    # token by token (op path; the text was sampled on the executor's graph, a third path): bounded as in the 2-layer test -- the KL term of
+    # scoring a text another path sampled is second order in the logit noise (measured at full depth: 8.520 vs 8.509 whole, 13B 3.6598 vs 3.6596)
+    assert abs(token - ref) < 0.02, rec
