@@ -859,9 +859,16 @@ def test_executor_refuses_an_adapter_on_an_act_order_o_proj():
     lora = ExLlamaLora(model, {"r": 8, "lora_alpha": 16}, "synthetic.bin", tensors=sd)
     with pytest.raises(RuntimeError, match="act-order"):
         model.enable_decode_graph(cache, lora=lora)
+    assert any("act-order o_proj" in w for w in model.executor_obstacles(lora=lora)) and model.executor_obstacles() == []
+    rep = model.decode_path_report(cache, lora=lora)                   # ... and the report names the tier that serves instead, and why
+    assert rep["tier"] == "ops_fused" and any("act-order o_proj" in w for w in rep["why_not_faster"]), rep
     ids = torch.randint(1, dims.vocab_size, (1, 9)).to("cuda:0")
     model.disable_decode_graph()
     assert torch.isfinite(model.forward(ids, cache, lora=lora)).all()       # the op path takes it
+    model.enable_decode_graph(cache)                                   # without the adapter the executor takes the model
+    rep = model.decode_path_report(cache, lora=lora)
+    assert rep["tier"] == "ops_fused" and any("act-order o_proj" in w for w in rep["why_not_faster"]), rep
+    assert model.decode_path_report(cache)["tier"] == "executor_graph"
     model.free_unmanaged()
 
 
