@@ -174,7 +174,7 @@ def perplexity_hip(dims, layers, groupsize, act_order, tokens=1536, seed=17, hea
     return rec, ids
 
 
-def perplexity_oracle(rec, ids, dims, log=None, tensors=None):
+def perplexity_oracle(rec, ids, dims, log=None, tensors=None, return_nll=False):
     """The oracle half: the CPU oracle's perplexity of the same text over ALL layers (weights dequantised one layer at a time, so a
     13B model needs a few GB of host memory, not 4 bytes per weight); completes and returns the record."""
     import time
@@ -203,11 +203,21 @@ def perplexity_oracle(rec, ids, dims, log=None, tensors=None):
     hn = O.rms_norm(hidden.reshape(-1, h), orc.norm_w, orc.eps)        # the tail of OracleLlama.forward
     lgo = (hn.astype(np.float32) @ orc.lm_head.astype(np.float32).T).astype(np.float16).astype(np.float32).reshape(bsz, q, -1)
     nll = -torch.log_softmax(torch.from_numpy(lgo), dim=-1).gather(-1, ids[:, 1:].unsqueeze(-1)).view(-1).double()
+    done = perplexity_record(rec, nll, time.time() - t1, say)
+    return (done, nll) if return_nll else done
+
+
+def perplexity_record(rec, nll, oracle_seconds=0.0, say=None):
+    """Completes a perplexity_hip record from the oracle's per-token negative log-likelihoods of the same text (computed just now by
+    perplexity_oracle, or read from tests/golden/ppl_full_depth_7b.npz when the sampled text is exactly the golden one)."""
+    import torch
+    say = say or (lambda *a: None)
+    nll = torch.as_tensor(nll).double().view(-1)
     n = int(nll.numel())
     ref = math.exp(float(nll.mean()))
     se = ref * float(nll.std()) / math.sqrt(n)                        # delta method: d exp(m) = exp(m) dm
     whole, token = rec["hip_whole"], rec["hip_token"]
-    say(f"oracle {ref:.4f} ({time.time() - t1:.1f} s)")
+    say(f"oracle {ref:.4f} ({oracle_seconds:.1f} s)")
     rec = dict(rec)
     rec.update({"tokens": n, "values": [whole, token, ref], "two_dp": [f"{whole:.2f}", f"{token:.2f}", f"{ref:.2f}"],
                 "delta_whole": whole - ref, "delta_token": token - ref,
@@ -216,7 +226,7 @@ def perplexity_oracle(rec, ids, dims, log=None, tensors=None):
                 "oracle_distance_to_rounding_boundary": abs((ref * 100) % 1.0 - 0.5) / 100,   # from the nearest x.xx5
                 "equal_to_2dp": f"{whole:.2f}" == f"{ref:.2f}",
                 "boundary_straddled": f"{whole:.2f}" != f"{ref:.2f}" and abs(whole - ref) < 0.005,
-                "oracle_seconds": round(time.time() - t1, 1)})
+                "oracle_seconds": round(oracle_seconds, 1)})
     return rec
 
 
