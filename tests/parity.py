@@ -222,7 +222,7 @@ def perplexity_record(rec, nll, oracle_seconds=0.0, say=None):
     rec.update({"tokens": n, "values": [whole, token, ref], "two_dp": [f"{whole:.2f}", f"{token:.2f}", f"{ref:.2f}"],
                 "delta_whole": whole - ref, "delta_token": token - ref,
                 "oracle_nll_std": float(nll.std()), "oracle_standard_error": se,
-                "delta_whole_over_standard_error": abs(whole - ref) / se,
+                "delta_whole_over_standard_error": abs(whole - ref) / se if se > 0 else float("inf"),
                 "oracle_distance_to_rounding_boundary": abs((ref * 100) % 1.0 - 0.5) / 100,   # from the nearest x.xx5
                 "equal_to_2dp": f"{whole:.2f}" == f"{ref:.2f}",
                 "boundary_straddled": f"{whole:.2f}" != f"{ref:.2f}" and abs(whole - ref) < 0.005,

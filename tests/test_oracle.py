@@ -241,3 +241,24 @@ def test_centered_nibbles_keep_a_deep_synthetic_model_in_the_fp16_range():
     a = synth.make_checkpoint(synth.LLAMA_TINY, seed=1, num_layers=1)
     b = synth.make_checkpoint(synth.LLAMA_TINY, seed=1, num_layers=1, nibbles="uniform")
     assert all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_perplexity_record_states_the_two_decimal_claim():
+    """tests/parity.py:perplexity_record -- the bookkeeping behind "perplexity equal to 2 dp": printed strings, |delta|, the standard
+    error of the estimate, and the one case in which equal values print differently (a straddled x.xx5 boundary)."""
+    import math
+    from parity import perplexity_record
+    nll = np.full(1535, math.log(8.1102))
+    nll[0:1534:2] += 0.3; nll[1:1534:2] -= 0.3                        # spread with zero mean: the perplexity stays 8.1102
+    ref = math.exp(float(nll.mean()))
+    rec = perplexity_record({"hip_whole": ref + 0.0033, "hip_token": ref + 0.004, "layers": 32}, nll)
+    assert rec["tokens"] == 1535 and rec["two_dp"][0] == rec["two_dp"][2] and rec["equal_to_2dp"] and not rec["boundary_straddled"]
+    assert abs(rec["delta_whole"] - 0.0033) < 1e-9 and abs(rec["oracle_standard_error"] - ref * float(np.std(nll, ddof=1)) / math.sqrt(1535)) < 1e-9
+    # a value 0.002 away from the oracle's, on the other side of 8.115: different strings, flagged as straddled, not as unequal values
+    nll2 = np.full(1535, math.log(8.1140))
+    rec2 = perplexity_record({"hip_whole": 8.1160, "hip_token": 8.1160, "layers": 32}, nll2)
+    assert rec2["two_dp"][0] == "8.12" and rec2["two_dp"][2] == "8.11" and not rec2["equal_to_2dp"] and rec2["boundary_straddled"]
+    assert rec2["oracle_distance_to_rounding_boundary"] <= abs(rec2["delta_whole"]) < 0.005
+    # ... and a real disagreement is neither
+    rec3 = perplexity_record({"hip_whole": 8.20, "hip_token": 8.20, "layers": 32}, nll2)
+    assert not rec3["equal_to_2dp"] and not rec3["boundary_straddled"]
