@@ -562,7 +562,10 @@ def test_rms_norm_golden(ce, golden_dir):
 
 
 @pytest.mark.parametrize("bsz,q_len,heads,hd,past", [(1, 1, 32, 128, 0), (1, 1, 32, 128, 1919), (2, 3, 4, 32, 5),
-                                                     (1, 2048, 32, 128, 0), (1, 7, 8, 64, 100)])
+                                                     (1, 2048, 32, 128, 0), (1, 7, 8, 64, 100),
+                                                     # head_dim that is no multiple of 16 (OpenLLaMA-3B: 100; rope.cu:27-87 takes any even
+                                                     # width): the element-pair kernel
+                                                     (1, 1, 32, 100, 77), (2, 9, 4, 100, 3), (1, 300, 8, 36, 0)])
 def test_rope_bit_exact(ce, bsz, q_len, heads, hd, past):
     gen = torch.Generator().manual_seed(q_len + heads)
     sin, cos = O.rope_tables(max(2048, past + q_len), hd)
@@ -607,6 +610,22 @@ def test_update_cache_bit_exact(ce):
     assert np.array_equal(vc.cpu().numpy().view(np.uint16), rv.view(np.uint16))
     with pytest.raises(RuntimeError, match="exceeds max_seq_len"):
         ce.exllama_ext.update_cache(k.to(DEV), v.to(DEV), kc, vc, max_seq - 1)
+    # head_dim 100 (no multiple of 8: the 4-byte copy kernel), also with the position on the device
+    bsz, q_len, kvh, hd, max_seq, past = 2, 5, 32, 100, 40, 11
+    k = torch.randn(bsz, q_len, kvh * hd, generator=gen).half()
+    v = torch.randn(bsz, q_len, kvh * hd, generator=gen).half()
+    rk = np.zeros((bsz, kvh, max_seq, hd), dtype=np.float16)
+    rv = np.zeros_like(rk)
+    O.update_cache(k.numpy(), v.numpy(), rk, rv, past)
+    for dev_pos in (False, True):
+        kc = torch.zeros(bsz, kvh, max_seq, hd, dtype=torch.float16, device=DEV)
+        vc = torch.zeros_like(kc)
+        if dev_pos:
+            ce.exllama_ext.update_cache(k.to(DEV), v.to(DEV), kc, vc, 0, past_len_dev=torch.tensor([past], dtype=torch.int32, device=DEV))
+        else:
+            ce.exllama_ext.update_cache(k.to(DEV), v.to(DEV), kc, vc, past)
+        assert np.array_equal(kc.cpu().numpy().view(np.uint16), rk.view(np.uint16))
+        assert np.array_equal(vc.cpu().numpy().view(np.uint16), rv.view(np.uint16))
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -677,6 +696,13 @@ def test_attention_decode_variants(ce):
     _attn_case(ce, 1, 3, 8, 8, 128, 10, 64, seed=2)                # short q_len: causal inside the new tokens
     _attn_case(ce, 1, 1, 4, 4, 128, 500, 2048, seed=3, dev_pos=True)
     _attn_case(ce, 2, 5, 4, 2, 32, 6, 32, seed=4, with_mask=True)  # additive padding mask (model.py:1016-1026)
+    # head_dim % 8 != 0 (OpenLLaMA-3B: 100): 8-byte accesses, 32 lanes per key row; decode, a short prompt, a long one (no flash kernel for
+    # this width: the split-KV kernel serves every query row), GQA, NaN behind the last key
+    _attn_case(ce, 1, 1, 32, 32, 100, 700, 1024, seed=5, poison=True)
+    _attn_case(ce, 2, 6, 8, 4, 100, 19, 64, seed=6, with_mask=True)
+    _attn_case(ce, 1, 150, 4, 4, 100, 0, 256, seed=7, poison=True)
+    _attn_case(ce, 1, 1, 4, 2, 36, 90, 128, seed=8, dev_pos=True)     # 9 lanes of 4 halves -> 16 lanes per key row
+    _attn_case(ce, 1, 2, 2, 2, 200, 33, 64, seed=9)                   # 50 lanes -> 64 lanes per key row
 
 
 @pytest.mark.parametrize("q_len,past,heads,kvh", [(16, 0, 4, 4), (128, 0, 4, 4), (200, 0, 8, 2), (333, 45, 4, 4), (64, 1000, 2, 2)])
