@@ -62,6 +62,9 @@ def parse_args():
     p.add_argument("--no-other-configs", action="store_true",
                    help="default 7B run on one GPU: do not run BASELINE configs[2..4] (13B act-order, 33B g32 act-order, 65B) and the drop-in "
                         "path as sub-runs after the headline")
+    p.add_argument("--sharded-at-one-gpu", action="store_true",
+                   help="test aid: run the sharded sub-runs (one-rank RCCL groups) behind a --gpus 1 headline too, so that the launching "
+                        "machinery of the N > 1 line is exercised on a one-GPU box")
     p.add_argument("--no-sharded", action="store_true",
                    help="--gpus N > 1: do not run the sharded sub-runs (--layer-split / --tensor-parallel over the same N GPUs) after the "
                         "replica headline")
@@ -194,8 +197,8 @@ def layer_split_main(args, dims, L, S, G, rank, world, dev, dist):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if line is not None:                                           # the contract's ONE JSON line is the last thing on stdout (RCCL prints its
-        print(line, flush=True)                                    # version banner there when the communicator goes, if NCCL_DEBUG asks for it)
+    if line is not None:                                           # the contract's ONE JSON line is the last thing on stdout
+        _print_last(line)
 
 
 def tensor_parallel_main(args, dims, L, S, G, rank, world, dev, dist):
@@ -287,8 +290,21 @@ def tensor_parallel_main(args, dims, L, S, G, rank, world, dev, dist):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if line is not None:                                           # the contract's ONE JSON line is the last thing on stdout (RCCL prints its
-        print(line, flush=True)                                    # version banner there when the communicator goes, if NCCL_DEBUG asks for it)
+    if line is not None:                                           # the contract's ONE JSON line is the last thing on stdout
+        _print_last(line)
+
+
+def _print_last(line):
+    """The contract's ONE JSON line must be the LAST thing on stdout.  RCCL writes its version banner through C stdio, which is fully
+    buffered when stdout is a file or pipe and would otherwise be flushed AFTER this line, at exit (seen on the GPU box: five banner
+    lines behind the JSON): flush the C buffers first, then write the line unbuffered."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                                 # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    print(line, flush=True)
 
 
 def device_state():
@@ -584,8 +600,9 @@ def main():
     # number in the line is measured in THIS invocation.  A sub-run that fails or times out leaves an {"error": ...} record.
     extras_ok = rank == 0 and not args.brief and args.model == "7b" and args.groupsize == 128 and not args.act_order and args.layers is None
     if extras_ok and world == 1:
-        del model, cache
-        torch.cuda.empty_cache()
+        if not args.sharded_at_one_gpu:
+            del model, cache
+            torch.cuda.empty_cache()
         if not args.no_other_configs:
             # BASELINE configs[2..4] on this one GPU (every model fits 288 GB): same protocol, fewer steps
             result["other_configs"] = {
@@ -604,7 +621,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if extras_ok and world > 1 and not args.no_sharded:
+    if extras_ok and (world > 1 or args.sharded_at_one_gpu) and not args.no_sharded:
         # the replicas are done and every other rank is exiting (its GPU is free): rank 0 launches ONE model sharded over the same N GPUs
         # -- the reference's layer split (model.py:636-668; P2P hidden-state hand-off over RCCL) and the tensor-parallel mode -- each as
         # its own torch.distributed.run job with a time limit, so a hang or crash there cannot take the replica headline with it
@@ -612,8 +629,8 @@ def main():
         torch.cuda.empty_cache()
         time.sleep(3.0)
         result["sharded"] = sharded_runs(world)
-    if rank == 0:                                                  # the ONE JSON line last (after RCCL's teardown output, if any)
-        print(json.dumps(result), flush=True)
+    if rank == 0:                                                  # the ONE JSON line last (after RCCL's output, if any)
+        _print_last(json.dumps(result))
 
 
 def _last_json_line(text):
