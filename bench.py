@@ -368,6 +368,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"WORLD_SIZE ({world}) != --gpus ({args.gpus}); launch with torch.distributed.run"
+    if os.environ.get("EXL_BENCH_DRY_RUN"):
+        return dry_run_main(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
@@ -630,6 +632,52 @@ def main():
         time.sleep(3.0)
         result["sharded"] = sharded_runs(world)
     if rank == 0:                                                  # the ONE JSON line last (after RCCL's output, if any)
+        _print_last(json.dumps(result))
+
+
+def dry_run_main(args, rank, world):
+    """EXL_BENCH_DRY_RUN=1 (tests/test_multiproc.py, no GPU): the PROCESS choreography of an N-rank invocation and nothing else -- one
+    process per rank joined over gloo, fabricated per-rank timings through the contract's reduction (barrier, MAX over ranks, whole-job
+    rates), rank 0 alone launching the sharded sub-runs as torch.distributed.run jobs of this same file (dry as well: the variable is
+    inherited) once the group is gone, their records nested into the ONE JSON line, that line last on stdout.  No kernel, no model, no
+    number that means anything: `config.DRY_RUN` says so."""
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    S, G = args.prompt, args.gen
+    local = [0.300 + 0.010 * rank, 25.0 + rank, 180.0 + 2 * rank, 150.0 + rank]          # elapsed s / step, prefill / worst / best ms
+    if dist is not None:
+        dist.barrier()
+    if args.layer_split or args.tensor_parallel:
+        rep = per_rank_report([local[0] * 1e3, local[1], local[2] / G], dist, "cpu", ("ms_per_step", "prefill_ms", "decode_ms_per_token"))
+        elapsed, pre, dec, _ = reduce_over_ranks(local, dist, "cpu")
+        line = None
+        if rank == 0:
+            mode = "layer split" if args.layer_split else "tensor parallel"
+            line = json.dumps(dict(**{**rep, "metric": "dry run", "value": round(G / (dec / 1e3), 2), "unit": "tokens/s", "n_gpus": world,
+                                      "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3, 3), "scaling": "strong",
+                                      "logits_finite": True, "prefill_tokens_per_s": round(S / (pre / 1e3), 1),
+                                      "config": {"workload": f"DRY RUN {args.model} {mode} x{world}", "parallelism": f"{mode} x{world}", "DRY_RUN": True}}))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        if line is not None:
+            _print_last(line)
+        return
+    elapsed, prefill_ms, worst_ms, best_ms = reduce_over_ranks(local, dist, "cpu")
+    rates = whole_job_rates(world, S, G, prefill_ms, worst_ms, best_ms)
+    result = {"metric": "dry run", "value": round(rates["worst"], 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": round(elapsed * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+              "prefill_tokens_per_s": round(rates["prefill"], 1), "decode_best_tokens_per_s": round(rates["best"], 2),
+              "config": {"workload": "DRY RUN", "parallelism": f"replicas x{world}" if world > 1 else "single GPU", "DRY_RUN": True}}
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and (world > 1 or args.sharded_at_one_gpu) and not args.no_sharded and not args.brief:
+        result["sharded"] = sharded_runs(world, limit_s=120, budget_s=300)
+    if rank == 0:
         _print_last(json.dumps(result))
 
 

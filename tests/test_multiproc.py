@@ -380,3 +380,34 @@ def test_host_staged_group_forwards_every_call():
         assert parts == [[0, 1, 2], [10, 11, 12], [20, 21, 22]]
         assert b == world - 1 and m == float(world - 1) and tok == want_tok
         assert ring == [float(v + (world - 1 if rank == 0 else rank - 1)) for v in range(4)]
+
+
+# ---- bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), DRY: the process choreography of the
+# N > 1 line under gloo on CPU -- both ranks through the barrier / MAX reduction, rank 0 alone launching the sharded sub-runs as
+# torch.distributed.run jobs of the same file once the group is gone, their records nested in the ONE JSON line, that line LAST on stdout.
+def test_bench_two_ranks_dry_run_prints_one_line_with_the_sharded_records():
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EXL_BENCH_DRY_RUN="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.strip()]
+    json_lines = [l for l in lines if l.startswith("{")]
+    assert len(json_lines) == 1 and lines[-1] == json_lines[0], lines[-3:]        # ONE line, and it is the last thing on stdout
+    d = json.loads(json_lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["DRY_RUN"] and d["scaling"] == "weak"
+    # MAX over ranks of the fabricated timings (rank 1 is the slower one), whole-job rate = 2 replicas
+    assert abs(d["ms_per_step"] - 310.0) < 1e-6 and abs(d["value"] - 2 * 128 / 0.182) < 0.01 and abs(d["prefill_tokens_per_s"] - 2 * 2048 / 0.026) < 0.1
+    sh = d["sharded"]
+    assert set(sh) == {"layer_split_7b", "layer_split_65b", "layer_split_33b_g32_actorder", "tensor_parallel_7b"}
+    for k, v in sh.items():
+        assert "error" not in v, (k, v)
+        assert v["n_gpus"] == 2 and v["rccl_ranks"] == 2 and v["backend"] == "gloo" and v["scaling"] == "strong" and v["logits_finite"]
+        assert [p["rank"] for p in v["per_rank"]] == [0, 1]
+        assert ("layer split x2" in v["decode_mode"]) == k.startswith("layer_split")
