@@ -62,6 +62,23 @@ def code_objects(so_path, workdir):
     return out
 
 
+def kernel_resources(so_path, workdir):
+    """Per kernel of the library, what the code object's metadata says it occupies: {name: dict(vgpr, agpr, sgpr, scratch, lds, threads)}
+    (llvm-readelf --notes: .vgpr_count, .agpr_count, .sgpr_count, .private_segment_fixed_size = scratch bytes per lane,
+    .group_segment_fixed_size = static LDS, .max_flat_workgroup_size).  tests/test_kernel_resources.py holds the occupancy
+    assumptions of DESIGN.md against it."""
+    out = {}
+    for co in code_objects(so_path, workdir):
+        txt = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+        for blk in txt.split("  - .agpr_count:")[1:]:
+            blk = ".agpr_count:" + blk
+            get = lambda k: re.search(r"\." + k + r":\s+(\S+)", blk).group(1)     # noqa: E731
+            out[get("name")] = dict(vgpr=int(get("vgpr_count")), agpr=int(get("agpr_count")), sgpr=int(get("sgpr_count")),
+                                    scratch=int(get("private_segment_fixed_size")), lds=int(get("group_segment_fixed_size")),
+                                    threads=int(get("max_flat_workgroup_size")))
+    return out
+
+
 def disassemble(co):
     """{kernel name: [(addr, mnemonic, operands)]}"""
     txt = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
