@@ -93,26 +93,26 @@ int exl_sampler_workspace(int device, size_t bytes, void** out)
 int exl_gemm_workspace(int device, size_t floats, float** out)
 {
     EXL_REQUIRE(device >= 0 && device < EXL_MAX_DEVICES, EXL_E_INVALID, "invalid device index %d", device);
-    // growth is serialised: two host threads running prompt passes on one device must not both free / allocate the buffer.
-    // Callers treat a non-zero return as "run the variant that needs no workspace" (launch_q4_gemm, plan_gemm_tail, half GEMM).
+    // QUIET on "no room": every caller treats a non-zero return as "run the variant that needs no workspace" (launch_q4_gemm's probe,
+    // plan_gemm_tail, the half GEMM) -- a message left in exl_last_error() here would be attached to some later, unrelated failure.
+    // Growth is serialised, and a buffer that has been handed out is never freed while the process lives: another host thread may hold
+    // the old pointer without having launched yet (the superseded buffers are kept, at most a handful: each growth is >= 1.25 x).
     static std::mutex grow_lock;
     std::lock_guard<std::mutex> hold(grow_lock);
     DeviceBuffers* b = &g_buffers[device];
     if (b->gemm_ws_floats < floats) {
-        if (floats > ((size_t) 512 << 20) / sizeof(float))
-            EXL_FAIL(EXL_E_TOO_SMALL, "GEMM workspace: %zu floats requested, the cap is 512 MiB", floats);
+        if (floats > ((size_t) 512 << 20) / sizeof(float)) return EXL_E_TOO_SMALL;
         int prev = 0;
         EXL_HIP(hipGetDevice(&prev));
         EXL_HIP(hipSetDevice(device));
-        if (b->gemm_ws) (void) hipFree(b->gemm_ws);         // (hipFree waits for the kernels still reading the old buffer)
-        b->gemm_ws = nullptr; b->gemm_ws_floats = 0;
         const size_t want = floats + floats / 4;             // head room: the next shape rarely needs a new allocation
-        const hipError_t e = hipMalloc((void**) &b->gemm_ws, want * sizeof(float));
+        float* fresh = nullptr;
+        const hipError_t e = hipMalloc((void**) &fresh, want * sizeof(float));
         (void) hipSetDevice(prev);
-        if (e != hipSuccess) {
-            (void) hipGetLastError();
-            EXL_FAIL(EXL_E_TOO_SMALL, "GEMM workspace: hipMalloc of %zu bytes failed (%s)", want * sizeof(float), hipGetErrorString(e));
-        }
+        if (e != hipSuccess) { (void) hipGetLastError(); return EXL_E_TOO_SMALL; }
+        static std::vector<float*> retired;                  // (never freed: see above)
+        if (b->gemm_ws) retired.push_back(b->gemm_ws);
+        b->gemm_ws = fresh;
         b->gemm_ws_floats = want;
     }
     *out = b->gemm_ws;

@@ -122,7 +122,7 @@ int launch_q4_gemm(const Q4Matrix* w, const f16* x, int rows, f16* out, int no_z
 // RMSNorm(x) (written to `tmp`); act-order matrices that share one map get their input gathered ONCE into `tmp` (by the norm
 // kernel when there is one, else by column_remap).  `tmp` must hold rows * K halves whenever either applies.
 struct PromptPrologue { const f16* norm_w; float eps; f16* tmp; size_t tmp_numel; };
-bool q4_same_map(const Q4Matrix* a, const Q4Matrix* b);      // both without a map, or maps with equal (height, hash)
+bool q4_same_map(const Q4Matrix* a, const Q4Matrix* b);      // both without a map, or maps of equal height whose entries are equal (hash first, then confirmed entry by entry)
 int launch_q4_qkv_rope_cache(const Q4Matrix* wq, const Q4Matrix* wk, const Q4Matrix* wv, const f16* x, int rows, f16* q_out,
                              const f16* sin, const f16* cos, f16* kc, f16* vc, int q_len, int heads, int kv_heads, int head_dim,
                              int past_len, int max_seq, const PromptPrologue& pro, hipStream_t s);

@@ -1459,7 +1459,7 @@ static int launch_gemm_t16m(const Q4Matrix* w, const f16* xin, int rows, f16* ou
     static bool big[EXL_MAX_DEVICES] = {};
     if (smem > 64 * 1024) EXL_TRY(exl_lds_opt_in((const void*) kfn, big));
     float* ws = nullptr;
-    if constexpr (KS > 1) EXL_TRY(exl_gemm_workspace(w->device, (size_t) KS * rows * N, &ws));
+    if constexpr (KS > 1) { if (exl_gemm_workspace(w->device, (size_t) KS * rows * N, &ws) != 0) EXL_FAIL(EXL_E_TOO_SMALL, "q4 GEMM: no room for the split-K workspace (%zu floats)", (size_t) KS * rows * N); }
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(WAVES_M * WAVES_N * 64), smem, s, xin, (const uint4*) w->qweight, w->qzeros,
                        w->scales, out, rows, K, N, gshift, w->groupsize, no_zero, mtiles, ntiles, ws);
     EXL_LAUNCH_CHECK();

@@ -411,3 +411,24 @@ def test_bench_two_ranks_dry_run_prints_one_line_with_the_sharded_records():
         assert v["n_gpus"] == 2 and v["rccl_ranks"] == 2 and v["backend"] == "gloo" and v["scaling"] == "strong" and v["logits_finite"]
         assert [p["rank"] for p in v["per_rank"]] == [0, 1]
         assert ("layer split x2" in v["decode_mode"]) == k.startswith("layer_split")
+
+
+def test_bench_gpus_2_without_a_launcher_launches_itself():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how the driver starts the N = 1 run): bench.py re-executes itself
+    under torch.distributed.run instead of dying on the WORLD_SIZE assert -- same ONE line, n_gpus 2 (dry run; --no-sharded keeps it short)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EXL_BENCH_DRY_RUN="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-sharded"],
+                       capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.strip()]
+    json_lines = [l for l in lines if l.startswith("{")]
+    assert len(json_lines) == 1 and lines[-1] == json_lines[0], lines[-3:]
+    d = json.loads(json_lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["DRY_RUN"] and d["scaling"] == "weak" and "sharded" not in d
+    assert abs(d["ms_per_step"] - 310.0) < 1e-6
