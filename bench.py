@@ -94,12 +94,38 @@ def decode_bytes_per_token(dims, g, ctx):
     return weights + kv
 
 
-def prefill_flops(dims, S):
+def prefill_flops(dims, S, causal=False):
+    """SURVEY.md 8d counts the attention of a prompt as 4 * S^2 * h per layer (every key for every query); the kernels skip the
+    masked half: causal=True counts what is actually multiplied (S (S + 1) / 2 pairs).  Both ride in path_roofline.prefill."""
     h, I, L, V = dims.hidden_size, dims.intermediate_size, dims.num_hidden_layers, dims.vocab_size
     kvd = dims.num_key_value_heads * dims.head_dim
     linear = 2 * S * L * (2 * h * h + 2 * h * kvd + 3 * h * I)
-    attn = 4 * S * S * h * L
+    attn = 4 * (S * (S + 1) // 2 if causal else S * S) * h * L
     return linear + attn + 2 * h * V
+
+
+def rocprof_average_us(kernel_substring):
+    """Average launch duration of a kernel from the newest committed profiles/rNN_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of
+    this same command, collected by scripts/gpu_rNN_profiles.sh): the figure the event timing beside it must agree with.  (None, None) when
+    there is no such file / row."""
+    import csv
+    import glob
+    import re
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")):
+        m = re.match(r"r(\d+)_bench_kernel_stats\.csv$", os.path.basename(path))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), path)
+    if best is None:
+        return None, None
+    try:
+        with open(best[1]) as f:
+            for row in csv.DictReader(f):
+                if kernel_substring in row.get("Name", ""):
+                    return round(float(row["AverageNs"]) / 1e3, 3), "profiles/" + os.path.basename(best[1])
+    except Exception:                                                 # noqa: BLE001
+        pass
+    return None, None
 
 
 def layer_split_main(args, dims, L, S, G, rank, world, dev, dist):
@@ -583,7 +609,10 @@ def main():
         "decode_best": {"bytes_per_token": int(b_best), "achieved_GBps": round(b_best / (best_ms / G / 1e3) / 1e9, 1),
                         "frac_of_8TBps": round(b_best / (best_ms / G / 1e3) / 1e9 / HBM_PEAK_GBS, 4)},
         "prefill": {"flops": prefill_flops(full, S), "achieved_TFLOPs": round(prefill_flops(full, S) / (prefill_ms / 1e3) / 1e12, 1),
-                    "frac_of_2.5PF": round(prefill_flops(full, S) / (prefill_ms / 1e3) / 1e12 / MFMA_PEAK_TFLOPS, 4)},
+                    "frac_of_2.5PF": round(prefill_flops(full, S) / (prefill_ms / 1e3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                    "flops_causal": prefill_flops(full, S, causal=True),
+                    "frac_of_2.5PF_causal": round(prefill_flops(full, S, causal=True) / (prefill_ms / 1e3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                    "note": "flops: SURVEY.md 8d's count (attention 4 S^2 h per layer); flops_causal: the masked half not counted -- what the kernels multiply"},
     }
 
     # ---- dominant-kernel roofline: the q4 decode GEMV, timed per launch with HIP events on the launch stream --
@@ -891,6 +920,8 @@ def decoder_roofline_probe(model, cache, dims, g, ctx, steps=6):
             "traffic": traffic,
             "traffic_source": pmc_src if traffic else None,
             "launches": L * steps, "avg_launch_us": round(ms[dom] * 1e3 / L, 3),
+            "rocprof_avg_us": rocprof_average_us("dec_ring_kernel<3, 8, 1, 2,")[0] if (h, I, g) == (4096, 11008, 128) else None,
+            "rocprof_source": rocprof_average_us("dec_ring_kernel<3, 8, 1, 2,")[1] if (h, I, g) == (4096, 11008, 128) else None,
             "algorithmic_bytes_per_launch": int(per_launch[dom]), "classes": classes,
             "token_ms_sum_of_classes": round(sum(ms.values()), 4),
             "note": "per class: %d passes over all %d layers' launches of that kernel, back to back between two HIP events on the "

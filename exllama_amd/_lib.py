@@ -53,6 +53,11 @@ SIGNATURES = {
     "exl_q4_attn_prompt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                            c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, C.POINTER(c_int)]),
     "exl_q4_mlp_prompt": (c_int, [c_void_p, c_void_p, C.c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, C.POINTER(c_int)]),
+    "exl_q4_layer_prompt": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float] + [c_void_p] * 7 + [c_void_p] * 4 + [c_int] * 4 +
+                            [c_void_p, c_void_p, c_size_t, c_int, C.POINTER(c_int), C.POINTER(c_int)]),
+    "exl_frag_bytes": (C.c_size_t, [c_int, c_int]),
+    "exl_q4_matmul_frag": (c_int, [C.POINTER(c_void_p), c_int, c_void_p, c_int, c_void_p, c_float, C.POINTER(c_void_p), c_int, c_int, c_void_p, c_int,
+                           c_void_p, c_void_p, c_int, c_void_p, C.POINTER(c_int), C.POINTER(c_int)]),
     "exl_q4_matmul_lora": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "exl_q4_reconstruct": (c_int, [c_void_p, c_void_p, c_void_p]),
     "exl_column_remap": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -502,6 +502,140 @@ extern "C" int exl_q4_mlp_prompt(void* x, const void* norm_w, float eps, void* g
     return q4_gemm(dm, act, rows, x, 1, bufs->temp_state, bufs->temp_state_numel, s);
 }
 
+// One decoder layer for a SHORT prompt (2 .. EXL_GEMM_SKINNY_MAX = 256 rows: BASELINE configs[0]'s 128-token prompt, a chat turn),
+// in place on the residual stream x [bsz * q_len, hidden] -- what the reference runs per layer as rms_norm, three q4_matmul, two
+// rope_, the cache copies, ATen attention, q4_matmul, rms_norm, two q4_matmul, silu_mul, q4_matmul from Python (model.py:421-552),
+// here ten launches enqueued by ONE call: RMSNorm -> fragment order | q / k / v GEMM | RoPE + cache | attention | re-tile | o_proj
+// (+ residual) | RMSNorm -> fragment order | gate / up GEMM + SiLU * mul (fragment-order output) | down_proj (+ residual)
+// (q4_gemm_frag.hip: why fragment order).  *launched = 0 and nothing enqueued when the layer is not covered (row count, layout, a map on
+// down_proj, maps of q / k / v or gate / up that differ): the caller runs the ops one by one.
+extern "C" int exl_q4_layer_prompt(void* x, int bsz, int q_len, int past_len, const void* in_norm_w, const void* post_norm_w, float eps,
+                                   void* wq, void* wk, void* wv, void* wo, void* wgate, void* wup, void* wdown, const void* sin, const void* cos,
+                                   void* key_cache, void* value_cache, int heads, int kv_heads, int head_dim, int max_seq_len, void* stream,
+                                   float* rowsq, size_t rowsq_floats, int rowsq_in_slots, int* rowsq_out_slots, int* launched)
+{
+    EXL_REQUIRE(launched, EXL_E_INVALID, "q4_layer_prompt: launched is null");
+    *launched = 0;
+    if (rowsq_out_slots) *rowsq_out_slots = 0;
+    Q4Matrix* m[7] = {q4_from_handle(wq), q4_from_handle(wk), q4_from_handle(wv), q4_from_handle(wo), q4_from_handle(wgate),
+                      q4_from_handle(wup), q4_from_handle(wdown)};
+    for (int i = 0; i < 7; ++i) EXL_REQUIRE(m[i], EXL_E_INVALID, "q4_layer_prompt: invalid q4 handle");
+    EXL_REQUIRE(bsz >= 0 && q_len >= 0 && past_len >= 0, EXL_E_INVALID, "q4_layer_prompt: negative size");
+    const int rows = bsz * q_len;
+    if (rows == 0) { *launched = 1; return 0; }
+    EXL_REQUIRE(x && in_norm_w && post_norm_w && sin && cos && key_cache && value_cache, EXL_E_INVALID, "q4_layer_prompt: null tensor pointer");
+    EXL_REQUIRE(past_len + q_len <= max_seq_len, EXL_E_INVALID, "q4_layer_prompt: past_len %d + q_len %d exceeds the cache length %d",
+                past_len, q_len, max_seq_len);
+    static const int skinny_max = getenv("EXL_GEMM_SKINNY_MAX") ? atoi(getenv("EXL_GEMM_SKINNY_MAX")) : 256;
+    static const bool off = getenv("EXL_GEMM_NO_FRAG") != nullptr;      // A/B switch: the op-by-op short-prompt path
+    if (off || rows < 2 || rows > skinny_max) return 0;
+    const int h = m[0]->height, inter = m[4]->width, qd = heads * head_dim, kvd = kv_heads * head_dim;
+    if (m[0]->width != qd || m[1]->width != kvd || m[2]->width != kvd || m[3]->height != qd || m[3]->width != h || m[5]->width != inter ||
+        m[4]->height != h || m[5]->height != h || m[6]->height != inter || m[6]->width != h || head_dim % 16 != 0) return 0;
+    for (int i = 0; i < 7; ++i) if (m[i]->layout != EXL_LAYOUT_T16 || m[i]->device != m[0]->device) return 0;
+    if (!q4_same_map(m[1], m[0]) || !q4_same_map(m[2], m[0]) || !q4_same_map(m[5], m[4]) || m[6]->x_map) return 0;
+    const Q4Matrix* qkv[3] = {m[0], m[1], m[2]};
+    const Q4Matrix* om[1] = {m[3]};
+    const Q4Matrix* gu[2] = {m[4], m[5]};
+    const Q4Matrix* dm[1] = {m[6]};
+    if (!gemm_t16r_covers(3, qkv, rows, 0) || !gemm_t16r_covers(1, om, rows, 0) || !gemm_t16r_covers(2, gu, rows, 1) ||
+        !gemm_t16r_covers(1, dm, rows, 0)) return 0;                 // group sizes / widths the fragment-order kernel is not built for
+    DeviceGuard guard(m[0]->device);
+    EXL_REQUIRE(guard.ok, EXL_E_INVALID, "q4_layer_prompt: cannot select device %d", m[0]->device);
+    // scratch (the library's own growing workspace: independent of what prepare_buffers was given)
+    const size_t b_xf = frag_bytes(rows, h), b_q = (size_t) rows * qd * 2, b_kv = (size_t) rows * kvd * 2, b_af = frag_bytes(rows, qd),
+                 b_act = frag_bytes(rows, inter);
+    auto al = [](size_t v) { return (v + 255) & ~(size_t) 255; };
+    const size_t b_sq = (size_t) rows * (size_t) (h / 32 + 4) * 4;    // o_proj's per-row partial sums of squares (launch_gemm_t16r: slots <= N / 32 + 3)
+    const size_t total = al(b_xf) + 2 * al(b_q) + 2 * al(b_kv) + al(b_af) + al(b_act) + al(b_sq);
+    float* wsf = nullptr;
+    if (exl_gemm_workspace(m[0]->device, (total + 3) / 4, &wsf) != 0) return 0;
+    unsigned char* p = (unsigned char*) wsf;
+    void* xf = p; p += al(b_xf);
+    f16* q = (f16*) p; p += al(b_q);
+    f16* attn = (f16*) p; p += al(b_q);
+    f16* k = (f16*) p; p += al(b_kv);
+    f16* v = (f16*) p; p += al(b_kv);
+    void* af = p; p += al(b_af);
+    void* actf = p; p += al(b_act);
+    float* osq = (float*) p;
+    float* ws = nullptr;
+    EXL_TRY(exl_workspace(m[0]->device, 0, &ws));
+    hipStream_t s = (hipStream_t) stream;
+    f16* xh = (f16*) x;
+    f16* qkv_out[3] = {q, k, v};
+    // The sums of squares of the two RMSNorms come from the GEMM that wrote the residual stream last: o_proj's epilogue for the second
+    // norm (own scratch), the PREVIOUS layer's down_proj for the first -- through the caller's `rowsq` (rowsq_in_slots > 0: it holds
+    // what that call left there for exactly this x; the caller's contract, include/exl_amd.h).  Without them the norm reads whole rows.
+    const bool sq_in = rowsq && rowsq_in_slots > 0 && (size_t) rows * (size_t) rowsq_in_slots <= rowsq_floats;
+    EXL_TRY(launch_to_frag(xh, (const f16*) in_norm_w, eps, m[0]->x_map, xf, rows, h, s, sq_in ? rowsq : nullptr, sq_in ? rowsq_in_slots : 0));
+    int r = launch_gemm_t16r(3, qkv, xf, rows, qkv_out, 0, 0, nullptr, s);
+    EXL_REQUIRE(r != 1, EXL_E_UNSUPPORTED, "q4_layer_prompt: q / k / v launch refused after the dry run accepted it");
+    if (r) return r;
+    EXL_TRY(launch_rope_qk_cache(q, k, v, (f16*) key_cache, (f16*) value_cache, (const f16*) sin, (const f16*) cos, bsz, q_len, heads, kv_heads,
+                                 head_dim, max_seq_len, past_len, nullptr, s));
+    EXL_TRY(launch_attention(q, (const f16*) key_cache, (const f16*) value_cache, attn, nullptr, bsz, q_len, heads, kv_heads, head_dim, max_seq_len,
+                             past_len, nullptr, ws, exl_buffers(m[0]->device)->workspace_floats, s));
+    EXL_TRY(launch_to_frag(attn, nullptr, 0.f, m[3]->x_map, af, rows, qd, s));
+    f16* o_out[1] = {xh};
+    int o_slots = 0;
+    r = launch_gemm_t16r(1, om, af, rows, o_out, 1, 0, nullptr, s, 0, osq, &o_slots);
+    EXL_REQUIRE(r != 1, EXL_E_UNSUPPORTED, "q4_layer_prompt: o_proj not covered behind a covered q / k / v launch");
+    if (r) return r;
+    EXL_TRY(launch_to_frag(xh, (const f16*) post_norm_w, eps, m[4]->x_map, xf, rows, h, s, osq, o_slots));
+    r = launch_gemm_t16r(2, gu, xf, rows, nullptr, 0, 1, actf, s);
+    EXL_REQUIRE(r != 1, EXL_E_UNSUPPORTED, "q4_layer_prompt: gate / up not covered behind a covered attention half");
+    if (r) return r;
+    const bool sq_out = rowsq && rowsq_out_slots && (size_t) rows * (size_t) (h / 32 + 4) <= rowsq_floats;
+    int d_slots = 0;
+    r = launch_gemm_t16r(1, dm, actf, rows, o_out, 1, 0, nullptr, s, 0, sq_out ? rowsq : nullptr, &d_slots);
+    EXL_REQUIRE(r != 1, EXL_E_UNSUPPORTED, "q4_layer_prompt: down_proj not covered behind a covered attention half");
+    if (r) return r;
+    if (sq_out) *rowsq_out_slots = d_slots;
+    *launched = 1;
+    return 0;
+}
+
+// The short-prompt product by itself (what exl_q4_layer_prompt runs four times per layer): xf = fragment order of [RMSNorm(x) * norm_w |
+// x], gathered through w[0]'s act-order map, then outs[i] (+)= xf @ W_i, or -- dual -- out_frag = silu(xf @ W_0) * (xf @ W_1) in the
+// fragment order a consumer with K = width reads (exl_frag_bytes(rows, width) bytes).  `kernel`: 0 = the launcher's choice,
+// 1 = q4_gemm_t16r, 2 = q4_gemm_t16g at any width, 3 / 4 / 5 = its <4, 4> / <4, 2> / <8, 4> block shapes.
+extern "C" size_t exl_frag_bytes(int rows, int K) { return rows > 0 && K > 0 ? frag_bytes(rows, K) : 0; }
+
+extern "C" int exl_q4_matmul_frag(void* const* w, int nmat, const void* x, int rows, const void* norm_w, float eps, void* const* outs,
+                                  int no_zero, int dual, void* out_frag, int kernel, void* stream, const float* rowsq_in, int rowsq_in_slots,
+                                  float* rowsq_out, int* rowsq_out_slots, int* launched)
+{
+    if (rowsq_out_slots) *rowsq_out_slots = 0;
+    EXL_REQUIRE(launched, EXL_E_INVALID, "q4_matmul_frag: launched is null");
+    *launched = 0;
+    EXL_REQUIRE(w && nmat >= 1 && nmat <= 3 && (!dual || nmat == 2), EXL_E_INVALID, "q4_matmul_frag: 1 .. 3 matrices (dual: 2), got %d", nmat);
+    const Q4Matrix* m[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < nmat; ++i) {
+        m[i] = q4_from_handle(w[i]);
+        EXL_REQUIRE(m[i], EXL_E_INVALID, "q4_matmul_frag: invalid q4 handle");
+        EXL_REQUIRE(m[i]->device == m[0]->device && m[i]->height == m[0]->height, EXL_E_INVALID, "q4_matmul_frag: matrices differ in device or height");
+    }
+    EXL_REQUIRE(rows >= 0, EXL_E_INVALID, "q4_matmul_frag: negative row count");
+    if (rows == 0) { *launched = 1; return 0; }
+    EXL_REQUIRE(x && (dual ? out_frag != nullptr : outs != nullptr), EXL_E_INVALID, "q4_matmul_frag: null tensor pointer");
+    for (int i = 1; i < nmat; ++i) if (!q4_same_map(m[i], m[0])) return 0;
+    if (rows > 256 || !gemm_t16r_covers(nmat, m, rows, dual)) return 0;
+    DeviceGuard guard(m[0]->device);
+    EXL_REQUIRE(guard.ok, EXL_E_INVALID, "q4_matmul_frag: cannot select device %d", m[0]->device);
+    float* wsf = nullptr;
+    if (exl_gemm_workspace(m[0]->device, (frag_bytes(rows, m[0]->height) + 3) / 4, &wsf) != 0) return 0;
+    hipStream_t s = (hipStream_t) stream;
+    EXL_TRY(launch_to_frag((const f16*) x, (const f16*) norm_w, eps, m[0]->x_map, wsf, rows, m[0]->height, s, rowsq_in, rowsq_in ? rowsq_in_slots : 0));
+    f16* o[3] = {nullptr, nullptr, nullptr};
+    if (!dual) for (int i = 0; i < nmat; ++i) { o[i] = (f16*) outs[i]; EXL_REQUIRE(o[i], EXL_E_INVALID, "q4_matmul_frag: null output pointer"); }
+    const int r = launch_gemm_t16r(nmat, m, wsf, rows, o, no_zero, dual, out_frag, s, kernel, rowsq_out, rowsq_out_slots);
+    if (r == 1) return 0;
+    if (r) return r;
+    *launched = 1;
+    return 0;
+}
+
 extern "C" int exl_q4_matmul_lora(void* w, const void* x, int x_height, void* out, const void* lora_a,
                                   const void* lora_b, int rank, void* lora_temp, void* stream)
 {

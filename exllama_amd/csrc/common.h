@@ -135,6 +135,15 @@ int launch_dec_sample(float* logits, float* probs, int64_t* history, int64_t* to
 int launch_embedding(const int64_t* ids, const f16* table, f16* out, int n_ids, int hidden, int vocab, hipStream_t s);
 int launch_head_rows(const f16* x, const f16* w, float* out, int rows, int hidden, int vocab, hipStream_t s);   // 1 = not covered
 int launch_head_gemm(const f16* x, const f16* w, float* out, int rows, int hidden, int vocab, hipStream_t s);   // 1 = not covered; half_gemm_nt.hip
+// q4_gemm_frag.hip: short-prompt GEMMs on fragment-order activations
+size_t frag_bytes(int rows, int K);
+int launch_to_frag(const f16* x, const f16* norm_w, float eps, const uint32_t* x_map, void* xf, int rows, int K, hipStream_t s,
+                   const float* rowsq = nullptr, int nslots = 0);   // rowsq: the producer's per-row partial sums of squares (GrArgs::rowsq)
+// 1 = not covered; force: which kernel (0 = the launcher's choice); rowsq / rowsq_slots: per-row partial sums of the squares of the output
+// (one matrix, not dual) for the RMSNorm behind the launch: rowsq[row * *rowsq_slots + slot], rows x 512 floats suffice up to 16384 columns
+int launch_gemm_t16r(int nmat, const Q4Matrix* const* w, const void* xf, int rows, f16* const* outs, int no_zero, int dual, void* out_frag,
+                     hipStream_t s, int force = 0, float* rowsq = nullptr, int* rowsq_slots = nullptr);
+bool gemm_t16r_covers(int nmat, const Q4Matrix* const* w, int rows, int dual);
 int launch_rms_norm(const f16* x, const f16* w, f16* out, float eps, int rows, int dim, hipStream_t s);
 int launch_rms_norm_gather(const f16* x, const f16* w, f16* out, const uint32_t* x_map, float eps, int rows, int dim, hipStream_t s);   // x_map NULL: plain norm
 // decode_fused.hip: one fused executor launch for the op-level entry points (0 done, 1 not covered, > 1 error)

@@ -226,6 +226,81 @@ class _ExllamaExt:
                                               _stream(x), C.byref(done)), "q4_mlp_prompt")
         return bool(done.value)
 
+    def q4_layer_prompt(self, x, bsz, q_len, past_len, in_norm_weight, post_norm_weight, eps, wq, wk, wv, wo, wgate, wup, wdown, sin, cos,
+                        key_cache, value_cache, num_heads, num_kv_heads, head_dim, max_seq_len, rowsq=None, rowsq_in_slots=0):
+        """One decoder layer of a SHORT prompt (2 .. 256 rows), in place on the residual stream x [bsz * q_len, hidden]: every launch of
+        the layer enqueued by one call (include/exl_amd.h: exl_q4_layer_prompt).  Returns (taken, rowsq_out_slots); taken False: the
+        layer is not covered, nothing that touches x or the cache was launched.  rowsq (fp32 scratch, rows * (hidden / 32 + 4) floats):
+        carries the RMSNorm partial sums from this layer's down_proj to the next layer's call (rowsq_in_slots = what the previous call
+        returned, 0 when x was written by anything else since)."""
+        for t, n in ((x, "x"), (in_norm_weight, "input_layernorm"), (post_norm_weight, "post_attention_layernorm"), (key_cache, "key_cache"),
+                     (value_cache, "value_cache")):
+            _req_dtype(t, torch.float16, n)
+            _req_cuda(t, n)
+        _req(x.is_contiguous() and x.dim() == 2 and x.size(0) == bsz * q_len, "x must be a contiguous [bsz * q_len, hidden] tensor")
+        done, slots = C.c_int(), C.c_int()
+        if rowsq is not None:
+            _req_dtype(rowsq, torch.float32, "rowsq")
+            _req_cuda(rowsq, "rowsq")
+            _req(rowsq.is_contiguous() and rowsq.device == x.device, "rowsq must be a contiguous fp32 tensor on x's device")
+        with _Guard(x.device):
+            check(self._lib.exl_q4_layer_prompt(x.data_ptr(), bsz, q_len, past_len, in_norm_weight.data_ptr(), post_norm_weight.data_ptr(),
+                                                float(eps), wq, wk, wv, wo, wgate, wup, wdown, sin.data_ptr(), cos.data_ptr(),
+                                                key_cache.data_ptr(), value_cache.data_ptr(), num_heads, num_kv_heads, head_dim, max_seq_len,
+                                                _stream(x), rowsq.data_ptr() if rowsq is not None else None,
+                                                rowsq.numel() if rowsq is not None else 0, int(rowsq_in_slots) if rowsq is not None else 0,
+                                                C.byref(slots), C.byref(done)), "q4_layer_prompt")
+        return bool(done.value), int(slots.value)
+
+    def q4_matmul_frag(self, x, ws, outs=None, norm_weight=None, eps=0.0, no_zero=False, dual=False, kernel=0, rowsq_in=None, rowsq_out=None):
+        """The short-prompt product by itself (include/exl_amd.h: exl_q4_matmul_frag): x [rows, K] against 1 .. 3 matrices `ws` (handles)
+        in one launch -> `outs` (row-major tensors, written / accumulated in place), or dual=True: returns silu(x @ W0) * (x @ W1) in
+        FRAGMENT ORDER as a uint8 tensor of exl_frag_bytes(rows, width) bytes (unfrag() turns it back).  Returns None when the launch is not
+        covered.  rowsq_in = (fp32 tensor [rows, slots]) partial sums of squares of x for the norm; rowsq_out = fp32 tensor of at least
+        rows * (width / 32 + 4) elements that receives those of the (single) output: self.last_rowsq_slots says how many per row."""
+        _req_dtype(x, torch.float16, "x")
+        _req_cuda(x, "x")
+        _req(x.is_contiguous() and x.dim() == 2, "x must be a contiguous [rows, K] tensor")
+        rows = x.size(0)
+        harr = (C.c_void_p * len(ws))(*ws)
+        done, oslots = C.c_int(), C.c_int()
+        for t in (rowsq_in, rowsq_out):
+            if t is not None:
+                _req_dtype(t, torch.float32, "rowsq")
+                _req_cuda(t, "rowsq")
+                _req(t.is_contiguous(), "rowsq tensors must be contiguous")
+        oarr = None
+        frag = None
+        if dual:
+            info = self.q4_info(ws[0]) if hasattr(self, "q4_info") else None
+            width = info["width"] if info else None
+            _req(width is not None, "q4_matmul_frag: cannot read the matrix width")
+            frag = torch.zeros(int(self._lib.exl_frag_bytes(rows, width)), dtype=torch.uint8, device=x.device)
+        else:
+            for o in outs:
+                _req_dtype(o, torch.float16, "out")
+                _req_cuda(o, "out")
+                _req(o.is_contiguous() and o.size(0) == rows, "outputs must be contiguous [rows, width] tensors")
+            oarr = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+        with _Guard(x.device):
+            check(self._lib.exl_q4_matmul_frag(harr, len(ws), x.data_ptr(), rows, norm_weight.data_ptr() if norm_weight is not None else None,
+                                               float(eps), oarr, int(bool(no_zero)), int(bool(dual)), frag.data_ptr() if dual else None,
+                                               int(kernel), _stream(x), rowsq_in.data_ptr() if rowsq_in is not None else None,
+                                               rowsq_in.size(1) if rowsq_in is not None else 0,
+                                               rowsq_out.data_ptr() if rowsq_out is not None else None, C.byref(oslots), C.byref(done)),
+                  "q4_matmul_frag")
+        self.last_rowsq_slots = int(oslots.value)
+        if not done.value:
+            return None
+        return frag if dual else outs
+
+    @staticmethod
+    def unfrag(frag, rows, K):
+        """Fragment order -> row-major [rows, K] fp16 (index arithmetic of include/exl_amd.h: exl_q4_matmul_frag; tests)."""
+        pad = frag.numel() // (2 * K)
+        t = frag.view(torch.float16).view(pad // 16, K // 128, 4, 4, 16, 8)        # [mt][rb][j][kg][r][8]
+        return t.permute(0, 4, 1, 3, 2, 5).reshape(pad, K)[:rows].contiguous()     # row 16 mt + r, k 128 rb + 32 kg + 8 j + e
+
     def q4_reconstruct(self, w, out):
         _req_dtype(out, torch.float16, "out")
         _req_cuda(out, "out")
@@ -456,14 +531,19 @@ import warnings as _warnings
 
 FAST_BINDING = None
 FAST_BINDING_ERROR = None
-if not _os.environ.get("EXL_NO_FAST_BINDING"):
+def _env_on(name):
+    """An environment switch is ON when it is set to anything but "" / "0" (EXL_X=0 must not enable it)."""
+    return _os.environ.get(name, "") not in ("", "0")
+
+
+if not _env_on("EXL_NO_FAST_BINDING"):
     try:
         from . import _exl_fast as FAST_BINDING
-    except ImportError as e:
+    except (ImportError, OSError) as e:                               # (OSError: a dependency of the module that does not load)
         FAST_BINDING_ERROR = str(e)
         _msg = ("exllama_amd: the compiled binding exllama_amd/_exl_fast.so is missing or does not load (%s); build it with "
                 "`make -C exllama_amd/csrc`" % e)
-        if _os.environ.get("EXL_REQUIRE_FAST_BINDING"):
+        if _env_on("EXL_REQUIRE_FAST_BINDING"):
             raise RuntimeError(_msg) from e
         _warnings.warn(_msg + " -- continuing on the ctypes path (same kernels, 12-18 us more host time per op call)", RuntimeWarning)
     if FAST_BINDING is not None:

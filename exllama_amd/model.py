@@ -420,6 +420,8 @@ class ExLlamaDecoderLayer:
             normed = self.post_attention_layernorm.forward(hidden_states, buffer)
             self.mlp.forward_residual(normed, hidden_states, lora)
             return hidden_states
+        if 2 <= rows <= 256 and self._short_prompt(hidden_states, cache, buffer, lora):
+            return hidden_states
         if cfg.fused_attn and rows == 1:
             self.self_attn.fused(hidden_states, cache, buffer, self.input_layernorm, lora)
         else:                                                        # (the norms run inside: a long prompt takes them as launch prologues)
@@ -429,6 +431,39 @@ class ExLlamaDecoderLayer:
         else:
             self.mlp.forward_residual(None, hidden_states, lora, norm=self.post_attention_layernorm)
         return hidden_states
+
+
+    def _short_prompt(self, hidden_states, cache, buffer, lora):
+        """A short prompt (2 .. 256 rows: BASELINE configs[0], a chat turn): the whole layer as ONE native call -- ten launches on
+        fragment-order activations (csrc/q4_gemm_frag.hip) instead of the fourteen op-by-op launches the reference's loop drives
+        from Python (model.py:421-552).  False: not taken (an adapter, a bias, an attention mask, a shape the kernels do not cover)."""
+        a, m = self.self_attn, self.mlp
+        projs = (a.q_proj, a.k_proj, a.v_proj, a.o_proj, m.gate_proj, m.up_proj, m.down_proj)
+        if any(p.lora_applies(lora) or p.bias is not None for p in projs) or a.o_gather or m.down_gather:
+            return False
+        if (buffer is not None and buffer.needs_mask) or not hidden_states.is_contiguous():
+            return False
+        cfg = self.config
+        bsz, q_len, hid = hidden_states.shape
+        # RMSNorm's sums of squares travel from a layer's down_proj to the next layer's first norm in buffer.rowsq (include/exl_amd.h:
+        # exl_q4_layer_prompt); they are valid for THIS x only if the previous layer of the same pass left them for it
+        rowsq, slots, tag = None, 0, (hidden_states.data_ptr(), bsz * q_len, self.index - 1, str(hidden_states.device))
+        if buffer is not None:
+            need = bsz * q_len * (hid // 32 + 4)
+            rowsq = getattr(buffer, "rowsq", None)
+            if rowsq is None or rowsq.numel() < need or rowsq.device != hidden_states.device:
+                rowsq = buffer.rowsq = torch.empty(need, dtype=torch.float32, device=hidden_states.device)
+                buffer.rowsq_tag = None
+            if getattr(buffer, "rowsq_tag", None) == tag:
+                slots = buffer.rowsq_slots
+        done, out_slots = ext.q4_layer_prompt(hidden_states.view(-1, hid), bsz, q_len, cache.current_seq_len, self.input_layernorm.weight,
+                                              self.post_attention_layernorm.weight, self.input_layernorm.variance_epsilon, *(p.q4 for p in projs),
+                                              a.sin, a.cos, cache.key_states[self.index], cache.value_states[self.index], cfg.num_attention_heads,
+                                              cfg.num_key_value_heads, cfg.head_dim, cache.max_seq_len, rowsq=rowsq, rowsq_in_slots=slots)
+        if buffer is not None:
+            buffer.rowsq_slots = out_slots if done else 0
+            buffer.rowsq_tag = (tag[0], tag[1], self.index, tag[3]) if done and out_slots > 0 else None
+        return done
 
 
 class ExLlamaCache:

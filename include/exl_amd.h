@@ -132,6 +132,34 @@ int exl_q4_attn_prompt(void* wq, void* wk, void* wv, const void* x, const void* 
  * rows * intermediate halves.  Same `launched` protocol; gate / up must be dual-eligible (act-order: one shared map). */
 int exl_q4_mlp_prompt(void* x, const void* norm_w, float eps, void* gate, void* up, void* down, int rows, void* act, void* stream,
                       int* launched);
+/* One decoder layer of a SHORT prompt (2 .. 256 rows) in place on the residual stream: the launches that replace what the reference's
+ * model.py:421-552 drives op by op at this height (rms_norm, q / k / v q4_matmul, rope_ x 2, cache copy, attention, o_proj q4_matmul,
+ * rms_norm, gate / up q4_matmul, silu_mul, down_proj q4_matmul), enqueued by ONE call; the GEMMs read their activations in the MFMA's
+ * fragment order, written by their producers (csrc/q4_gemm_frag.hip).  *launched = 0: not covered (row count, a LoRA / bias is the
+ * caller's test, layouts, act-order maps that differ inside q / k / v or gate / up, a map on down_proj) -- run the ops one by one. */
+int exl_q4_layer_prompt(void* x, int bsz, int q_len, int past_len, const void* in_norm_w, const void* post_norm_w, float eps,
+                        void* wq, void* wk, void* wv, void* wo, void* wgate, void* wup, void* wdown, const void* sin, const void* cos,
+                        void* key_cache, void* value_cache, int heads, int kv_heads, int head_dim, int max_seq_len, void* stream,
+                        float* rowsq, size_t rowsq_floats, int rowsq_in_slots, int* rowsq_out_slots, int* launched);
+/* rowsq (optional, rows * (hidden / 32 + 4) floats; rowsq_floats = its size): the sums of squares RMSNorm needs travel from the GEMM that
+ * wrote the residual stream to the norm that reads it, as `slots` partial sums per row.  On return *rowsq_out_slots > 0 says: rowsq holds
+ * them for the x this call left behind.  Pass that number as rowsq_in_slots to the NEXT layer's call if -- and only if -- nothing has
+ * written x in between (same pointer, same rows); pass 0 otherwise (the first layer, a layer not taken by this entry point before): the
+ * norm then reads whole rows itself (slower, same result up to the order of an fp32 sum). */
+size_t exl_frag_bytes(int rows, int K);
+/* The short-prompt product by itself (the building block of exl_q4_layer_prompt; what the reference runs at this height as
+ * q4_matmul -> reconstruct + cuBLAS, exllama_ext.cpp:199-240, q4_matmul.cu:301-344): x [rows, K] row-major is turned into fragment
+ * order (with RMSNorm when norm_w != NULL, gathered through w[0]'s act-order map), then outs[i] (+)= x @ W_i for 1 .. 3 matrices of one
+ * launch, or (dual, nmat = 2) out_frag = silu(x @ W_0) * (x @ W_1) in the fragment order of a consumer with K = width:
+ *     out_frag[((mt * (K / 32) + 4 rb + j) * 64 + lane) * 16 .. + 16] = act[16 mt + (lane & 15)][128 rb + 32 (lane >> 4) + 8 j .. + 8]
+ * (exl_frag_bytes(rows, width) bytes: rows padded to 64, from 65 rows on to a multiple of 128).  kernel: 0 = the launcher's choice,
+ * 1 = activations in registers (narrow matrices), 2 .. 5 = activations shared through LDS (block shapes, csrc/q4_gemm_frag.hip).
+ * *launched = 0: not covered (more than 256 rows, layout, group size, maps that differ).
+ * rowsq_in / rowsq_in_slots: partial sums of squares of x for the RMSNorm (NULL / 0: the norm sums whole rows itself); rowsq_out: receives
+ * rowsq_out[row * *rowsq_out_slots + slot] for ONE output matrix (not dual; rows * (width / 32 + 4) floats), what the next norm adds up. */
+int exl_q4_matmul_frag(void* const* w, int nmat, const void* x, int rows, const void* norm_w, float eps, void* const* outs,
+                       int no_zero, int dual, void* out_frag, int kernel, void* stream, const float* rowsq_in, int rowsq_in_slots,
+                       float* rowsq_out, int* rowsq_out_slots, int* launched);
 /* out = x @ W + (x @ lora_A) @ lora_B   (reference: exllama_ext.cpp:245-324 q4_matmul_lora) */
 int exl_q4_matmul_lora(void* w, const void* x, int x_height, void* out, const void* lora_a, const void* lora_b,
                        int rank, void* lora_temp, void* stream);

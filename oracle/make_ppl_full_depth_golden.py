@@ -9,6 +9,7 @@ The text itself comes from the GPU (it is what the HIP path sampled): `scripts/p
 on an MI355X leaves DIR/ppl_7b_17.pt; this script (any host, no GPU) reads it, runs the oracle, and writes the fixture.
 
     python oracle/make_ppl_full_depth_golden.py gpurun_out/r05e/ppl/ppl_7b_17.pt
+    python oracle/make_ppl_full_depth_golden.py gpurun_out/r06f/ppl/ppl_13b_act_17.pt      (round 6: BASELINE configs[2], 40 layers, act-order)
 """
 import os
 import sys
@@ -27,9 +28,10 @@ def main():
     from parity import perplexity_oracle
     blob = torch.load(sys.argv[1])
     rec, ids = blob["rec"], blob["ids"]
-    assert rec["model"] == "7b" and rec["layers"] == 32 and rec["seed"] == 17
-    done, nll = perplexity_oracle(rec, ids, synth.PRESETS["7b"], log=lambda *a: print(*a, flush=True), return_nll=True)
-    out = os.path.join(ROOT, "tests", "golden", "ppl_full_depth_7b.npz")
+    dims = synth.PRESETS[rec["model"]]
+    assert rec["layers"] == dims.num_hidden_layers and rec["seed"] == 17
+    done, nll = perplexity_oracle(rec, ids, dims, log=lambda *a: print(*a, flush=True), return_nll=True)
+    out = os.path.join(ROOT, "tests", "golden", "ppl_full_depth_%s%s.npz" % (rec["model"], "_act" if rec.get("act_order") else ""))
     np.savez_compressed(out, ids=ids.numpy().astype(np.int32), oracle_nll=nll.numpy().astype(np.float64),
                         meta=np.array([rec["layers"], rec["groupsize"], rec["seed"], rec["ckpt_seed"], int(rec["head_scale"] * 1000)], dtype=np.int64))
     print("wrote", out, "oracle perplexity", done["values"][2], "HIP whole (at generation time)", done["values"][0])

@@ -88,6 +88,24 @@ def _truth_close(got, runs, truth, step, tag=""):
     assert g_blk <= TRUTH_FACTOR * o_blk + ulp, (tag, "16-element block", g_blk / scale, o_blk / scale)
 
 
+def _direct_steps_close(got_steps, runs, truth, tag="", well=1.0e-3):
+    """The float64 truth criterion above never compares a decode step with the fp16 ORACLE itself -- a defect of the truth model would
+    move both sides.  So, next to it: every step at which the oracle is WELL-CONDITIONED (all four of its realisations within
+    `well` x scale of the truth in the maximum norm: one-ulp noise does not move the logits there) is compared with the clean
+    fp16 oracle directly, at ORACLE_TOL like every other HIP-vs-oracle model comparison.  Returns the number of steps compared:
+    the caller asserts that there was at least one."""
+    n = 0
+    for i, got in enumerate(got_steps):
+        want = np.asarray(truth[i], dtype=np.float64)
+        scale = max(float(np.abs(want).max()), 1e-3)
+        if max(_err_stats(run[i], want)[0] for run in runs) > well * scale:
+            continue
+        _model_close(np.asarray(got.detach().cpu() if hasattr(got, "detach") else got), np.asarray(runs[0][i]), ORACLE_TOL,
+                     f"{tag}: step {i} vs the fp16 oracle, directly (well-conditioned step)")
+        n += 1
+    return n
+
+
 def _model_close(got, ref, tol, tag=""):
     """Whole-model comparison of logits / cache rows: an absolute bound at the scale of the largest reference value, plus -- because
     that bound alone would let a wrong low-magnitude column or one bad KV split through -- the relative RMS error over the whole

@@ -256,6 +256,122 @@ def test_q4_gemm_vs_oracle(ce, K, N, gs, act, rows):
     _close(out2.cpu().numpy(), O.q4_matmul_recons(x.numpy(), out=res.numpy(), **ow), ulps=1.5)
 
 
+# Short-prompt products on fragment-order activations (csrc/q4_gemm_frag.hip; exl_q4_matmul_frag = one of the four GEMM launches of
+# exl_q4_layer_prompt): (K, widths of the matrices of ONE launch, group size, act-order, dual = gate / up + SiLU * mul, RMSNorm prologue)
+FRAG_CASES = [
+    (4096, (4096, 4096, 4096), 128, False, False, True),        # 7B q / k / v
+    (4096, (11008, 11008), 128, False, True, True),             # 7B gate / up
+    (4096, (4096,), 128, False, False, False),                  # 7B o_proj
+    (11008, (4096,), 128, False, False, False),                 # 7B down_proj (86 row-blocks: K-groups of unequal length)
+    (5120, (5120, 5120, 5120), 128, True, False, True),         # 13B act-order: one shared map, applied by the producer
+    (5120, (13824, 13824), 128, True, True, True),
+    (6656, (6656, 6656, 6656), 32, True, False, True),          # 33B g32: four groups per row-block
+    (6656, (17920, 17920), 32, True, True, False),
+    (8192, (8192, 1024, 1024), 128, False, False, True),        # 70B GQA: matrices of different widths in one launch
+    (512, (640, 640), 64, False, True, True),                   # 4 row-blocks: one step per K-group of four (a consumer's K is a multiple of 128)
+    (384, (352,), 32, False, False, False),                     # 3 row-blocks (an empty last step), 22 tiles
+]
+
+
+FRAG_KERNELS = {0: "auto", 1: "t16r", 2: "t16g", 3: "t16g_4x4", 4: "t16g_4x2", 5: "t16g_8x4"}
+
+
+@pytest.mark.parametrize("K,widths,gs,act,dual,norm", FRAG_CASES)
+def test_q4_matmul_frag_vs_oracle(ce, K, widths, gs, act, dual, norm):
+    """Every kernel / block shape of the short-prompt GEMM against the oracle's reconstruct + matmul (q4_matmul.cu:301-344), with the
+    RMSNorm and act-order gather of the fragment-order producer in front, the residual accumulation and the SiLU * mul epilogue
+    (fragment-order output, un-permuted here); rows around the 16- / 64- / 128-row tile edges."""
+    ext = ce.exllama_ext
+    lins, g_idx = [], None
+    gen = torch.Generator().manual_seed(K + 7 * widths[0] + len(widths))
+    for N in widths:
+        lin = synth.make_q4_linear(K, N, gs, act, gen, "cpu", zeros="rand", std=0.02 * (4096 / K) ** 0.5, g_idx=g_idx)
+        g_idx = lin.get("g_idx")                                     # one launch = one act-order map (GPTQ: the matrices share their input)
+        lins.append(lin)
+    keep = [_handle(ce, lin) for lin in lins]                        # (handle, device tensors: the handle points INTO them)
+    hs = [h for h, _ in keep]
+    ows = [_oracle_w(lin) for lin in lins]
+    nw = (torch.rand(K, generator=gen) + 0.5).half()
+    nwd = nw.to(DEV) if norm else None
+    eps = 1e-6
+    covered = {k: 0 for k in FRAG_KERNELS}
+    for rows in (2, 17, 64, 70, 128, 250, 256):
+        x = torch.randn(rows, K, generator=gen).half()
+        xd = x.to(DEV)
+        xn = O.rms_norm(x.numpy(), nw.numpy(), eps) if norm else x.numpy()
+        refs = [O.q4_matmul_recons(xn, **ow) for ow in ows]
+        res = [(torch.randn(rows, N, generator=gen) * 0.5).half() for N in widths]
+        refs_acc = None if dual else [O.q4_matmul_recons(xn, out=r.numpy().copy(), **ow) for r, ow in zip(res, ows)]
+        ref_act = O.silu_mul(refs[0], refs[1]) if dual else None
+        for kernel, kname in FRAG_KERNELS.items():
+            tag = f"{kname}, {rows} rows"
+            if dual:
+                got = ext.q4_matmul_frag(xd, hs, norm_weight=nwd, eps=eps, dual=True, kernel=kernel)
+                if got is None:
+                    continue
+                full = ext.unfrag(got, got.numel() // (2 * widths[0]), widths[0])
+                try:
+                    _close(full[:rows].cpu().numpy(), ref_act, ulps=2.0)      # (one more rounding: the product of two rounded halves)
+                except AssertionError as e:
+                    raise AssertionError(f"{tag}: {e}") from None
+                assert not full[rows:].any(), f"{tag}: padding rows of the fragment-order output must be zero"
+            else:
+                outs = [torch.full((rows, N), float("nan"), dtype=torch.float16, device=DEV) for N in widths]
+                if ext.q4_matmul_frag(xd, hs, outs, norm_weight=nwd, eps=eps, kernel=kernel) is None:
+                    continue
+                acc = [r.to(DEV).clone() for r in res]
+                assert ext.q4_matmul_frag(xd, hs, acc, norm_weight=nwd, eps=eps, no_zero=True, kernel=kernel) is not None
+                # (with the RMSNorm in front 2 ulps: the row's scale 1 / rms is rounded to fp16 once on either side -- where the two fp32
+                # sums of squares straddle a rounding boundary every element of the normed row moves one step: measured 1.56 ulps on one
+                # element of the 13B act-order case, r06j)
+                try:
+                    for o, r in zip(outs, refs):
+                        _close(o.cpu().numpy(), r, ulps=2.0 if norm else 1.5)
+                    for o, r in zip(acc, refs_acc):
+                        _close(o.cpu().numpy(), r, ulps=2.0 if norm else 1.5)
+                except AssertionError as e:
+                    raise AssertionError(f"{tag}: {e}") from None
+            covered[kernel] += 1
+    assert covered[0] == 7 and covered[1] == 7, covered               # the launcher's choice and the narrow kernel take every case of the list
+    assert covered[2] == 7 and covered[3] == 7 and covered[4] == 7 and covered[5] == 4, list(covered.items())   # (<8, 4>: from 65 rows on)
+
+
+@pytest.mark.parametrize("K,N,rows", [(4096, 4096, 128), (11008, 4096, 70), (5120, 5120, 250), (4096, 4096, 2)])
+def test_q4_matmul_frag_row_sums_of_squares_feed_the_next_norm(ce, K, N, rows):
+    """The RMSNorm behind o_proj / down_proj takes its sums of squares from the GEMM's epilogue (GrArgs::rowsq: one partial sum per row and
+    column group, of the FINAL fp16 values, residual included) instead of reading the rows again: the partial sums add up to the squares of
+    what the launch wrote, and a norm fed with them gives what the norm that sums for itself gives (one fp32 sum in another order: at
+    most the last bit of the scale, i.e. one fp16 step on few elements) -- for every kernel / block shape that can write x."""
+    ext = ce.exllama_ext
+    gen = torch.Generator().manual_seed(K + N + rows)
+    lin = synth.make_q4_linear(K, N, 128, False, gen, "cpu", zeros="rand", std=0.02 * (4096 / K) ** 0.5)
+    lin2 = synth.make_q4_linear(N, 512, 128, False, gen, "cpu", zeros="rand", std=0.02)
+    (h, keep), (h2, keep2) = _handle(ce, lin), _handle(ce, lin2)
+    x = torch.randn(rows, K, generator=gen).half().to(DEV)
+    res = (torch.randn(rows, N, generator=gen) * 0.5).half()
+    nw = (torch.rand(N, generator=gen) + 0.5).half().to(DEV)
+    took = 0
+    for kernel in (0, 1, 2, 3, 4, 5):
+        out = res.to(DEV).clone()
+        sq = torch.full((rows * (N // 32 + 4),), float("nan"), dtype=torch.float32, device=DEV)
+        if ext.q4_matmul_frag(x, [h], [out], no_zero=True, kernel=kernel, rowsq_out=sq) is None:
+            continue
+        slots = ext.last_rowsq_slots
+        assert 0 < slots <= N // 32 + 4, (kernel, slots)
+        part = sq[:rows * slots].view(rows, slots)
+        want = (out.float() ** 2).sum(1)
+        assert torch.isfinite(part).all(), kernel
+        assert torch.allclose(part.sum(1), want, rtol=2e-5, atol=0), (kernel, float((part.sum(1) - want).abs().max()))
+        # the next launch's norm: fed with the partial sums / summing for itself
+        a = torch.empty((rows, 512), dtype=torch.float16, device=DEV)
+        b = torch.empty_like(a)
+        assert ext.q4_matmul_frag(out, [h2], [a], norm_weight=nw, eps=1e-6, kernel=1) is not None
+        assert ext.q4_matmul_frag(out, [h2], [b], norm_weight=nw, eps=1e-6, kernel=1, rowsq_in=part.contiguous()) is not None
+        _same_up_to_fp32_order(a, b)
+        took += 1
+    assert took >= 4
+
+
 def test_q4_matmul_zero_rows_is_a_no_op(ce):
     lin, gen = _lin(512, 256, 128, False, seed=5)
     h, d = _handle(ce, lin)
