@@ -547,7 +547,8 @@ extern "C" int exl_q4_layer_prompt(void* x, int bsz, int q_len, int past_len, co
                  b_act = frag_bytes(rows, inter);
     auto al = [](size_t v) { return (v + 255) & ~(size_t) 255; };
     const size_t b_sq = (size_t) rows * (size_t) (h / 32 + 4) * 4;    // o_proj's per-row partial sums of squares (launch_gemm_t16r: slots <= N / 32 + 3)
-    const size_t total = al(b_xf) + 2 * al(b_q) + 2 * al(b_kv) + al(b_af) + al(b_act) + al(b_sq);
+    const size_t b_ks = gemm_frag_ksplit_floats(rows, h) * 4;         // o_proj / down_proj with K cut over blocks: their fp32 slices
+    const size_t total = al(b_xf) + 2 * al(b_q) + 2 * al(b_kv) + al(b_af) + al(b_act) + al(b_sq) + al(b_ks);
     float* wsf = nullptr;
     if (exl_gemm_workspace(m[0]->device, (total + 3) / 4, &wsf) != 0) return 0;
     unsigned char* p = (unsigned char*) wsf;
@@ -558,7 +559,8 @@ extern "C" int exl_q4_layer_prompt(void* x, int bsz, int q_len, int past_len, co
     f16* v = (f16*) p; p += al(b_kv);
     void* af = p; p += al(b_af);
     void* actf = p; p += al(b_act);
-    float* osq = (float*) p;
+    float* osq = (float*) p; p += al(b_sq);
+    float* kws = (float*) p;
     float* ws = nullptr;
     EXL_TRY(exl_workspace(m[0]->device, 0, &ws));
     hipStream_t s = (hipStream_t) stream;
@@ -579,7 +581,7 @@ extern "C" int exl_q4_layer_prompt(void* x, int bsz, int q_len, int past_len, co
     EXL_TRY(launch_to_frag(attn, nullptr, 0.f, m[3]->x_map, af, rows, qd, s));
     f16* o_out[1] = {xh};
     int o_slots = 0;
-    r = launch_gemm_t16r(1, om, af, rows, o_out, 1, 0, nullptr, s, 0, osq, &o_slots);
+    r = launch_gemm_t16r(1, om, af, rows, o_out, 1, 0, nullptr, s, 0, osq, &o_slots, kws, b_ks / 4);
     EXL_REQUIRE(r != 1, EXL_E_UNSUPPORTED, "q4_layer_prompt: o_proj not covered behind a covered q / k / v launch");
     if (r) return r;
     EXL_TRY(launch_to_frag(xh, (const f16*) post_norm_w, eps, m[4]->x_map, xf, rows, h, s, osq, o_slots));
@@ -588,7 +590,7 @@ extern "C" int exl_q4_layer_prompt(void* x, int bsz, int q_len, int past_len, co
     if (r) return r;
     const bool sq_out = rowsq && rowsq_out_slots && (size_t) rows * (size_t) (h / 32 + 4) <= rowsq_floats;
     int d_slots = 0;
-    r = launch_gemm_t16r(1, dm, actf, rows, o_out, 1, 0, nullptr, s, 0, sq_out ? rowsq : nullptr, &d_slots);
+    r = launch_gemm_t16r(1, dm, actf, rows, o_out, 1, 0, nullptr, s, 0, sq_out ? rowsq : nullptr, &d_slots, kws, b_ks / 4);
     EXL_REQUIRE(r != 1, EXL_E_UNSUPPORTED, "q4_layer_prompt: down_proj not covered behind a covered attention half");
     if (r) return r;
     if (sq_out) *rowsq_out_slots = d_slots;
@@ -624,12 +626,15 @@ extern "C" int exl_q4_matmul_frag(void* const* w, int nmat, const void* x, int r
     DeviceGuard guard(m[0]->device);
     EXL_REQUIRE(guard.ok, EXL_E_INVALID, "q4_matmul_frag: cannot select device %d", m[0]->device);
     float* wsf = nullptr;
-    if (exl_gemm_workspace(m[0]->device, (frag_bytes(rows, m[0]->height) + 3) / 4, &wsf) != 0) return 0;
+    const size_t xf_floats = ((frag_bytes(rows, m[0]->height) + 255) & ~(size_t) 255) / 4;
+    const size_t ks_floats = nmat == 1 && !dual ? gemm_frag_ksplit_floats(rows, m[0]->width) : 0;
+    if (exl_gemm_workspace(m[0]->device, xf_floats + ks_floats, &wsf) != 0) return 0;
     hipStream_t s = (hipStream_t) stream;
     EXL_TRY(launch_to_frag((const f16*) x, (const f16*) norm_w, eps, m[0]->x_map, wsf, rows, m[0]->height, s, rowsq_in, rowsq_in ? rowsq_in_slots : 0));
     f16* o[3] = {nullptr, nullptr, nullptr};
     if (!dual) for (int i = 0; i < nmat; ++i) { o[i] = (f16*) outs[i]; EXL_REQUIRE(o[i], EXL_E_INVALID, "q4_matmul_frag: null output pointer"); }
-    const int r = launch_gemm_t16r(nmat, m, wsf, rows, o, no_zero, dual, out_frag, s, kernel, rowsq_out, rowsq_out_slots);
+    const int r = launch_gemm_t16r(nmat, m, wsf, rows, o, no_zero, dual, out_frag, s, kernel, rowsq_out, rowsq_out_slots,
+                                   ks_floats ? wsf + xf_floats : nullptr, ks_floats);
     if (r == 1) return 0;
     if (r) return r;
     *launched = 1;

@@ -142,7 +142,8 @@ int launch_to_frag(const f16* x, const f16* norm_w, float eps, const uint32_t* x
 // 1 = not covered; force: which kernel (0 = the launcher's choice); rowsq / rowsq_slots: per-row partial sums of the squares of the output
 // (one matrix, not dual) for the RMSNorm behind the launch: rowsq[row * *rowsq_slots + slot], rows x 512 floats suffice up to 16384 columns
 int launch_gemm_t16r(int nmat, const Q4Matrix* const* w, const void* xf, int rows, f16* const* outs, int no_zero, int dual, void* out_frag,
-                     hipStream_t s, int force = 0, float* rowsq = nullptr, int* rowsq_slots = nullptr);
+                     hipStream_t s, int force = 0, float* rowsq = nullptr, int* rowsq_slots = nullptr, float* kws = nullptr, size_t kws_floats = 0);
+size_t gemm_frag_ksplit_floats(int rows, int N);                    // scratch for the K-cut form of a one-matrix launch (kws): 8 fp32 slices of the padded output
 bool gemm_t16r_covers(int nmat, const Q4Matrix* const* w, int rows, int dual);
 int launch_rms_norm(const f16* x, const f16* w, f16* out, float eps, int rows, int dim, hipStream_t s);
 int launch_rms_norm_gather(const f16* x, const f16* w, f16* out, const uint32_t* x_map, float eps, int rows, int dim, hipStream_t s);   // x_map NULL: plain norm

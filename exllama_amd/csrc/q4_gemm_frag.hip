@@ -35,6 +35,9 @@ struct GrArgs {
     unsigned char* out_frag;      // EPI 1: silu(gate) * up in fragment order for a consumer with K = m[0].N
     int rb_per_wave, nrg, ncg;
     int stagger;                  // blocks start their walk over K at different row-blocks (see q4_gemm_t16g_kernel)
+    int ks;                       // q4_gemm_t16g, EPI 0: K is cut over ks blocks per output tile; the last one to arrive adds the slices up
+    float* kws;                   //   fp32 slices [tile][ks][items][8]
+    int* kcnt;                    //   arrivals per tile: zero before the launch, zero behind it
     float* rowsq;                 // EPI 0, one matrix: rowsq[row * rowsq_stride + slot] = sum of the squares of the row's FINAL fp16 values in the
     int rowsq_stride;             // columns of slot (a column group / column-wave): the RMSNorm behind this launch adds the slots up (to_frag_kernel)
 };
@@ -293,7 +296,9 @@ __global__ __launch_bounds__(GR_WAVES * 64) void q4_gemm_t16g_kernel(const GrArg
     int b = blockIdx.x;
     if ((gridDim.x & 7) == 0) { const int per = gridDim.x >> 3; b = (b & 7) * per + (b >> 3); }   // (q4_gemm_t16r: row groups of a column group on one XCD)
     const int nrg = a.nrg;
-    const int cg = b / nrg, rg = b - cg * nrg;
+    const int ks = a.ks > 1 ? a.ks : 1;                               // blocks per output tile (K ranges); the row groups of a range are neighbours
+    const int cg = b / (nrg * ks), rem = b - cg * nrg * ks;
+    const int kz = rem / nrg, rg = rem - kz * nrg;
     const int K32 = a.K >> 5;
 
     const unsigned char* wq[CT]; const unsigned char* zq[CT]; const unsigned char* sq[CT];
@@ -323,8 +328,9 @@ __global__ __launch_bounds__(GR_WAVES * 64) void q4_gemm_t16g_kernel(const GrArg
         gsh[ct] = m.gsh; n8[ct] = m.N >> 3; nn[ct] = m.N; mi_[ct] = mi; n0_[ct] = tile < ntiles ? tile * 16 : -1;
         shz[ct] = (n & 7) * 4;
     }
-    const int RB = a.m[0].RB;
-    const int nsteps = (RB + NKW - 1) / NKW;                          // the same for every wave (barriers); a K-group's last step may be empty
+    const int rb_lo = (int) ((long) kz * a.m[0].RB / ks);             // this block's row-blocks: [rb_lo, RB)
+    const int RB = (int) ((long) (kz + 1) * a.m[0].RB / ks);
+    const int nsteps = (RB - rb_lo + NKW - 1) / NKW;                  // the same for every wave (barriers); a K-group's last step may be empty
     // Where the walk over K starts (a.stagger, an experiment kept as a switch: blocks that run side by side on one XCD read the SAME
     // activation lines at the same moment; started one step apart they would not.  The L2 turned out to serve them either way.)
     const int off = a.stagger ? (int) ((unsigned) (blockIdx.x >> 3) % (unsigned) nsteps) : 0;
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(GR_WAVES * 64) void q4_gemm_t16g_kernel(const GrArg
     auto rb_of = [&](int s) {                                        // row-block of step s of this K-group (>= RB: an empty step)
         int sp = s + off;                                             // rotated step (the surplus step behind the last one stays behind)
         sp = s >= nsteps ? nsteps : sp >= nsteps ? sp - nsteps : sp;
-        return sp * NKW + kw;
+        return rb_lo + sp * NKW + kw;
     };
     auto issue_piece = [&](int rb, int set, int i) {                  // piece i of this wave's share of the slab: (row tile p / 4, MFMA p % 4)
         const int p = cw * PPW + i;
@@ -462,7 +468,7 @@ __global__ __launch_bounds__(GR_WAVES * 64) void q4_gemm_t16g_kernel(const GrArg
         constexpr int set = decltype(set_tag)::value;
         int sp = s + off;                                             // rotated step (the surplus step behind the last one stays behind)
         sp = s >= nsteps ? nsteps : sp >= nsteps ? sp - nsteps : sp;
-        int rb = sp * NKW + kw;
+        int rb = rb_lo + sp * NKW + kw;
         rb = rb < RB ? rb : RB - 1;                                   // (an empty last step copies the last row-block again: same counts, product skipped)
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
@@ -489,7 +495,7 @@ __global__ __launch_bounds__(GR_WAVES * 64) void q4_gemm_t16g_kernel(const GrArg
         rg_barrier();                                                 // every wave's pieces of slab s have landed
         int sp = s + off;
         sp = s >= nsteps ? nsteps : sp >= nsteps ? sp - nsteps : sp;
-        if (sp * NKW + kw < RB) {
+        if (rb_lo + sp * NKW + kw < RB) {
             f16x8 bq[CT][4];
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
@@ -558,35 +564,29 @@ __global__ __launch_bounds__(GR_WAVES * 64) void q4_gemm_t16g_kernel(const GrArg
     constexpr int ITEMS = ROWS * 2;                                   // (row, half) of each of THIS wave's column tiles, dealt over its NKW waves
     constexpr int NIT = (ITEMS + NKW * 64 - 1) / (NKW * 64);
     const int r0 = rg * ROWS;
-    float ssr[NIT];                                                   // EPI 0: squares of what this thread stored, per item
+    auto gather = [&](int ri, float* v) {                             // the K-groups' sums of one item, fixed order
 #pragma unroll
-    for (int n = 0; n < NIT; ++n) ssr[n] = 0.f;
-    static_for<0, OCT>([&](auto ctc) {
-    constexpr int ct = decltype(ctc)::value;
-#pragma unroll
-    for (int n = 0; n < NIT; ++n) {
-        const int it = kw * 64 + lane + n * NKW * 64;
-        if (it >= ITEMS) continue;                                    // (wave-uniform: ITEMS is a multiple of 64)
-        const int hf = it & 1, r = it >> 1;
-        const int ri = ((r >> 4) * CT + ct) * 256 + (r & 15) * 16 + hf * 8;
-        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
 #pragma unroll
         for (int q = 0; q < NKW; ++q) {
             const float* pr = red + (q * NCW + cw) * RED + ri;
             const float4 p0 = *(const float4*) pr, p1 = *(const float4*) (pr + 4);
             v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w; v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
         }
-        const int row = r0 + r;
-        const int n0 = n0_[ct], mi = mi_[ct], ldn = nn[ct];
-        if (n0 < 0) continue;
-        if constexpr (EPI == 1) {
-            float u[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    };
+    if constexpr (EPI == 1) {
 #pragma unroll
-            for (int q = 0; q < NKW; ++q) {
-                const float* pr = red + (q * NCW + cw) * RED + ri + 256;      // the up tile sits behind the gate tile
-                const float4 p0 = *(const float4*) pr, p1 = *(const float4*) (pr + 4);
-                u[0] += p0.x; u[1] += p0.y; u[2] += p0.z; u[3] += p0.w; u[4] += p1.x; u[5] += p1.y; u[6] += p1.z; u[7] += p1.w;
-            }
+        for (int n = 0; n < NIT; ++n) {
+            const int it = kw * 64 + lane + n * NKW * 64;
+            if (it >= ITEMS) continue;                                // (wave-uniform: ITEMS is a multiple of 64)
+            const int hf = it & 1, r = it >> 1;
+            const int ri = (r >> 4) * CT * 256 + (r & 15) * 16 + hf * 8;
+            const int row = r0 + r;
+            const int n0 = n0_[0], ldn = nn[0];
+            if (n0 < 0) continue;
+            float v[8], u[8];
+            gather(ri, v);
+            gather(ri + 256, u);                                      // the up tile sits behind the gate tile
             f16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = silu_mul_f16((f16) v[j], (f16) u[j]);
@@ -594,26 +594,99 @@ __global__ __launch_bounds__(GR_WAVES * 64) void q4_gemm_t16g_kernel(const GrArg
             const int c = nc >> 3;                                    // chunk of the consumer's K (to_frag_kernel: the same placement)
             const size_t piece = ((size_t) (row >> 4) * (size_t) (ldn >> 5) + (size_t) ((c >> 4) * 4 + (c & 3))) * 64 + (size_t) (((c >> 2) & 3) * 16 + (row & 15));
             *(uint4*) (a.out_frag + piece * 16) = __builtin_bit_cast(uint4, o);
-        } else {
-            if (row >= a.rows) continue;
-            f16* ob = mi == 0 ? a.out[0] : mi == 1 ? a.out[1] : a.out[2];
-            f16* o = ob + (size_t) row * ldn + n0 + hf * 8;
-            f16x8 ov;
-            if (a.no_zero) {
-                const f16x8 old = *(const f16x8*) o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ov[j] = (f16) (v[j] + (float) old[j]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ov[j] = (f16) v[j];
-            }
-            *(f16x8*) o = ov;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = (float) ov[j]; ssr[n] = fmaf(f, f, ssr[n]); }
         }
-    }
-    });
-    if constexpr (EPI == 0) {
+    } else {
+        float vv[OCT][NIT][8];
+        static_for<0, OCT>([&](auto ctc) {
+            constexpr int ct = decltype(ctc)::value;
+#pragma unroll
+            for (int n = 0; n < NIT; ++n) {
+                const int it = kw * 64 + lane + n * NKW * 64;
+                if (it >= ITEMS) continue;
+                const int hf = it & 1, r = it >> 1;
+                gather(((r >> 4) * CT + ct) * 256 + (r & 15) * 16 + hf * 8, vv[ct][n]);
+            }
+        });
+        if (ks > 1) {
+            // K cut over ks blocks: every block leaves its slice of the tile in a.kws; the one that arrives LAST (a counter per tile) adds
+            // the slices up in the order of their K ranges -- whoever it is: bit-reproducible -- and finishes the tile.  Visibility across
+            // CUs / XCDs: 16-byte sc1 (write-through) stores, drained, then the arrival (agent-scope atomic); the last arrival reads with sc1
+            // loads (MI355X_MICROARCH.md, correctness boundaries: "16 B sc1 stores AND sc1 loads").
+            volatile int* s_last = (volatile int*) smem;             // (the reduction buffer is free behind the barrier below; static LDS next to
+                                                                      // 128 KiB of dynamic would need its own opt-in arithmetic)
+            constexpr int PER = NCW * OCT * ITEMS;                    // items of a tile
+            const size_t tile = (size_t) rg * (size_t) a.ncg + (size_t) cg;
+            float* mine = a.kws + ((tile * ks + kz) * PER) * 8;
+            static_for<0, OCT>([&](auto ctc) {
+                constexpr int ct = decltype(ctc)::value;
+#pragma unroll
+                for (int n = 0; n < NIT; ++n) {
+                    const int it = kw * 64 + lane + n * NKW * 64;
+                    if (it >= ITEMS) continue;
+                    float* d = mine + ((size_t) ((cw * OCT + ct) * ITEMS + it)) * 8;
+                    const f32x4 lo = {vv[ct][n][0], vv[ct][n][1], vv[ct][n][2], vv[ct][n][3]}, hi = {vv[ct][n][4], vv[ct][n][5], vv[ct][n][6], vv[ct][n][7]};
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" :: "v"(d), "v"(lo), "v"(hi) : "memory");
+                }
+            });
+            // (write-through stores, drained, instead of a release fence: `__threadfence()` writes the whole L2 back -- measured with it,
+            // r06l: 85 us per launch at 8 ranges where K whole takes 18)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const int old = __hip_atomic_fetch_add(a.kcnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *s_last = old == ks - 1;
+                if (old == ks - 1) a.kcnt[tile] = 0;                  // (every block of the tile has arrived: ready for the next launch)
+            }
+            __syncthreads();
+            if (!*s_last) return;
+            const float* all = a.kws + (tile * ks * PER) * 8;
+            static_for<0, OCT>([&](auto ctc) {
+                constexpr int ct = decltype(ctc)::value;
+#pragma unroll
+                for (int n = 0; n < NIT; ++n) {
+                    const int it = kw * 64 + lane + n * NKW * 64;
+                    if (it >= ITEMS) continue;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vv[ct][n][j] = 0.f;
+                    for (int z = 0; z < ks; ++z) {
+                        const float* d = all + ((size_t) z * PER + (size_t) ((cw * OCT + ct) * ITEMS + it)) * 8;
+                        f32x4 p0, p1;                                 // (sc1: past this CU's and this XCD's caches)
+                        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                                     : "=&v"(p0), "=&v"(p1) : "v"(d) : "memory");
+                        vv[ct][n][0] += p0[0]; vv[ct][n][1] += p0[1]; vv[ct][n][2] += p0[2]; vv[ct][n][3] += p0[3];
+                        vv[ct][n][4] += p1[0]; vv[ct][n][5] += p1[1]; vv[ct][n][6] += p1[2]; vv[ct][n][7] += p1[3];
+                    }
+                }
+            });
+        }
+        float ssr[NIT];                                               // squares of what this thread stores, per item
+#pragma unroll
+        for (int n = 0; n < NIT; ++n) ssr[n] = 0.f;
+        static_for<0, OCT>([&](auto ctc) {
+            constexpr int ct = decltype(ctc)::value;
+#pragma unroll
+            for (int n = 0; n < NIT; ++n) {
+                const int it = kw * 64 + lane + n * NKW * 64;
+                if (it >= ITEMS) continue;
+                const int hf = it & 1, row = r0 + (it >> 1);
+                const int n0 = n0_[ct], mi = mi_[ct], ldn = nn[ct];
+                if (n0 < 0 || row >= a.rows) continue;
+                f16* ob = mi == 0 ? a.out[0] : mi == 1 ? a.out[1] : a.out[2];
+                f16* o = ob + (size_t) row * ldn + n0 + hf * 8;
+                f16x8 ov;
+                if (a.no_zero) {
+                    const f16x8 old = *(const f16x8*) o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ov[j] = (f16) (vv[ct][n][j] + (float) old[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ov[j] = (f16) vv[ct][n][j];
+                }
+                *(f16x8*) o = ov;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = (float) ov[j]; ssr[n] = fmaf(f, f, ssr[n]); }
+            }
+        });
         if (a.rowsq) {                                                // (uniform) slot = this column-wave: the two halves of a row are neighbouring lanes
 #pragma unroll
             for (int n = 0; n < NIT; ++n) {
@@ -772,6 +845,8 @@ int launch_to_frag(const f16* x, const f16* norm_w, float eps, const uint32_t* x
     return 0;
 }
 
+size_t gemm_frag_ksplit_floats(int rows, int N) { return (size_t) 8 * (size_t) frag_rows(rows) * (size_t) ((N + 127) / 128 * 128); }
+
 static int gr_gshift(const Q4Matrix* w)
 {
     if (w->groups <= 1) return 31;
@@ -799,6 +874,12 @@ static int gr_go(GrArgs& a, int rows, int col_groups, hipStream_t s)
     return 0;
 }
 
+static int t16g_pipelined()                                          // A/B: the pipelined step (default) / the plain step (EXL_GEMM_T16G_PF=0)
+{
+    static const int pf = getenv("EXL_GEMM_T16G_PF") ? atoi(getenv("EXL_GEMM_T16G_PF")) : 1;
+    return pf;
+}
+
 template <int MT, int NCW, int EPI>
 static int gg_go(GrArgs& a, int rows, int units, hipStream_t s)
 {
@@ -806,20 +887,40 @@ static int gg_go(GrArgs& a, int rows, int units, hipStream_t s)
     constexpr int NKW = GR_WAVES / NCW;
     a.nrg = (rows + MT * 16 - 1) / (MT * 16);
     a.ncg = (units + NCW - 1) / NCW;
+    const int ks = a.ks > 1 ? a.ks : 1;
     const size_t smem = (size_t) NKW * MT * 8192;                     // the ring (two slabs per K-group) >= the reduction (MT * 16 KiB)
-    static const int pf = getenv("EXL_GEMM_T16G_PF") ? atoi(getenv("EXL_GEMM_T16G_PF")) : 1;     // A/B: who places the LDS reads
+    const int pf = ks > 1 ? 1 : t16g_pipelined();                     // (K cut over blocks: the pipelined kernel only)
     auto kfn = pf ? q4_gemm_t16g_kernel<MT, NCW, EPI, 1> : q4_gemm_t16g_kernel<MT, NCW, EPI, 0>;
     static bool big[2][EXL_MAX_DEVICES] = {};
     if (smem > 64 * 1024) EXL_TRY(exl_lds_opt_in((const void*) kfn, big[pf ? 1 : 0]));
-    hipLaunchKernelGGL(kfn, dim3((unsigned) (a.nrg * a.ncg)), dim3(GR_WAVES * 64), smem, s, a);
+    hipLaunchKernelGGL(kfn, dim3((unsigned) (a.nrg * a.ncg * ks)), dim3(GR_WAVES * 64), smem, s, a);
     EXL_LAUNCH_CHECK();
+    return 0;
+}
+
+// arrival counters of the K-cut launches: one int per output tile, zero between launches (the last arrival resets its own)
+#define GG_KCNT 16384
+static int ksplit_counters(int device, int** out)
+{
+    static std::mutex lock;
+    static int* cnt[EXL_MAX_DEVICES] = {};
+    std::lock_guard<std::mutex> hold(lock);
+    EXL_REQUIRE(device >= 0 && device < EXL_MAX_DEVICES, EXL_E_INVALID, "q4 gemm: device %d out of range", device);
+    if (!cnt[device]) {
+        int* p = nullptr;
+        EXL_HIP(hipMalloc((void**) &p, GG_KCNT * sizeof(int)));
+        EXL_HIP(hipMemset(p, 0, GG_KCNT * sizeof(int)));
+        EXL_HIP(hipDeviceSynchronize());
+        cnt[device] = p;
+    }
+    *out = cnt[device];
     return 0;
 }
 
 // The matrices of one launch: T16 layout, same K, power-of-two group size >= 32, no map left to apply (the producer of xf gathered).
 // Returns 1 for what the kernel does not cover.  outs: row-major outputs (EPI 0) / out_frag: fragment-order silu(gate) * up (dual).
 int launch_gemm_t16r(int nmat, const Q4Matrix* const* w, const void* xf, int rows, f16* const* outs, int no_zero, int dual, void* out_frag,
-                     hipStream_t s, int force, float* rowsq, int* rowsq_slots)
+                     hipStream_t s, int force, float* rowsq, int* rowsq_slots, float* kws, size_t kws_floats)
 {
     if (rowsq_slots) *rowsq_slots = 0;
     if (nmat != 1 || dual) rowsq = nullptr;                           // (one slot = the columns of one block / column-wave of ONE matrix)
@@ -856,7 +957,7 @@ int launch_gemm_t16r(int nmat, const Q4Matrix* const* w, const void* xf, int row
     static const int g_min = getenv("EXL_GEMM_T16G_MIN_BLOCKS") ? atoi(getenv("EXL_GEMM_T16G_MIN_BLOCKS")) : 160;
     // (force, the op-level entry point's kernel choice for tests and A/B runs: 0 as above, 1 the narrow kernel, 2 the wide kernel at any
     // width, 3 / 4 / 5 its <4, 4> / <4, 2> / <8, 4> block shape)
-    if ((!no_g && force == 0) || force >= 2) {
+    if ((!no_g && force == 0) || (force >= 2 && force <= 5)) {
         const int units = dual ? w[0]->width / 16 : (tiles + 1) / 2;  // what one wave owns: a gate + an up tile / two tiles
         const long need = force ? 0 : g_min;
         auto blocks = [&](int mt, int ncw) { return (long) ((rows + mt * 16 - 1) / (mt * 16)) * ((units + ncw - 1) / ncw); };
@@ -872,9 +973,35 @@ int launch_gemm_t16r(int nmat, const Q4Matrix* const* w, const void* xf, int row
             if (t44) { slots((units + 3) / 4 * 4); return gg_go<4, 4, 0>(a, rows, units, s); }
             if (t42) { slots((units + 1) / 2 * 2); return gg_go<4, 2, 0>(a, rows, units, s); }
         }
-        if (force >= 2) return 1;                                     // the forced shape does not take this launch
+        if (force >= 2) return 1;                                     // the forced shape does not take this launch (6: the K-cut form, below)
     }
-    // Narrow launches: column tiles per block as wide as still gives about a block per CU -- the activation traffic of the launch is
+    // Narrow launches (o_proj, down_proj: N = hidden).  With K whole, a block per 64 x 32 outputs is what fills the chip, and every such
+    // block pulls 64 rows x K of activations through its CU (r06j, 7B at 128 rows: 11.4 / 28.2 us).  The alternative -- K cut over `ks`
+    // blocks per tile, the wide kernel's 128 x 128 tiles, the block that arrives last at a tile adding the fp32 slices up
+    // (q4_gemm_t16g_kernel: ks) -- is built, bit-exact run to run and parity-tested (kernel choice 6 of exl_q4_matmul_frag), and LOSES:
+    // 23.7 / 42.7 us at 4 / 8 ranges (profiles/r06_short_prompt.txt: a block of 4-5 steps is mostly start-up, and the hand-over costs
+    // 64 KiB of write-through stores per block plus a last block that reads ks x 64 KiB back).  Off unless EXL_GEMM_KSPLIT=n (n ranges;
+    // -1: the launcher's choice) or the caller forces it.
+    static const int ks_env = getenv("EXL_GEMM_KSPLIT") ? atoi(getenv("EXL_GEMM_KSPLIT")) : 0;
+    if (!dual && nmat == 1 && kws && (force == 6 || (force == 0 && ks_env != 0 && !no_g))) {
+        const int units = (tiles + 1) / 2, RBn = K / 128;
+        const bool m8 = rows > 64;
+        const int rg_n = m8 ? (rows + 127) / 128 : (rows + 63) / 64, cg_n = (units + 3) / 4;
+        int ks = ks_env > 0 ? ks_env : (256 + rg_n * cg_n / 2) / (rg_n * cg_n);
+        ks = ks > 8 ? 8 : ks;
+        if (ks_env <= 0) ks = ks > RBn / 8 ? RBn / 8 : ks;           // (four steps per K-group: below that a block is start-up and hand-over)
+        ks = ks > RBn / 4 ? RBn / 4 : ks;                            // (never fewer than two)
+        const size_t need = (size_t) rg_n * cg_n * ks * (m8 ? 128 : 64) * 128;
+        if (ks >= 2 && need <= kws_floats && rg_n * cg_n <= GG_KCNT) {
+            a.ks = ks;
+            a.kws = kws;
+            if (!g_gr_dry) EXL_TRY(ksplit_counters(w[0]->device, &a.kcnt));
+            slots(cg_n * 4);
+            return m8 ? gg_go<8, 4, 0>(a, rows, units, s) : gg_go<4, 4, 0>(a, rows, units, s);
+        }
+    }
+    if (force == 6) return 1;                                         // (the K-cut form was asked for and does not take this launch)
+    // K whole: column tiles per block as wide as still gives about a block per CU -- the activation traffic of the launch is
     // (tiles / CT) x rows x K x 2 bytes through the CUs' L1s, the weight expansion is repeated by every row group.
     const int nrg = (rows + 63) / 64;
     if (dual) {
@@ -895,7 +1022,7 @@ bool gemm_t16r_covers(int nmat, const Q4Matrix* const* w, int rows, int dual)
     static std::mutex lock;
     std::lock_guard<std::mutex> hold(lock);
     g_gr_dry = true;
-    const int r = launch_gemm_t16r(nmat, w, nullptr, rows, nullptr, 0, dual, nullptr, nullptr, 0, nullptr, nullptr);
+    const int r = launch_gemm_t16r(nmat, w, nullptr, rows, nullptr, 0, dual, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0);
     g_gr_dry = false;
     return r == 0;
 }

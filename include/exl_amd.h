@@ -153,7 +153,8 @@ size_t exl_frag_bytes(int rows, int K);
  * launch, or (dual, nmat = 2) out_frag = silu(x @ W_0) * (x @ W_1) in the fragment order of a consumer with K = width:
  *     out_frag[((mt * (K / 32) + 4 rb + j) * 64 + lane) * 16 .. + 16] = act[16 mt + (lane & 15)][128 rb + 32 (lane >> 4) + 8 j .. + 8]
  * (exl_frag_bytes(rows, width) bytes: rows padded to 64, from 65 rows on to a multiple of 128).  kernel: 0 = the launcher's choice,
- * 1 = activations in registers (narrow matrices), 2 .. 5 = activations shared through LDS (block shapes, csrc/q4_gemm_frag.hip).
+ * 1 = activations in registers (narrow matrices), 2 .. 5 = activations shared through LDS (block shapes, csrc/q4_gemm_frag.hip),
+ * 6 = that kernel with K cut over several blocks per output tile (one matrix: o_proj / down_proj).
  * *launched = 0: not covered (more than 256 rows, layout, group size, maps that differ).
  * rowsq_in / rowsq_in_slots: partial sums of squares of x for the RMSNorm (NULL / 0: the norm sums whole rows itself); rowsq_out: receives
  * rowsq_out[row * *rowsq_out_slots + slot] for ONE output matrix (not dual; rows * (width / 32 + 4) floats), what the next norm adds up. */

