@@ -546,7 +546,7 @@ extern "C" int exl_q4_layer_prompt(void* x, int bsz, int q_len, int past_len, co
     const size_t b_xf = frag_bytes(rows, h), b_q = (size_t) rows * qd * 2, b_kv = (size_t) rows * kvd * 2, b_af = frag_bytes(rows, qd),
                  b_act = frag_bytes(rows, inter);
     auto al = [](size_t v) { return (v + 255) & ~(size_t) 255; };
-    const size_t b_sq = (size_t) rows * (size_t) (h / 32 + 4) * 4;    // o_proj's per-row partial sums of squares (launch_gemm_t16r: slots <= N / 32 + 3)
+    const size_t b_sq = (size_t) rows * (size_t) (h / 16 + 4) * 4;    // o_proj's per-row partial sums of squares (launch_gemm_t16r: slots <= N / 16)
     const size_t b_ks = gemm_frag_ksplit_floats(rows, h) * 4;         // o_proj / down_proj with K cut over blocks: their fp32 slices
     const size_t total = al(b_xf) + 2 * al(b_q) + 2 * al(b_kv) + al(b_af) + al(b_act) + al(b_sq) + al(b_ks);
     float* wsf = nullptr;
@@ -588,7 +588,7 @@ extern "C" int exl_q4_layer_prompt(void* x, int bsz, int q_len, int past_len, co
     r = launch_gemm_t16r(2, gu, xf, rows, nullptr, 0, 1, actf, s);
     EXL_REQUIRE(r != 1, EXL_E_UNSUPPORTED, "q4_layer_prompt: gate / up not covered behind a covered attention half");
     if (r) return r;
-    const bool sq_out = rowsq && rowsq_out_slots && (size_t) rows * (size_t) (h / 32 + 4) <= rowsq_floats;
+    const bool sq_out = rowsq && rowsq_out_slots && (size_t) rows * (size_t) (h / 16 + 4) <= rowsq_floats;
     int d_slots = 0;
     r = launch_gemm_t16r(1, dm, actf, rows, o_out, 1, 0, nullptr, s, 0, sq_out ? rowsq : nullptr, &d_slots, kws, b_ks / 4);
     EXL_REQUIRE(r != 1, EXL_E_UNSUPPORTED, "q4_layer_prompt: down_proj not covered behind a covered attention half");

@@ -140,7 +140,7 @@ size_t frag_bytes(int rows, int K);
 int launch_to_frag(const f16* x, const f16* norm_w, float eps, const uint32_t* x_map, void* xf, int rows, int K, hipStream_t s,
                    const float* rowsq = nullptr, int nslots = 0);   // rowsq: the producer's per-row partial sums of squares (GrArgs::rowsq)
 // 1 = not covered; force: which kernel (0 = the launcher's choice); rowsq / rowsq_slots: per-row partial sums of the squares of the output
-// (one matrix, not dual) for the RMSNorm behind the launch: rowsq[row * *rowsq_slots + slot], rows x 512 floats suffice up to 16384 columns
+// (one matrix, not dual) for the RMSNorm behind the launch: rowsq[row * *rowsq_slots + slot], rows x (width / 16 + 4) floats hold any shape
 int launch_gemm_t16r(int nmat, const Q4Matrix* const* w, const void* xf, int rows, f16* const* outs, int no_zero, int dual, void* out_frag,
                      hipStream_t s, int force = 0, float* rowsq = nullptr, int* rowsq_slots = nullptr, float* kws = nullptr, size_t kws_floats = 0);
 size_t gemm_frag_ksplit_floats(int rows, int N);                    // scratch for the K-cut form of a one-matrix launch (kws): 8 fp32 slices of the padded output

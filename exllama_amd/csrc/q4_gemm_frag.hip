@@ -382,7 +382,7 @@ __global__ __launch_bounds__(GR_WAVES * 64) void q4_gemm_t16g_kernel(const GrArg
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(wr[0][0]), "+v"(wr[0][1]), "+v"(zr[0][0]), "+v"(zr[0][1]), "+v"(sr[0][0]), "+v"(sr[0][1]),
                      "+v"(wr[1][0]), "+v"(wr[1][1]), "+v"(zr[1][0]), "+v"(zr[1][1]), "+v"(sr[1][0]), "+v"(sr[1][1]) :: "memory");
     };
-    constexpr int HALF = MT / 2;                                      // groups that carry slab requests
+    constexpr int HALF = MT >= 2 ? MT / 2 : 1;                        // groups that carry slab requests
     constexpr int PPG = (PPW + HALF - 1) / HALF;                      // pieces per such group
     constexpr int WPG = (CT * 4 + MT - 1) / MT;                       // weight words expanded per group
     auto step = [&](auto set_tag, int s) {
@@ -757,8 +757,17 @@ __global__ __launch_bounds__(TF_WAVES * 64) void to_frag_kernel(const f16* __res
     if (norm_w) {
         float ss = 0.f;
         if (rowsq) {                                                  // the producer's partial sums: slot s of the row to thread s mod (4 nw)
-            if (live)
-                for (int sl = wave * 4 + kg; sl < nslots; sl += nw * 4) ss += rowsq[(size_t) row * nslots + sl];
+            if (live) {                                               // (eight requests at a time, then added in slot order: a loop of dependent
+                const float* pr = rowsq + (size_t) row * nslots;      // load-and-add took 7-10 us for 256 slots, r06m)
+                const int st = nw * 4;
+                for (int sl = wave * 4 + kg; sl < nslots; sl += 8 * st) {
+                    float t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u] = sl + u * st < nslots ? pr[sl + u * st] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) ss += t[u];
+                }
+            }
         } else if (hold) {
 #pragma unroll
             for (int i = 0; i < TF_HOLD; ++i)
@@ -957,21 +966,32 @@ int launch_gemm_t16r(int nmat, const Q4Matrix* const* w, const void* xf, int row
     static const int g_min = getenv("EXL_GEMM_T16G_MIN_BLOCKS") ? atoi(getenv("EXL_GEMM_T16G_MIN_BLOCKS")) : 160;
     // (force, the op-level entry point's kernel choice for tests and A/B runs: 0 as above, 1 the narrow kernel, 2 the wide kernel at any
     // width, 3 / 4 / 5 its <4, 4> / <4, 2> / <8, 4> block shape)
-    if ((!no_g && force == 0) || (force >= 2 && force <= 5)) {
+    // Row tiles per block: what the rows fill -- 1 / 2 / 4 / 8 tiles of 16 (a prompt of a few tokens, a chat turn, does a sixteenth of
+    // the LDS reads and MFMAs of a 128-row block and runs at the rate the weights stream).
+    // (force, the op-level entry point's kernel choice for tests and A/B runs: 0 as above, 1 the narrow kernel, 2 the wide kernel at any
+    // width, 3 / 4 / 5 its <4, 4> / <4, 2> / <8, 4> block shape, 7 .. 10 <1, 4> / <1, 2> / <2, 4> / <2, 2>)
+    const int mt_fit = rows <= 16 ? 1 : rows <= 32 ? 2 : rows <= 64 ? 4 : 8;
+    if ((!no_g && force == 0) || (force >= 2 && force <= 5) || (force >= 7 && force <= 10)) {
         const int units = dual ? w[0]->width / 16 : (tiles + 1) / 2;  // what one wave owns: a gate + an up tile / two tiles
         const long need = force ? 0 : g_min;
         auto blocks = [&](int mt, int ncw) { return (long) ((rows + mt * 16 - 1) / (mt * 16)) * ((units + ncw - 1) / ncw); };
-        const bool t8 = rows > 64 && (force == 5 || (force <= 2 && blocks(8, 4) >= need));
-        const bool t44 = force == 3 || (force <= 2 && blocks(4, 4) >= need);
-        const bool t42 = force == 4 || (force <= 2 && blocks(4, 2) >= need);
-        if (dual) {
-            if (t8) return gg_go<8, 4, 1>(a, rows, units, s);
-            if (t44) return gg_go<4, 4, 1>(a, rows, units, s);
-            if (t42) return gg_go<4, 2, 1>(a, rows, units, s);
+        int mt = 0, ncw = 0;
+        if (force <= 2) {
+            if (blocks(mt_fit, 4) >= need) { mt = mt_fit; ncw = 4; }
+            else if (mt_fit == 8 && blocks(4, 4) >= need) { mt = 4; ncw = 4; }
+            else if (blocks(mt_fit == 8 ? 4 : mt_fit, 2) >= need) { mt = mt_fit == 8 ? 4 : mt_fit; ncw = 2; }
         } else {
-            if (t8) { slots((units + 3) / 4 * 4); return gg_go<8, 4, 0>(a, rows, units, s); }
-            if (t44) { slots((units + 3) / 4 * 4); return gg_go<4, 4, 0>(a, rows, units, s); }
-            if (t42) { slots((units + 1) / 2 * 2); return gg_go<4, 2, 0>(a, rows, units, s); }
+            static const int shape[11][2] = {{0, 0}, {0, 0}, {0, 0}, {4, 4}, {4, 2}, {8, 4}, {0, 0}, {1, 4}, {1, 2}, {2, 4}, {2, 2}};
+            mt = shape[force][0]; ncw = shape[force][1];
+            if (mt == 8 && rows <= 64) mt = 0;                        // (the buffers of <= 64 rows hold 64)
+        }
+        if (mt) {
+            if (!dual) slots((units + ncw - 1) / ncw * ncw);
+#define GG_CASE(M, N) case M * 10 + N: return dual ? gg_go<M, N, 1>(a, rows, units, s) : gg_go<M, N, 0>(a, rows, units, s)
+            switch (mt * 10 + ncw) {
+                GG_CASE(8, 4); GG_CASE(4, 4); GG_CASE(4, 2); GG_CASE(2, 4); GG_CASE(2, 2); GG_CASE(1, 4); GG_CASE(1, 2);
+            }
+#undef GG_CASE
         }
         if (force >= 2) return 1;                                     // the forced shape does not take this launch (6: the K-cut form, below)
     }
@@ -1007,6 +1027,13 @@ int launch_gemm_t16r(int nmat, const Q4Matrix* const* w, const void* xf, int row
     if (dual) {
         if (w[0]->width % 32 != 0) return 1;                          // two gate + two up tiles per block
         return gr_go<4, 4, 1>(a, rows, w[0]->width / 32, s);
+    }
+    if (mt_fit <= 2) {                                               // a few rows: one or two row tiles per block, the decode GEMV's shape
+        bool by2 = true;
+        for (int i = 0; i < nmat; ++i) by2 = by2 && (w[i]->width % 32 == 0);
+        if (by2 && tiles / 2 >= 200) { slots(tiles / 2); return mt_fit == 1 ? gr_go<1, 2, 0>(a, rows, tiles / 2, s) : gr_go<2, 2, 0>(a, rows, tiles / 2, s); }
+        slots(tiles);
+        return mt_fit == 1 ? gr_go<1, 1, 0>(a, rows, tiles, s) : gr_go<2, 1, 0>(a, rows, tiles, s);
     }
     bool by4 = true;                                                 // a block's tiles never straddle two matrices
     for (int i = 0; i < nmat; ++i) by4 = by4 && (w[i]->width % 64 == 0);

@@ -230,7 +230,7 @@ class _ExllamaExt:
                         key_cache, value_cache, num_heads, num_kv_heads, head_dim, max_seq_len, rowsq=None, rowsq_in_slots=0):
         """One decoder layer of a SHORT prompt (2 .. 256 rows), in place on the residual stream x [bsz * q_len, hidden]: every launch of
         the layer enqueued by one call (include/exl_amd.h: exl_q4_layer_prompt).  Returns (taken, rowsq_out_slots); taken False: the
-        layer is not covered, nothing that touches x or the cache was launched.  rowsq (fp32 scratch, rows * (hidden / 32 + 4) floats):
+        layer is not covered, nothing that touches x or the cache was launched.  rowsq (fp32 scratch, rows * (hidden / 16 + 4) floats):
         carries the RMSNorm partial sums from this layer's down_proj to the next layer's call (rowsq_in_slots = what the previous call
         returned, 0 when x was written by anything else since)."""
         for t, n in ((x, "x"), (in_norm_weight, "input_layernorm"), (post_norm_weight, "post_attention_layernorm"), (key_cache, "key_cache"),
@@ -257,7 +257,7 @@ class _ExllamaExt:
         in one launch -> `outs` (row-major tensors, written / accumulated in place), or dual=True: returns silu(x @ W0) * (x @ W1) in
         FRAGMENT ORDER as a uint8 tensor of exl_frag_bytes(rows, width) bytes (unfrag() turns it back).  Returns None when the launch is not
         covered.  rowsq_in = (fp32 tensor [rows, slots]) partial sums of squares of x for the norm; rowsq_out = fp32 tensor of at least
-        rows * (width / 32 + 4) elements that receives those of the (single) output: self.last_rowsq_slots says how many per row."""
+        rows * (width / 16 + 4) elements that receives those of the (single) output: self.last_rowsq_slots says how many per row."""
         _req_dtype(x, torch.float16, "x")
         _req_cuda(x, "x")
         _req(x.is_contiguous() and x.dim() == 2, "x must be a contiguous [rows, K] tensor")

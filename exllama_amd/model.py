@@ -449,7 +449,7 @@ class ExLlamaDecoderLayer:
         # exl_q4_layer_prompt); they are valid for THIS x only if the previous layer of the same pass left them for it
         rowsq, slots, tag = None, 0, (hidden_states.data_ptr(), bsz * q_len, self.index - 1, str(hidden_states.device))
         if buffer is not None:
-            need = bsz * q_len * (hid // 32 + 4)
+            need = bsz * q_len * (hid // 16 + 4)
             rowsq = getattr(buffer, "rowsq", None)
             if rowsq is None or rowsq.numel() < need or rowsq.device != hidden_states.device:
                 rowsq = buffer.rowsq = torch.empty(need, dtype=torch.float32, device=hidden_states.device)

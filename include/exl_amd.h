@@ -141,7 +141,7 @@ int exl_q4_layer_prompt(void* x, int bsz, int q_len, int past_len, const void* i
                         void* wq, void* wk, void* wv, void* wo, void* wgate, void* wup, void* wdown, const void* sin, const void* cos,
                         void* key_cache, void* value_cache, int heads, int kv_heads, int head_dim, int max_seq_len, void* stream,
                         float* rowsq, size_t rowsq_floats, int rowsq_in_slots, int* rowsq_out_slots, int* launched);
-/* rowsq (optional, rows * (hidden / 32 + 4) floats; rowsq_floats = its size): the sums of squares RMSNorm needs travel from the GEMM that
+/* rowsq (optional, rows * (hidden / 16 + 4) floats; rowsq_floats = its size): the sums of squares RMSNorm needs travel from the GEMM that
  * wrote the residual stream to the norm that reads it, as `slots` partial sums per row.  On return *rowsq_out_slots > 0 says: rowsq holds
  * them for the x this call left behind.  Pass that number as rowsq_in_slots to the NEXT layer's call if -- and only if -- nothing has
  * written x in between (same pointer, same rows); pass 0 otherwise (the first layer, a layer not taken by this entry point before): the
@@ -154,10 +154,11 @@ size_t exl_frag_bytes(int rows, int K);
  *     out_frag[((mt * (K / 32) + 4 rb + j) * 64 + lane) * 16 .. + 16] = act[16 mt + (lane & 15)][128 rb + 32 (lane >> 4) + 8 j .. + 8]
  * (exl_frag_bytes(rows, width) bytes: rows padded to 64, from 65 rows on to a multiple of 128).  kernel: 0 = the launcher's choice,
  * 1 = activations in registers (narrow matrices), 2 .. 5 = activations shared through LDS (block shapes, csrc/q4_gemm_frag.hip),
- * 6 = that kernel with K cut over several blocks per output tile (one matrix: o_proj / down_proj).
+ * 6 = that kernel with K cut over several blocks per output tile (one matrix: o_proj / down_proj), 7 .. 10 = its one- and two-row-tile
+ * shapes (prompts of up to 16 / 32 rows).
  * *launched = 0: not covered (more than 256 rows, layout, group size, maps that differ).
  * rowsq_in / rowsq_in_slots: partial sums of squares of x for the RMSNorm (NULL / 0: the norm sums whole rows itself); rowsq_out: receives
- * rowsq_out[row * *rowsq_out_slots + slot] for ONE output matrix (not dual; rows * (width / 32 + 4) floats), what the next norm adds up. */
+ * rowsq_out[row * *rowsq_out_slots + slot] for ONE output matrix (not dual; rows * (width / 16 + 4) floats), what the next norm adds up. */
 int exl_q4_matmul_frag(void* const* w, int nmat, const void* x, int rows, const void* norm_w, float eps, void* const* outs,
                        int no_zero, int dual, void* out_frag, int kernel, void* stream, const float* rowsq_in, int rowsq_in_slots,
                        float* rowsq_out, int* rowsq_out_slots, int* launched);

@@ -70,4 +70,10 @@ def test_prompt_kernels(res):
             assert r["threads"] == 512 and r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 256, (n, r)
         if "half_gemm_nt_kernel" in n:
             assert r["scratch"] == 0, (n, r)
-    assert seen == {"t16w", "t16d2", "flash8"}, seen
+        if "q4_gemm_t16g_kernel" in n or "q4_gemm_t16r_kernel" in n:     # short prompts: 8 waves, hand-counted requests -- one block per CU
+            seen.add("t16g" if "t16g" in n else "t16r")                  # (2 waves per SIMD: <= 256), never a spill
+            assert r["threads"] == 512 and r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 256 and r["lds"] == 0, (n, r)
+        if "to_frag_kernel" in n:
+            seen.add("to_frag")
+            assert r["scratch"] == 0 and r["vgpr"] <= 256, (n, r)
+    assert seen == {"t16w", "t16d2", "flash8", "t16g", "t16r", "to_frag"}, seen
