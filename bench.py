@@ -568,7 +568,11 @@ def main():
         if S >= 128:
             ms_128, _ = timed_prefill(128)
             extra["prompt_128_tokens"] = {"prefill_tokens_per_s": round(128 / (ms_128 / 1e3), 1), "prefill_ms": round(ms_128, 3),
-                                          "note": "BASELINE configs[0] prompt length (<= 256 rows: the short-prompt GEMM, csrc/q4_gemm_skinny.hip; op-by-op eager launches)"}
+                                          "note": "BASELINE configs[0] prompt length (2 .. 256 rows: one native call per layer, GEMMs on fragment-order "
+                                                  "activations, csrc/q4_gemm_frag.hip; round 5 ran 12 eager launches per layer here: 5.27 ms)"}
+            ms_16, _ = timed_prefill(16)
+            extra["prompt_16_tokens"] = {"prefill_tokens_per_s": round(16 / (ms_16 / 1e3), 1), "prefill_ms": round(ms_16, 3),
+                                         "note": "a chat turn: one row tile per block (the weights stream once, at about the decode step's rate)"}
         result["other_lengths"] = extra
 
         # ---- the reference's own generation loop on THIS repository's model.py (test_benchmark_inference.py:182-197: forward, then

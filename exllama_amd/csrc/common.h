@@ -94,8 +94,12 @@ struct DeviceBuffers {
 };
 DeviceBuffers* exl_buffers(int device);           // never NULL for 0 <= device < EXL_MAX_DEVICES
 int exl_workspace(int device, size_t floats, float** out);   // fails if too small / not prepared
-#define SMP_BIG_MAX 65536                             // entries the sampler's whole-vocabulary sort holds (a power of two)
-#define SMP_BIG_BYTES ((size_t) SMP_BIG_MAX * (8 + 4 + 4 + 4 + 4))
+// The sampler's whole-vocabulary sort (top_k = 0 or > 1024) works in a per-device workspace sized for the vocabulary rounded up to a
+// power of two: a 64-bit key, two probabilities and two indices per entry.  (Round 5 held 65536 entries, fixed; Llama-3's 128256
+// tokens and anything else up to 2^22 fit now.)
+#define SMP_BIG_LIMIT (1 << 22)
+static inline size_t smp_big_np(int vocab) { size_t np = 1; while (np < (size_t) (vocab > 1 ? vocab : 1)) np <<= 1; return np; }
+static inline size_t smp_big_bytes(int vocab) { return smp_big_np(vocab) * (8 + 4 + 4 + 4 + 4); }
 int exl_sampler_workspace(int device, size_t bytes, void** out);  // allocated once per device (NOT capturable)
 int exl_gemm_workspace(int device, size_t floats, float** out);   // grows (device-synchronising, NOT capturable) up to 512 MiB; non-zero: no room
 extern ExlTuning g_tuning;

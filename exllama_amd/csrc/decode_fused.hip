@@ -1374,7 +1374,7 @@ extern "C" int exl_decoder_create(int device, int n_layers, int hidden, int inte
     if (e != hipSuccess) { delete d; EXL_FAIL((int) e, "decoder_create: %s", hipGetErrorString(e)); }
     if (lm_head) {                                                   // the sampler's whole-vocabulary workspace (top_k = 0 / > 1024): a captured
         void* sw = nullptr;                                          // exl_decoder_step_sample cannot allocate it
-        const int rs = exl_sampler_workspace(device, SMP_BIG_BYTES, &sw);
+        const int rs = vocab <= SMP_BIG_LIMIT ? exl_sampler_workspace(device, smp_big_bytes(vocab), &sw) : 0;
         if (rs) { (void) hipFree(d->block); delete d; return rs; }
     }
     unsigned char* b = (unsigned char*) d->block;

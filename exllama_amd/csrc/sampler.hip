@@ -17,7 +17,7 @@
 //      one to one.)
 // One block of 1024 threads.  1 <= top_k <= 1024 (dec_sample_kernel): selection by a 4-pass radix select on the probability
 // bits, the candidates sorted by a bitonic network in LDS.  top_k = 0 -- the reference then sorts the WHOLE vocabulary and does
-// not renormalise (generator.py:110-111) -- and top_k > 1024 (dec_sample_big_kernel): the whole vocabulary (<= 65536 entries) is
+// not renormalise (generator.py:110-111) -- and top_k > 1024 (dec_sample_big_kernel): the whole vocabulary is
 // sorted in a per-device workspace by the same network run in LDS-sized chunks, and the reference's sequential loops (top-p /
 // min-p, typical, the draw) walk the sorted list chunk by chunk, so any number of survivors is handled.
 #include "common.h"
@@ -498,18 +498,19 @@ int launch_dec_sample(float* logits, float* probs, int64_t* history, int64_t* to
         return 0;
     }
     // top_k = 0 or beyond the LDS network: the whole-vocabulary sort in the device's sampler workspace
-    EXL_REQUIRE(vocab <= SMP_BIG_MAX, EXL_E_UNSUPPORTED, "device sampler: top_k = %d needs the whole-vocabulary sort, which holds at most %d entries (vocabulary %d)",
-                s->top_k, SMP_BIG_MAX, vocab);
+    EXL_REQUIRE(vocab <= SMP_BIG_LIMIT, EXL_E_UNSUPPORTED, "device sampler: top_k = %d needs the whole-vocabulary sort, which holds at most %d entries (vocabulary %d)",
+                s->top_k, SMP_BIG_LIMIT, vocab);
     int dev = 0;
     EXL_HIP(hipGetDevice(&dev));
     void* base = nullptr;
-    EXL_TRY(exl_sampler_workspace(dev, SMP_BIG_BYTES, &base));          // allocated once per device (NOT capturable: exl_decoder_create does it up front)
+    EXL_TRY(exl_sampler_workspace(dev, smp_big_bytes(vocab), &base));   // grows with the vocabulary (NOT capturable: exl_decoder_create does it up front)
+    const size_t np = smp_big_np(vocab);
     SamplerBig w;
     w.key = (unsigned long long*) base;
-    w.cp = (float*) (w.key + SMP_BIG_MAX);
-    w.cp2 = w.cp + SMP_BIG_MAX;
-    w.ci = (int*) (w.cp2 + SMP_BIG_MAX);
-    w.ci2 = w.ci + SMP_BIG_MAX;
+    w.cp = (float*) (w.key + np);
+    w.cp2 = w.cp + np;
+    w.ci = (int*) (w.cp2 + np);
+    w.ci2 = w.ci + np;
     hipLaunchKernelGGL(dec_sample_big_kernel, dim3(1), dim3(SMP_THREADS), 0, stream, a, w);
     EXL_LAUNCH_CHECK();
     return 0;

@@ -261,11 +261,9 @@ int exl_decoder_step_greedy(void* decoder, int64_t* token_io_dev, int32_t* pos_d
 typedef struct ExlSampler {
     float   temperature;        /* > 0                                                            (Settings.temperature, 0.95) */
     int32_t top_k;              /* 0 = the whole vocabulary, sorted, not renormalised (generator.py:110-111); > 1024 also sorts it (top_k, 40).
-                                   LIMIT: the whole-vocabulary sort (top_k = 0 or > 1024) holds at most 65536 entries -- every Llama-1/2
-                                   tokenizer the reference loads has 32000 -- and returns EXL_E_UNSUPPORTED (message in exl_last_error)
-                                   for a larger vocabulary; 1 <= top_k <= 1024 works for any vocabulary size.  Callers with a larger
-                                   vocabulary and top_k = 0 sample on the host from the executor's logits (the reference's own
-                                   generator.py:91-170 loop does exactly that). */
+                                   The whole-vocabulary sort (top_k = 0 or > 1024) works in a per-device workspace that grows with the
+                                   vocabulary (24 bytes per entry of the next power of two; up to 2^22 entries, EXL_E_UNSUPPORTED beyond);
+                                   1 <= top_k <= 1024 needs none. */
     float   top_p;              /* 0 disables                                                                  (top_p, 0.65) */
     float   min_p;              /* cut inside the top-p loop (generator.py:128)                                 (min_p, 0.0) */
     float   typical;            /* 0 disables locally typical sampling                                        (typical, 0.0) */

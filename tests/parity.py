@@ -145,9 +145,10 @@ def _ppl_checkpoint(dims, layers, groupsize, act_order, head_scale, ckpt_seed, z
 
 
 def perplexity_hip(dims, layers, groupsize, act_order, tokens=1536, seed=17, head_scale=4.6, ckpt_seed=23, device="cuda:0", log=None, tensors=None,
-                   zeros="sym"):
-    """The HIP half of perplexity_three_ways: samples the text on the decode path and scores it on the whole-chunk and the
-    token-by-token path.  Returns (record, ids [1, tokens] LongTensor on the host)."""
+                   zeros="sym", text=None):
+    """The HIP half of perplexity_three_ways: samples the text on the decode path (or takes `text`, [1, tokens] ids: a text this same
+    checkpoint sampled earlier -- a committed fixture) and scores it on the whole-chunk and the token-by-token path.  Returns (record,
+    ids [1, tokens] LongTensor on the host)."""
     import time
     import torch
     from exllama_amd import synth
@@ -164,20 +165,25 @@ def perplexity_hip(dims, layers, groupsize, act_order, tokens=1536, seed=17, hea
     say(f"checkpoint + model: {time.time() - t0:.1f} s")
     gen = torch.Generator().manual_seed(seed)
     cache = ExLlamaCache(model)
-    seq = torch.randint(1, dims.vocab_size, (4,), generator=gen).tolist()
-    lg = model.forward(torch.tensor([seq], device=device), cache)
-    if not bool(torch.isfinite(lg).all()):
-        raise RuntimeError(f"the synthetic model's logits are not finite after {len(seq)} tokens (zeros={zeros!r}, {layers} layers): "
-                           "its activations left the fp16 range -- not a checkpoint to measure perplexity on")
-    if dims.head_dim == 128:
-        model.enable_decode_graph(cache)                              # the sampling loop on the executor's graph
-    while len(seq) < tokens:
-        nxt = int(torch.multinomial(torch.softmax(lg[0, -1].float().cpu(), -1), 1, generator=gen))
-        seq.append(nxt)
-        lg = model.forward(torch.tensor([[nxt]], device=device), cache)
-    sampled_on = model.decode_path_report(cache)["tier"]
-    model.disable_decode_graph()
-    ids = torch.tensor([seq])
+    if text is not None:
+        ids = torch.as_tensor(np.asarray(text), dtype=torch.long).view(1, -1)
+        assert ids.shape[1] == tokens, (ids.shape, tokens)
+        sampled_on = "fixture"
+    else:
+        seq = torch.randint(1, dims.vocab_size, (4,), generator=gen).tolist()
+        lg = model.forward(torch.tensor([seq], device=device), cache)
+        if not bool(torch.isfinite(lg).all()):
+            raise RuntimeError(f"the synthetic model's logits are not finite after {len(seq)} tokens (zeros={zeros!r}, {layers} layers): "
+                               "its activations left the fp16 range -- not a checkpoint to measure perplexity on")
+        if dims.head_dim == 128:
+            model.enable_decode_graph(cache)                          # the sampling loop on the executor's graph
+        while len(seq) < tokens:
+            nxt = int(torch.multinomial(torch.softmax(lg[0, -1].float().cpu(), -1), 1, generator=gen))
+            seq.append(nxt)
+            lg = model.forward(torch.tensor([[nxt]], device=device), cache)
+        sampled_on = model.decode_path_report(cache)["tier"]
+        model.disable_decode_graph()
+        ids = torch.tensor([seq])
     p = Perplexity(model=model, cache=ExLlamaCache(model))
     p.add_tokens(ids.to(device), chunk_size=tokens, overlap=0)
     whole = p.test(quiet=True)

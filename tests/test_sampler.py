@@ -160,6 +160,28 @@ def test_device_sampler_matches_the_oracle_token_for_token():
 
 
 @pytest.mark.gpu
+def test_device_sampler_whole_vocabulary_sort_beyond_65536_entries():
+    """Round 5's whole-vocabulary sort (top_k = 0 / > 1024) held 65536 entries; its workspace now grows with the vocabulary: Llama-3's
+    128256 tokens and a ragged 70001, against the oracle of the reference's sample() (generator.py:91-170), and a second, smaller
+    vocabulary afterwards (the workspace is only ever grown)."""
+    from exllama_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(7)
+    for V in (128256, 70001, 32000):
+        for kw in (dict(top_k=0), dict(top_k=0, temperature=1.5, top_p=0.9, min_p=0.0001), dict(top_k=5000, top_p=0.0, rep_penalty_max=1.0),
+                   dict(top_k=0, top_p=0.0, typical=0.5)):
+            logits = (rs.randn(V) * rs.uniform(1.0, 5.0)).astype(np.float32)
+            hist = rs.randint(0, V, size=300)
+            u = float(rs.rand())
+            got, got_p = _device_sample(lib, logits, hist, _lib.ExlSampler(**kw), u, 400)
+            want, want_p, idx, probs = S.sample(logits, hist, u=u, **{**dict(temperature=0.95, top_k=40, top_p=0.65), **kw})
+            if got != want:
+                assert S.boundary_distance(probs, u) < 1e-5, (V, kw, got, want, u)
+            else:
+                assert abs(got_p - want_p) <= 1e-5 * max(1.0, want_p)
+
+
+@pytest.mark.gpu
 def test_generate_sample_inside_the_graph_equals_the_host_loop():
     """model.generate_sample: decode kernels + sampler in one replayed graph per token.  The tokens must be the ones the oracle
     sampler picks from the logits an ordinary forward pass produces for the same history and the same draws."""
