@@ -648,13 +648,24 @@ __global__ __launch_bounds__(GR_WAVES * 64) void q4_gemm_t16g_kernel(const GrArg
                     if (it >= ITEMS) continue;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) vv[ct][n][j] = 0.f;
-                    for (int z = 0; z < ks; ++z) {
-                        const float* d = all + ((size_t) z * PER + (size_t) ((cw * OCT + ct) * ITEMS + it)) * 8;
-                        f32x4 p0, p1;                                 // (sc1: past this CU's and this XCD's caches)
-                        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
-                                     : "=&v"(p0), "=&v"(p1) : "v"(d) : "memory");
-                        vv[ct][n][0] += p0[0]; vv[ct][n][1] += p0[1]; vv[ct][n][2] += p0[2]; vv[ct][n][3] += p0[3];
-                        vv[ct][n][4] += p1[0]; vv[ct][n][5] += p1[1]; vv[ct][n][6] += p1[2]; vv[ct][n][7] += p1[3];
+                    for (int z0 = 0; z0 < ks; z0 += 4) {              // four slices per round trip (sc1: past this CU's and this XCD's caches)
+                        const float* d[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            d[u] = all + ((size_t) (z0 + u < ks ? z0 + u : ks - 1) * PER + (size_t) ((cw * OCT + ct) * ITEMS + it)) * 8;
+                        f32x4 q[8];
+                        asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+                                     "global_load_dwordx4 %2, %9, off sc1\n\tglobal_load_dwordx4 %3, %9, off offset:16 sc1\n\t"
+                                     "global_load_dwordx4 %4, %10, off sc1\n\tglobal_load_dwordx4 %5, %10, off offset:16 sc1\n\t"
+                                     "global_load_dwordx4 %6, %11, off sc1\n\tglobal_load_dwordx4 %7, %11, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                                     : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
+                                     : "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]) : "memory");
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (z0 + u < ks) {                        // (in the order of the K ranges)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) { vv[ct][n][j] += q[2 * u][j]; vv[ct][n][4 + j] += q[2 * u + 1][j]; }
+                            }
                     }
                 }
             });
