@@ -602,6 +602,36 @@ def main():
         tiers["unit"] = "tokens/s; wall clock around %d tokens incl. host time, context %d.. (worst) / 4.. (best)" % (G, S)
         result["host_argmax_loop"] = tiers
 
+        # ---- batch > 1 (the reference's batched / CFG / beam generators call forward with bsz > 1, model.py:528): outside the executor
+        # (batch 1 only) -- the general op path, q4_matmul at 2 .. 8 rows + attention per layer from Python.  Measured, so that the tier
+        # has a number: sequences x tokens per second at context S (the K / V rows behind the position are whatever the cache holds:
+        # a rate measurement, no text), 16 steps after 4 warm ones.
+        if not args.brief:
+            from exllama_amd.model import ExLlamaCache as _Cache
+            batched = {}
+            try:
+                for bsz in (2, 4, 8):
+                    bc = _Cache(model, batch_size=bsz)
+                    tok = torch.randint(1, 31999, (bsz, 1), device=dev)
+                    bc.current_seq_len = S
+                    for _ in range(4):
+                        lg = model.forward(tok, bc)
+                        bc.current_seq_len = S
+                    torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    for i in range(16):
+                        lg = model.forward(tok, bc)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t
+                    batched["bsz_%d" % bsz] = {"steps_per_s": round(16 / dt, 2), "tokens_per_s_all_sequences": round(16 * bsz / dt, 1),
+                                              "logits_finite": bool(torch.isfinite(lg).all())}
+                    del bc, lg
+                    torch.cuda.empty_cache()
+                batched["tier"] = "ops_general (decode_path_report): no executor for batch > 1; context %d .. %d" % (S, S + 16)
+            except Exception as e:                                    # noqa: BLE001  (never let this leg take the headline with it)
+                batched["error"] = "%s: %s" % (type(e).__name__, e)
+            result["batched_decode"] = batched
+
     # ---- whole-path roofline fractions (algorithmic bytes / flops) ------------------------------
     full = synth.LlamaDims(dims.hidden_size, dims.intermediate_size, L, dims.num_attention_heads, dims.num_key_value_heads,
                            dims.vocab_size)
