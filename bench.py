@@ -627,7 +627,7 @@ def main():
                                               "logits_finite": bool(torch.isfinite(lg).all())}
                     del bc, lg
                     torch.cuda.empty_cache()
-                batched["tier"] = "ops_general (decode_path_report): no executor for batch > 1; context %d .. %d" % (S, S + 16)
+                batched["tier"] = "%s (decode_path_report): no executor for batch > 1; context %d .. %d" % (getattr(model, "_last_path", "?"), S, S + 16)
             except Exception as e:                                    # noqa: BLE001  (never let this leg take the headline with it)
                 batched["error"] = "%s: %s" % (type(e).__name__, e)
             result["batched_decode"] = batched

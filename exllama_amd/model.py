@@ -420,7 +420,8 @@ class ExLlamaDecoderLayer:
             normed = self.post_attention_layernorm.forward(hidden_states, buffer)
             self.mlp.forward_residual(normed, hidden_states, lora)
             return hidden_states
-        if 2 <= rows <= 256 and self._short_prompt(hidden_states, cache, buffer, lora):
+        self.took_layer_call = 2 <= rows <= 256 and self._short_prompt(hidden_states, cache, buffer, lora)
+        if self.took_layer_call:
             return hidden_states
         if cfg.fused_attn and rows == 1:
             self.self_attn.fused(hidden_states, cache, buffer, self.input_layernorm, lora)
@@ -739,8 +740,6 @@ class ExLlama:
                 and input_mask is None and not preprocess_only and st["has_embed"] and st["has_head"]):
             self._count_path(self._executor_tier(st))
             return self._decode_step(input_ids, cache, str(output_device))
-        if seq_len == 1:
-            self._count_path(self._op_tier(bsz))
         devs = cfg.device_map.get_layers_devs()
 
         buffer = ExLlamaBuffer(cfg)
@@ -761,6 +760,11 @@ class ExLlama:
 
         hidden = self.embed(input_ids)
         hidden = self.forward_layers(hidden, cache, buffers, lora)
+        if seq_len == 1:                                              # (counted by what the layers DID: the layer call reports per layer)
+            took = bsz > 1 and all(getattr(l, "took_layer_call", False) for l in self.layers)
+            if bsz > 1:
+                self._layer_call_seen = took
+            self._count_path("layer_call" if took else ("ops_fused" if cfg.tp is None and cfg.fused_attn and bsz == 1 else "ops_general"))
         cache.current_seq_len += seq_len
         if preprocess_only:
             return None
@@ -829,6 +833,8 @@ class ExLlama:
         "executor_eager": "native decode executor, eager launches (5 per layer + head)",
         "executor_pieces_tp": "native decode executor in half-layer pieces, the residual stream all-reduced between them (tensor parallel)",
         "ops_fused": "op by op: q4_attn -> attention -> q4_attn_2 -> q4_mlp per layer (the reference's fused decode ops, model.py:524-552)",
+        "layer_call": "batch 2 .. 256, one token each: ONE native call per layer (exl_q4_layer_prompt: the short-prompt launches on "
+                      "fragment-order activations, csrc/q4_gemm_frag.hip) -- no adapter, bias, mask or tensor-parallel shard",
         "ops_general": "op by op, general path: norm, q/k/v projections, RoPE, cache update, attention, o_proj, norm, gate/up, SiLU, down "
                        "(batched generation, fused_attn off, or a tensor-parallel shard outside the executor; <= fused_mlp_thd rows still "
                        "take q4_mlp for the MLP half, as in the reference)",
@@ -844,10 +850,13 @@ class ExLlama:
             return "executor_pieces_tp"
         return "executor_graph" if st["graph"] is not None else "executor_eager"
 
-    def _op_tier(self, bsz):
+    def _op_tier(self, bsz, lora=None):
         cfg = self.config
         if cfg.tp is None and cfg.fused_attn and bsz == 1:
             return "ops_fused"
+        if cfg.tp is None and 2 <= bsz <= 256 and lora is None and not os.environ.get("EXL_GEMM_NO_FRAG") and \
+                getattr(self, "_layer_call_seen", True):              # (what ExLlamaDecoderLayer.forward tries first; False once a layer refused)
+            return "layer_call"
         return "ops_general"
 
     def executor_obstacles(self, batch_size=1, lora=None):
@@ -885,7 +894,7 @@ class ExLlama:
         bsz = batch_size if batch_size is not None else (cache.batch_size if cache is not None else 1)
         on_executor = (st is not None and (cache is None or cache is st["cache"]) and bsz == 1 and lora is st.get("lora")
                        and st["has_embed"] and st["has_head"])
-        tier = self._executor_tier(st) if on_executor else self._op_tier(bsz)
+        tier = self._executor_tier(st) if on_executor else self._op_tier(bsz, lora)
         why = []
         if not on_executor:
             obstacles = self.executor_obstacles(bsz, lora)
