@@ -876,7 +876,8 @@ static int gr_gshift(const Q4Matrix* w)
     return (1 << sh) == gp ? sh : -1;
 }
 
-static bool g_gr_dry = false;                                       // gemm_t16r_covers: run the launcher's tests, launch nothing
+static thread_local bool g_gr_dry = false;                          // gemm_t16r_covers: run the launcher's tests, launch nothing (per thread:
+                                                                     // another host thread's real launch must not see it)
 
 template <int MT, int CT, int EPI>
 static int gr_go(GrArgs& a, int rows, int col_groups, hipStream_t s)
@@ -1057,8 +1058,6 @@ int launch_gemm_t16r(int nmat, const Q4Matrix* const* w, const void* xf, int row
 // Would launch_gemm_t16r take this launch?  (The layer entry point asks for all four of its GEMMs BEFORE it enqueues anything.)
 bool gemm_t16r_covers(int nmat, const Q4Matrix* const* w, int rows, int dual)
 {
-    static std::mutex lock;
-    std::lock_guard<std::mutex> hold(lock);
     g_gr_dry = true;
     const int r = launch_gemm_t16r(nmat, w, nullptr, rows, nullptr, 0, dual, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0);
     g_gr_dry = false;
