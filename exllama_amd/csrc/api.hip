@@ -576,9 +576,17 @@ extern "C" int exl_q4_layer_prompt(void* x, int bsz, int q_len, int past_len, co
     if (r) return r;
     EXL_TRY(launch_rope_qk_cache(q, k, v, (f16*) key_cache, (f16*) value_cache, (const f16*) sin, (const f16*) cos, bsz, q_len, heads, kv_heads,
                                  head_dim, max_seq_len, past_len, nullptr, s));
-    EXL_TRY(launch_attention(q, (const f16*) key_cache, (const f16*) value_cache, attn, nullptr, bsz, q_len, heads, kv_heads, head_dim, max_seq_len,
-                             past_len, nullptr, ws, exl_buffers(m[0]->device)->workspace_floats, s));
-    EXL_TRY(launch_to_frag(attn, nullptr, 0.f, m[3]->x_map, af, rows, qd, s));
+    // the MFMA attention kernels store their output in o_proj's fragment order themselves (no act-order map on o_proj: nothing to gather);
+    // otherwise -- fewer than 16 query rows, another head_dim, a map -- row-major, then the re-tile launch
+    static const bool no_attn_frag = getenv("EXL_ATTN_NO_FRAG") != nullptr;          // A/B switch
+    if (q_len >= 16 && head_dim == 128 && !m[3]->x_map && !no_attn_frag) {
+        EXL_TRY(launch_flash_prefill(q, (const f16*) key_cache, (const f16*) value_cache, (f16*) af, bsz, q_len, heads, kv_heads, head_dim, max_seq_len,
+                                     past_len, s, 1));
+    } else {
+        EXL_TRY(launch_attention(q, (const f16*) key_cache, (const f16*) value_cache, attn, nullptr, bsz, q_len, heads, kv_heads, head_dim, max_seq_len,
+                                 past_len, nullptr, ws, exl_buffers(m[0]->device)->workspace_floats, s));
+        EXL_TRY(launch_to_frag(attn, nullptr, 0.f, m[3]->x_map, af, rows, qd, s));
+    }
     f16* o_out[1] = {xh};
     int o_slots = 0;
     r = launch_gemm_t16r(1, om, af, rows, o_out, 1, 0, nullptr, s, 0, osq, &o_slots, kws, b_ks / 4);

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restri
 }
 
 int launch_flash_prefill(const f16* q, const f16* kc, const f16* vc, f16* out, int bsz, int q_len, int heads,
-                         int kv_heads, int hd, int max_seq, int past_len, hipStream_t s);
+                         int kv_heads, int hd, int max_seq, int past_len, hipStream_t s, int frag);
 
 int launch_attention(const f16* q, const f16* kc, const f16* vc, f16* out, const f16* mask, int bsz, int q_len,
                      int heads, int kv_heads, int hd, int max_seq, int past_len, const int32_t* past_len_dev,
@@ -168,7 +168,7 @@ int launch_attention(const f16* q, const f16* kc, const f16* vc, f16* out, const
 
     // long prompts without an explicit mask: MFMA flash kernel
     if (q_len >= 16 && !mask && !past_len_dev && hd == 128)
-        return launch_flash_prefill(q, kc, vc, out, bsz, q_len, heads, kv_heads, hd, max_seq, past_len, s);
+        return launch_flash_prefill(q, kc, vc, out, bsz, q_len, heads, kv_heads, hd, max_seq, past_len, s, 0);
 
     // grid sizing uses the host position; with a device-side position it is an upper bound
     const int kv_max = past_len_dev ? max_seq : past_len + q_len;

@@ -139,6 +139,10 @@ int launch_dec_sample(float* logits, float* probs, int64_t* history, int64_t* to
 int launch_embedding(const int64_t* ids, const f16* table, f16* out, int n_ids, int hidden, int vocab, hipStream_t s);
 int launch_head_rows(const f16* x, const f16* w, float* out, int rows, int hidden, int vocab, hipStream_t s);   // 1 = not covered
 int launch_head_gemm(const f16* x, const f16* w, float* out, int rows, int hidden, int vocab, hipStream_t s);   // 1 = not covered; half_gemm_nt.hip
+// flash_prefill.hip: the MFMA prompt attention (head_dim 128, q_len >= 16, no mask); frag = 1: the output in the fragment order of
+// q4_gemm_frag.hip (rows = bsz * q_len, K = heads * 128; `out` holds frag_bytes(rows, heads * 128))
+int launch_flash_prefill(const f16* q, const f16* kc, const f16* vc, f16* out, int bsz, int q_len, int heads, int kv_heads, int hd, int max_seq,
+                         int past_len, hipStream_t s, int frag);
 // q4_gemm_frag.hip: short-prompt GEMMs on fragment-order activations
 size_t frag_bytes(int rows, int K);
 int launch_to_frag(const f16* x, const f16* norm_w, float eps, const uint32_t* x_map, void* xf, int rows, int K, hipStream_t s,

@@ -66,7 +66,7 @@ __device__ __forceinline__ FaFragOffsets fa_frag_offsets(int c, int g)
 __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const f16* __restrict__ q, const f16* __restrict__ kc,
                                                             const f16* __restrict__ vc, f16* __restrict__ out,
                                                             int q_len, int heads, int kv_heads, int max_seq,
-                                                            int past_len, float c1 /* scale * log2(e) */)
+                                                            int past_len, float c1 /* scale * log2(e) */, int frag)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[FA_BKV * FA_HD * 2 * 2];
     unsigned char* k_lds = lds;
@@ -264,6 +264,11 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const f16* __rest
     if (qrow >= q_len) return;
     const float inv = 1.0f / l_tot;
     f16* op = out + (((size_t) b * q_len + qrow) * heads + h) * FA_HD;
+    // frag: the output in the FRAGMENT ORDER the short-prompt o_proj GEMM reads (q4_gemm_frag.hip; K = heads * 128: head h is row-block h,
+    // d = 32 dt + 8 rq + 4 g + e is k-group dt, MFMA rq): the 8 bytes below land at halves 4 g .. of piece (row / 16, 4 h + rq), lane
+    // 16 dt + row % 16 -- the re-tile launch between attention and o_proj (5-6 us in the chain of a layer) is not needed
+    const size_t R = (size_t) b * q_len + qrow;
+    f16* fp = out + ((((R >> 4) * (size_t) (heads * 4) + (size_t) (4 * h)) * 64 + (R & 15)) * 8 + 4 * g);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -271,7 +276,8 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_kernel(const f16* __rest
             f16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (f16) (acc_o[dt][rq * 4 + e] * inv);
-            *(f16x4*) (op + dt * 32 + 8 * rq + 4 * g) = o;
+            if (frag) *(f16x4*) (fp + (size_t) (rq * 64 + dt * 16) * 8) = o;
+            else *(f16x4*) (op + dt * 32 + 8 * rq + 4 * g) = o;
         }
 }
 
@@ -303,7 +309,7 @@ typedef __fp16 fa_h4 __attribute__((__vector_size__(8)));
 __global__ __launch_bounds__(512) void flash_prefill8_kernel(const f16* __restrict__ q, const f16* __restrict__ kc,
                                                              const f16* __restrict__ vc, f16* __restrict__ out,
                                                              int q_len, int heads, int kv_heads, int max_seq,
-                                                             int past_len, float c1 /* scale * log2(e) */)
+                                                             int past_len, float c1 /* scale * log2(e) */, int frag)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     const uint32_t lds_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) unsigned char*) lds8;
@@ -545,6 +551,11 @@ __global__ __launch_bounds__(512) void flash_prefill8_kernel(const f16* __restri
     if (qrow >= q_len) return;
     const float inv = 1.0f / l_tot;
     f16* op = out + (((size_t) b * q_len + qrow) * heads + h) * FA_HD;
+    // frag: the output in the FRAGMENT ORDER the short-prompt o_proj GEMM reads (q4_gemm_frag.hip; K = heads * 128: head h is row-block h,
+    // d = 32 dt + 8 rq + 4 g + e is k-group dt, MFMA rq): the 8 bytes below land at halves 4 g .. of piece (row / 16, 4 h + rq), lane
+    // 16 dt + row % 16 -- the re-tile launch between attention and o_proj (5-6 us in the chain of a layer) is not needed
+    const size_t R = (size_t) b * q_len + qrow;
+    f16* fp = out + ((((R >> 4) * (size_t) (heads * 4) + (size_t) (4 * h)) * 64 + (R & 15)) * 8 + 4 * g);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -552,12 +563,13 @@ __global__ __launch_bounds__(512) void flash_prefill8_kernel(const f16* __restri
             f16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (f16) (acc_o[dt][rq * 4 + e] * inv);
-            *(f16x4*) (op + dt * 32 + 8 * rq + 4 * g) = o;
+            if (frag) *(f16x4*) (fp + (size_t) (rq * 64 + dt * 16) * 8) = o;
+            else *(f16x4*) (op + dt * 32 + 8 * rq + 4 * g) = o;
         }
 }
 
 int launch_flash_prefill(const f16* q, const f16* kc, const f16* vc, f16* out, int bsz, int q_len, int heads,
-                         int kv_heads, int hd, int max_seq, int past_len, hipStream_t s)
+                         int kv_heads, int hd, int max_seq, int past_len, hipStream_t s, int frag)
 {
     EXL_REQUIRE(hd == FA_HD, EXL_E_UNSUPPORTED, "flash prefill: head_dim must be 128 (got %d)", hd);
     const float c1 = (1.0f / sqrtf((float) hd)) * 1.4426950408889634f;
@@ -572,14 +584,14 @@ int launch_flash_prefill(const f16* q, const f16* kc, const f16* vc, f16* out, i
     const bool four_waves = four_waves_env || (q_len <= FA_BQ && past_len + q_len <= 4 * FA_BKV);
     if (four_waves) {
         hipLaunchKernelGGL(flash_prefill_kernel, grid, dim3(256), 0, s, q, kc, vc, out, q_len, heads, kv_heads, max_seq,
-                           past_len, c1);
+                           past_len, c1, frag);
         EXL_LAUNCH_CHECK();
         return 0;
     }
     static bool big[EXL_MAX_DEVICES] = {};
     EXL_TRY(exl_lds_opt_in((const void*) flash_prefill8_kernel, big));
     hipLaunchKernelGGL(flash_prefill8_kernel, grid, dim3(512), FA8_LDS_BYTES, s, q, kc, vc, out, q_len, heads, kv_heads, max_seq,
-                       past_len, c1);
+                       past_len, c1, frag);
     EXL_LAUNCH_CHECK();
     return 0;
 }

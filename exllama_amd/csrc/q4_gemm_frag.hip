@@ -983,7 +983,9 @@ int launch_gemm_t16r(int nmat, const Q4Matrix* const* w, const void* xf, int row
     // (force, the op-level entry point's kernel choice for tests and A/B runs: 0 as above, 1 the narrow kernel, 2 the wide kernel at any
     // width, 3 / 4 / 5 its <4, 4> / <4, 2> / <8, 4> block shape, 7 .. 10 <1, 4> / <1, 2> / <2, 4> / <2, 2>)
     const int mt_fit = rows <= 16 ? 1 : rows <= 32 ? 2 : rows <= 64 ? 4 : 8;
-    if ((!no_g && force == 0) || (force >= 2 && force <= 5) || (force >= 7 && force <= 10)) {
+    // (EXL_GEMM_SMALL_NARROW=1, an A/B switch: prompts of up to 32 rows on the narrow kernel for EVERY launch -- the decode GEMV's shape)
+    static const bool small_narrow = getenv("EXL_GEMM_SMALL_NARROW") != nullptr;
+    if ((!no_g && force == 0 && !(small_narrow && mt_fit <= 2)) || (force >= 2 && force <= 5) || (force >= 7 && force <= 10)) {
         const int units = dual ? w[0]->width / 16 : (tiles + 1) / 2;  // what one wave owns: a gate + an up tile / two tiles
         const long need = force ? 0 : g_min;
         auto blocks = [&](int mt, int ncw) { return (long) ((rows + mt * 16 - 1) / (mt * 16)) * ((units + ncw - 1) / ncw); };
@@ -1037,6 +1039,7 @@ int launch_gemm_t16r(int nmat, const Q4Matrix* const* w, const void* xf, int row
     // (tiles / CT) x rows x K x 2 bytes through the CUs' L1s, the weight expansion is repeated by every row group.
     const int nrg = (rows + 63) / 64;
     if (dual) {
+        if (mt_fit <= 2) return mt_fit == 1 ? gr_go<1, 2, 1>(a, rows, w[0]->width / 16, s) : gr_go<2, 2, 1>(a, rows, w[0]->width / 16, s);
         if (w[0]->width % 32 != 0) return 1;                          // two gate + two up tiles per block
         return gr_go<4, 4, 1>(a, rows, w[0]->width / 32, s);
     }
