@@ -270,6 +270,7 @@ FRAG_CASES = [
     (8192, (8192, 1024, 1024), 128, False, False, True),        # 70B GQA: matrices of different widths in one launch
     (512, (640, 640), 64, False, True, True),                   # 4 row-blocks: one step per K-group of four (a consumer's K is a multiple of 128)
     (384, (352,), 32, False, False, False),                     # 3 row-blocks (an empty last step), 22 tiles
+    (9216, (256,), 128, True, False, True),                     # K > 8192: the norm's whole-row pass re-reads instead of holding the row in registers
 ]
 
 
