@@ -42,6 +42,19 @@ struct GrArgs {
     int rowsq_stride;             // columns of slot (a column group / column-wave): the RMSNorm behind this launch adds the slots up (to_frag_kernel)
 };
 
+#ifdef EXL_T16G_PROBE
+// Phase stamps of q4_gemm_t16g's pipelined step (scripts/probe_t16g.py; NOT in the product build): s_memtime of wave 0 and wave NCW (the
+// first wave of each K-group) of blocks 0 and gridDim.x / 2, at the marks below.
+__device__ unsigned long long g_t16g_probe[4][64];
+#define GG_STAMP(i) do { if (pslot >= 0 && (i) < 64) g_t16g_probe[pslot][(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int exl_debug_t16g_probe(unsigned long long* out)
+{
+    return (int) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_t16g_probe), sizeof(unsigned long long) * 4 * 64);
+}
+#else
+#define GG_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 __device__ __forceinline__ void gr_ld16(u32x4& d, uint32_t voff, const void* sbase)   // uniform base + lane offset (L2-resident or re-read: no nt)
 {
@@ -385,9 +398,15 @@ __global__ __launch_bounds__(GR_WAVES * 64) void q4_gemm_t16g_kernel(const GrArg
     constexpr int HALF = MT >= 2 ? MT / 2 : 1;                        // groups that carry slab requests
     constexpr int PPG = (PPW + HALF - 1) / HALF;                      // pieces per such group
     constexpr int WPG = (CT * 4 + MT - 1) / MT;                       // weight words expanded per group
+#ifdef EXL_T16G_PROBE
+    const int pslot = (lane == 0 && (wave == 0 || wave == NCW) && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2))
+                      ? (blockIdx.x == 0 ? 0 : 2) + (wave == 0 ? 0 : 1) : -1;
+#endif
+    GG_STAMP(0);
     auto step = [&](auto set_tag, int s) {
         constexpr int p = decltype(set_tag)::value;                   // s & 1
         constexpr int pn = p ^ 1;
+        if (s < 10) GG_STAMP(2 + 6 * s);                              // step start
         int rbn = rb_of(s + 1), rbw = rb_of(s + 3);
         const bool live_n = rbn < RB;
         rbn = rbn < RB ? rbn : RB - 1;                                // (empty steps request the last row-block again: same counts)
@@ -428,9 +447,14 @@ __global__ __launch_bounds__(GR_WAVES * 64) void q4_gemm_t16g_kernel(const GrArg
                 for (int ct = 0; ct < CT; ++ct)
                     acc[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[g & 1][j], bq[p][ct][j], acc[g][ct], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (g == 0) { if (s < 10) GG_STAMP(3 + 6 * s); }      // first group issued
+            if constexpr (g == HALF - 1) { if (s < 10) GG_STAMP(4 + 6 * s); } // slab requests out
         });
+        if (s < 10) GG_STAMP(5 + 6 * s);                              // all groups issued
         gg_wait<NW_LOADS>(wr[p][0], wr[p][1], zr[p][0], zr[p][1], sr[p][0], sr[p][1]);   // (releases the weights of step s + 2)
+        if (s < 10) GG_STAMP(6 + 6 * s);                              // requests landed
         rg_barrier();
+        if (s < 10) GG_STAMP(7 + 6 * s);                              // barrier passed
     };
     {   // prologue: slab 0, the weights of steps 0 and 1; expand step 0; request step 2
         int r0 = rb_of(0), r1 = rb_of(1), r2 = rb_of(2);
@@ -457,6 +481,7 @@ __global__ __launch_bounds__(GR_WAVES * 64) void q4_gemm_t16g_kernel(const GrArg
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) issue_wt(r2, std::integral_constant<int, 0>{}, ct);
         rg_barrier();
+        GG_STAMP(1);                                                  // prologue done
     }
     for (int s = 0; s < nsteps; s += 2) {                             // (an odd walk ends with one surplus step: scale 0)
         step(std::integral_constant<int, 0>{}, s);
