@@ -290,3 +290,26 @@ def test_compiled_binding_raises_what_the_ctypes_path_raises():
         fast.rms_norm(h, h)
     with pytest.raises(TypeError):
         fast.attention(h, h, h, h, 0, 1, bogus=1)
+
+
+def test_fragment_order_is_what_the_header_says(lib):
+    """include/exl_amd.h (exl_q4_matmul_frag): out_frag[((mt * (K / 32) + 4 rb + j) * 64 + lane) * 16 .. + 16] = act[16 mt + (lane & 15)][128 rb +
+    32 (lane >> 4) + 8 j .. + 8]; exl_frag_bytes pads the rows to 64, from 65 rows on to a multiple of 128.  cuda_ext.unfrag is that
+    formula backwards (the GPU tests read fragment-order outputs through it): held here against the formula itself, on the host."""
+    from exllama_amd import cuda_ext
+    assert lib.exl_frag_bytes(1, 128) == 64 * 128 * 2 and lib.exl_frag_bytes(64, 256) == 64 * 256 * 2
+    assert lib.exl_frag_bytes(65, 128) == 128 * 128 * 2 and lib.exl_frag_bytes(129, 128) == 256 * 128 * 2 and lib.exl_frag_bytes(0, 128) == 0
+    rows, K = 70, 384
+    pad = lib.exl_frag_bytes(rows, K) // (2 * K)
+    act = np.zeros((pad, K), dtype=np.float16)
+    act[:rows] = np.random.RandomState(3).randn(rows, K).astype(np.float16)
+    frag = np.zeros(pad * K, dtype=np.float16)
+    for mt in range(pad // 16):
+        for rb in range(K // 128):
+            for j in range(4):
+                for lane in range(64):
+                    at = ((mt * (K // 32) + 4 * rb + j) * 64 + lane) * 8
+                    k0 = 128 * rb + 32 * (lane >> 4) + 8 * j
+                    frag[at:at + 8] = act[16 * mt + (lane & 15), k0:k0 + 8]
+    back = cuda_ext._ExllamaExt.unfrag(torch.from_numpy(frag).view(torch.uint8), rows, K)
+    assert back.shape == (rows, K) and np.array_equal(back.numpy(), act[:rows])
