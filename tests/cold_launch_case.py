@@ -1,4 +1,4 @@
-"""Child process of tests/test_cold_launch_gpu.py: ONE hand-counted prefill kernel as the first GEMM launch of a fresh process,
+"""Child process of tests/test_cold_launch_gpu.py: ONE hand-counted prompt-pass kernel as the first GEMM launch of a fresh process,
 on memory the allocator hands out poisoned (NaN), with a freshly copied activation tensor and a sentinel-filled output.
 
     python tests/cold_launch_case.py <case> <data.npz>        (environment: the EXL_GEMM_* switch that selects the kernel)
@@ -85,6 +85,25 @@ def main():
         ok &= verdict(case, "q", q[0], d["ref_q"], 2.0)
         ok &= verdict(case, "k", kc[0, :, :rows].permute(1, 0, 2).reshape(rows, kvh * hd), d["ref_k"], 2.0)
         ok &= verdict(case, "v", vc[0, :, :rows].permute(1, 0, 2).reshape(rows, kvh * hd), d["ref_v"], 2.0)
+    elif case in ("t16g_dual", "t16g_dual_small", "t16r"):
+        # round 6: the short-prompt GEMMs on fragment-order activations (csrc/q4_gemm_frag.hip), through exl_q4_matmul_frag
+        h1, k1 = handle(d, "w")
+        N = int(d["w_scales"].shape[1])
+        torch.cuda.synchronize()
+        if case == "t16r":
+            out = torch.full((rows, N), SENT, dtype=torch.float16, device=DEV)
+            assert ext.q4_matmul_frag(x_host.to(DEV), [h1], [out], kernel=1) is not None       # the narrow kernel, cold
+            out_e = torch.empty((rows, N), dtype=torch.float16, device=DEV)
+            assert ext.q4_matmul_frag(x_host.to(DEV), [h1], [out_e], kernel=1) is not None
+            torch.cuda.synchronize()
+            ok &= verdict(case, "cold/sentinel", out, d["ref"], 1.5)
+            ok &= verdict(case, "second/empty", out_e, d["ref"], 1.5)
+        else:
+            h2, k2 = handle(d, "v")
+            got = ext.q4_matmul_frag(x_host.to(DEV), [h1, h2], dual=True, kernel=0)             # the launcher's choice: the wide kernel
+            assert got is not None
+            torch.cuda.synchronize()
+            ok &= verdict(case, "cold", ext.unfrag(got, rows, N), d["ref"], 4.0)
     else:
         raise SystemExit(f"unknown case {case}")
     if ok:

@@ -21,7 +21,7 @@ from oracle import exl_oracle as O
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REPEATS = 4            # processes per kernel: 7 kernels x 4 = 28 cold launches
+REPEATS = 4            # processes per kernel: 10 kernels x 4 = 40 cold launches
 
 #        case       K     N      gs   rows  environment that routes the launch to the kernel
 CASES = {
@@ -32,6 +32,9 @@ CASES = {
     "t16s": (4096, 11008, 128, 128, {}),                                     # q4_gemm_t16s_kernel: short prompts
     "t16d2": (4096, 11008, 128, 700, {}),                                    # q4_gemm_t16d2_kernel: gate / up + SiLU
     "t16w1": (4096, 4096, 128, 600, {}),                                     # q4_gemm_t16w_kernel<1>: q / k / v + RoPE + cache
+    "t16g_dual": (4096, 11008, 128, 128, {}),                                # q4_gemm_t16g_kernel<8,4,1>: short-prompt gate / up + SiLU (LDS-DMA ring, counted vmcnt)
+    "t16g_dual_small": (4096, 11008, 128, 9, {}),                            # q4_gemm_t16g_kernel<1,4,1>: one row tile per block
+    "t16r": (11008, 4096, 128, 100, {}),                                     # q4_gemm_t16r_kernel<4,2,0>: short-prompt down_proj (activations in registers)
 }
 
 
@@ -59,7 +62,7 @@ def test_hand_counted_gemm_kernels_cold(case, tmp_path):
     path = str(tmp_path / f"{case}.npz")
     lin, gen = _lin(K, N, gs, seed=2)
     x = torch.randn(rows, K, generator=gen).half()
-    if case == "t16d2":
+    if case in ("t16d2", "t16g_dual", "t16g_dual_small"):
         lin2, _ = _lin(K, N, gs, seed=3)
         ref = O.silu_mul(O.q4_matmul_recons(x.numpy(), **_ow(lin)), O.q4_matmul_recons(x.numpy(), **_ow(lin2)))
         _save(path, {"x": x.numpy(), "ref": ref}, w=lin, v=lin2)
